@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REFERENCE ITSELF (oracle/_ref, built by `make -C oracle ref`).
+
+Runs only in the build container (needs /root/reference for the build and /opt/conda MPICH to run); the
+resulting fixtures are data only -- inputs (seeded synthetic data + parameter values) and the reference's
+outputs (likelihoodRR.out traces, sample files, proposal_count.txt, direct forward-call known answers,
+RNG vectors).  Nothing of the reference's source text is stored.
+
+    python tests/golden/make_golden.py            # regenerate every fixture
+
+Cases
+  c1        5 ev x  8 stn, seed 0, 2 ranks x 2 chains, 20000 it   (BASELINE config #1 plumbing case)
+  c2      100 ev x 16 stn, seed 2, 1 rank  x 2 chains,  4000 it   (BASELINE config #2; 2 chains: quirk 1)
+  missing   6 ev x 10 stn, seed 7, 5 entries with t_stdv = 0, 1 rank x 3 chains (missing-data rule)
+  timeonly  8 ev x 12 stn, seed 3, use_amp = F, solve_qs = solve_a_corr = F, 3 ranks x 2 chains
+  fixedcorr 7 ev x  9 stn, seed 4, solve_t_corr = solve_vs = F, 2 ranks x 3 chains, n_cool = 2
+  c3     1000 ev x 64 stn, seed 1, 1 rank x 8 chains, 600 it: inputs are NOT stored (2 MB) -- the seeded
+         generator reproduces them; a checksum of the inputs is stored instead.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
+sys.path.insert(0, ROOT)
+from hypotremormcmc_amd import synth  # noqa: E402
+
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "hypo_tremor_mcmc_ref")
+PROBE_BIN = os.path.join(ROOT, "oracle", "_ref", "ref_probe")
+MPIEXEC = "/opt/conda/bin/mpiexec"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+CASES = {
+    "c1": dict(n_events=5, n_sta=8, seed=0, n_missing=0,
+               params=dict(n_procs=2, n_chains=2, n_cool=1, n_iter=20000, n_burn=10000, n_interval=100)),
+    "c2": dict(n_events=100, n_sta=16, seed=2, n_missing=0,
+               params=dict(n_procs=1, n_chains=2, n_cool=1, n_iter=4000, n_burn=2000, n_interval=50)),
+    "missing": dict(n_events=6, n_sta=10, seed=7, n_missing=5,
+                    params=dict(n_procs=1, n_chains=3, n_cool=1, n_iter=6000, n_burn=1000, n_interval=25)),
+    "timeonly": dict(n_events=8, n_sta=12, seed=3, n_missing=0,
+                     params=dict(n_procs=3, n_chains=2, n_cool=1, n_iter=6000, n_burn=3000, n_interval=40,
+                                 use_amp="F", solve_qs="F", solve_a_corr="F")),
+    "fixedcorr": dict(n_events=7, n_sta=9, seed=4, n_missing=0,
+                      params=dict(n_procs=2, n_chains=3, n_cool=2, n_iter=5000, n_burn=0, n_interval=20,
+                                  solve_t_corr="F", solve_vs="F", temp_high="50.0")),
+    "c3": dict(n_events=1000, n_sta=64, seed=1, n_missing=0, store_inputs=False,
+               params=dict(n_procs=1, n_chains=8, n_cool=1, n_iter=600, n_burn=300, n_interval=10)),
+}
+
+
+def checksum(data) -> str:
+    h = hashlib.sha256()
+    for a in (data.sta_x, data.sta_y, data.sta_z, data.t_obs, data.t_stdv, data.a_obs, data.a_stdv):
+        h.update(np.ascontiguousarray(a, dtype="<f8").tobytes())
+    return h.hexdigest()
+
+
+def read_records(path, n_val):
+    dt = np.dtype([("iter", "<i4"), ("val", "<f8", (n_val,))])
+    if not os.path.exists(path) or os.path.getsize(path) == 0:
+        return np.zeros(0, np.int32), np.zeros((0, n_val))
+    a = np.fromfile(path, dtype=dt)
+    return a["iter"].copy(), a["val"].reshape(-1, n_val).copy()
+
+
+def probe(workdir, data, params, n_cases=4):
+    """Known answers straight from the reference's cls_forward / mod_random / cls_obs_data."""
+    E, S = data.n_events, data.n_sta
+    rng = np.random.default_rng(1234 + E + S)
+    tf = lambda v: "T" if str(v).upper().startswith("T") else "F"
+    cases = []
+    with open(os.path.join(workdir, "probe_in.txt"), "w") as f:
+        f.write(f"{S} {E} {tf(params.get('use_time', 'T'))} {tf(params.get('use_amp', 'T'))} {n_cases}\n")
+        for arr in (data.sta_x, data.sta_y, data.sta_z):
+            f.write(" ".join("%.17g" % v for v in arr) + "\n")
+        for k in range(n_cases):
+            hypo = data.ev_xyz + rng.normal(0, 2.0, data.ev_xyz.shape)
+            hypo[:, 2] = np.abs(hypo[:, 2]) + 0.5
+            hypo = hypo.reshape(-1)
+            tc = rng.normal(0, 0.3, S)
+            ac = rng.normal(0, 0.02, S)
+            vs = 3.0 + rng.normal(0, 0.3)
+            qs = 250.0 + rng.normal(0, 40.0)
+            evt = int(rng.integers(1, E + 1))
+            xyz = hypo[3 * (evt - 1):3 * evt] + rng.normal(0, 1.0, 3)
+            xyz[2] = abs(xyz[2]) + 0.1
+            cases.append(dict(hypo=hypo, t_corr=tc, a_corr=ac, vs=vs, qs=qs, evt_id=evt, xyz=xyz))
+            f.write(" ".join("%.17g" % v for v in hypo) + "\n")
+            f.write(" ".join("%.17g" % v for v in tc) + "\n")
+            f.write("%.17g\n" % vs)
+            f.write(" ".join("%.17g" % v for v in ac) + "\n")
+            f.write("%.17g\n" % qs)
+            f.write("%d\n" % evt)
+            f.write(" ".join("%.17g" % v for v in xyz) + "\n")
+    subprocess.check_call([PROBE_BIN], cwd=workdir, stdout=subprocess.DEVNULL)
+    toks = open(os.path.join(workdir, "probe_out.txt")).read().split()
+    pos = 0
+    out = {}
+    rngv = np.empty((4, 12))
+    for r in range(4):
+        assert toks[pos] == "rng" and toks[pos + 1] == "rank"
+        pos += 3
+        rngv[r] = [float(t) for t in toks[pos:pos + 12]]
+        pos += 12
+    out["probe_rng"] = rngv
+    assert toks[pos] == "initial_guess"
+    pos += 1
+    out["probe_xy_mu"] = np.array([float(t) for t in toks[pos:pos + 2 * E]]).reshape(E, 2)
+    pos += 2 * E
+    L = np.empty((n_cases, 3))
+    for k in range(n_cases):
+        assert toks[pos] == "case"
+        pos += 2
+        L[k] = [float(t) for t in toks[pos:pos + 3]]
+        pos += 3
+        if k == 0:
+            for name, n in (("t_syn", S * E), ("a_syn", S * E), ("t_syn_single", S), ("a_syn_single", S)):
+                assert toks[pos] == name, (toks[pos], name)
+                pos += 1
+                out["probe_" + name] = np.array([float(t) for t in toks[pos:pos + n]])
+                pos += n
+    out["probe_L"] = L
+    for key in ("hypo", "t_corr", "a_corr", "xyz"):
+        out["probe_in_" + key] = np.array([c[key] for c in cases])
+    out["probe_in_vs"] = np.array([c["vs"] for c in cases])
+    out["probe_in_qs"] = np.array([c["qs"] for c in cases])
+    out["probe_in_evt_id"] = np.array([c["evt_id"] for c in cases], dtype=np.int32)
+    return out
+
+
+def run_case(name, spec):
+    data = synth.make_synthetic(spec["n_events"], spec["n_sta"], spec["seed"], spec["n_missing"])
+    work = tempfile.mkdtemp(prefix="htm_golden_")
+    try:
+        synth.write_dataset(work, data)
+        params = synth.write_param_file(os.path.join(work, "run.in"), **spec["params"])
+        n_procs = int(params["n_procs"])
+        subprocess.check_call([MPIEXEC, "-np", str(n_procs), REF_BIN, "run.in"], cwd=work,
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        E, S = data.n_events, data.n_sta
+        fx = {}
+        for r in range(n_procs):
+            it, v = read_records(os.path.join(work, "likelihood%02d.out" % r), 1)
+            fx[f"lik_iter_{r}"] = it
+            fx[f"lik_{r}"] = v[:, 0]
+            for nm, nv in (("vs", 1), ("qs", 1), ("t_corr", S), ("a_corr", S), ("hypo", 3 * E)):
+                it, v = read_records(os.path.join(work, "%s.%02d.out" % (nm, r)), nv)
+                if name == "c3" and nm == "hypo":
+                    v = v[-2:]  # keep the fixture small: last two hypocentre samples only
+                    it = it[-2:]
+                fx[f"{nm}_iter_{r}"] = it
+                fx[f"{nm}_{r}"] = v
+        rows = [ln.split('"') for ln in open(os.path.join(work, "proposal_count.txt"))]
+        fx["count_labels"] = np.array([r[1] for r in rows])
+        fx["n_propose"] = np.array([int(r[2].split()[0]) for r in rows], dtype=np.int64)
+        fx["n_accept"] = np.array([int(r[2].split()[1]) for r in rows], dtype=np.int64)
+        if spec.get("store_inputs", True):
+            fx.update(probe(work, data, params))
+            for key in ("sta_x", "sta_y", "sta_z", "t_obs", "t_stdv", "a_obs", "a_stdv", "ev_xyz"):
+                fx["in_" + key] = getattr(data, key)
+        fx["in_checksum"] = np.array(checksum(data))
+        fx["in_seed"] = np.array(spec["seed"])
+        fx["in_n_missing"] = np.array(spec["n_missing"])
+        fx["in_shape"] = np.array([E, S])
+        fx["param_keys"] = np.array(list(params.keys()))
+        fx["param_vals"] = np.array([str(v) for v in params.values()])
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **fx)
+        print(name, "ok:", {k: (v.shape if hasattr(v, "shape") else v) for k, v in fx.items()
+                            if k.startswith("lik_") and not k.startswith("lik_iter")})
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    if not (os.path.exists(REF_BIN) and os.path.exists(PROBE_BIN)):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
+    for nm in (sys.argv[1:] or list(CASES)):
+        run_case(nm, CASES[nm])

@@ -1,0 +1,86 @@
+"""CPU: pin the oracle (oracle/htm_oracle.c) against fixtures produced by the compiled reference.
+
+The reference has no tests of its own; tests/golden/*.npz were produced by running the
+unmodified reference (oracle/_ref, AMD flang) -- see tests/golden/make_golden.py.  The restatement is
+expected to be BIT-IDENTICAL (same libm, same operation order), which is what is asserted.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests.helpers import CASES, load_case, tf
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_trace_counts_and_samples_match_reference(name):
+    fx, data, params = load_case(name)
+    job = oracle.Job(params, data)
+    job.run(int(params["n_iter"]))
+    for r in range(int(params["n_procs"])):
+        it, lk = job.likelihood_trace(r)
+        assert np.array_equal(it, fx[f"lik_iter_{r}"])
+        assert np.array_equal(lk, fx[f"lik_{r}"])          # bit-exact
+        smp = job.samples(r)
+        assert np.array_equal(smp["iter"], fx[f"vs_iter_{r}"])
+        assert np.array_equal(smp["vs"], fx[f"vs_{r}"][:, 0])
+        assert np.array_equal(smp["qs"], fx[f"qs_{r}"][:, 0])
+        assert np.array_equal(smp["t_corr"], fx[f"t_corr_{r}"])
+        assert np.array_equal(smp["a_corr"], fx[f"a_corr_{r}"])
+        n_h = len(fx[f"hypo_{r}"])
+        if n_h:
+            assert np.array_equal(smp["hypo"][-n_h:], fx[f"hypo_{r}"])
+    npr, nac = job.counts()
+    assert np.array_equal(npr, fx["n_propose"])
+    assert np.array_equal(nac, fx["n_accept"])
+    # quirk 2: labels as the reference writes them, cut to 5 characters
+    assert [s.strip() for s in fx["count_labels"].tolist()] == ["vs", "t_cor", "qs", "a_cor", "x", "y", "z"]
+
+
+@pytest.mark.parametrize("name", [c for c in CASES if c != "c3"])
+def test_forward_known_answers(name):
+    fx, data, params = load_case(name)
+    f = oracle.Forward(data.sta_x, data.sta_y, data.sta_z, data.t_obs, data.t_stdv, data.a_obs, data.a_stdv,
+                       tf(params.get("use_time", "T")), tf(params.get("use_amp", "T")))
+    for k in range(len(fx["probe_L"])):
+        h = fx["probe_in_hypo"][k]; tc = fx["probe_in_t_corr"][k]; ac = fx["probe_in_a_corr"][k]
+        vs = fx["probe_in_vs"][k]; qs = fx["probe_in_qs"][k]; evt = int(fx["probe_in_evt_id"][k])
+        h2 = h.copy(); h2[3 * (evt - 1):3 * evt] = fx["probe_in_xyz"][k]
+        Lf = f.calc_log_likelihood(h, tc, vs, ac, qs)
+        Lp = f.partially_update_log_likelihood(evt, h, Lf, h2, tc, vs, ac, qs)
+        Lm = f.calc_log_likelihood(h2, tc, vs, ac, qs)
+        assert [Lf, Lp, Lm] == fx["probe_L"][k].tolist()
+    h = fx["probe_in_hypo"][0]; tc = fx["probe_in_t_corr"][0]; ac = fx["probe_in_a_corr"][0]
+    vs = fx["probe_in_vs"][0]; qs = fx["probe_in_qs"][0]; evt = int(fx["probe_in_evt_id"][0])
+    assert np.array_equal(f.calc_travel_time(h, tc, vs).reshape(-1), fx["probe_t_syn"])
+    assert np.array_equal(f.calc_amp(h, ac, qs, vs).reshape(-1), fx["probe_a_syn"])
+    assert np.array_equal(f.calc_travel_time_single(evt, h, tc, vs), fx["probe_t_syn_single"])
+    assert np.array_equal(f.calc_amp_single(evt, h, ac, qs, vs), fx["probe_a_syn_single"])
+
+
+def test_rng_golden_vectors():
+    fx, _, _ = load_case("c1")
+    for r in range(4):
+        g = oracle.Rng(r)
+        v = [g.rand_u() for _ in range(8)] + [g.rand_u2(), g.rand_g(), g.rand_r(), g.rand_g()]
+        assert v == fx["probe_rng"][r].tolist()
+    # SURVEY.md §8a vectors (seed state + first draws, ranks 0..2)
+    assert tuple("%08x" % w for w in oracle.Rng(0).state) == ("4b88a366", "1b11733c", "097044b6", "00676ea2")
+    assert tuple("%08x" % w for w in oracle.Rng(1).state) == ("311ce1d7", "6c840a86", "28236c5f", "019ea85d")
+    assert tuple("%08x" % w for w in oracle.Rng(2).state) == ("bcfac056", "f557a69c", "65e6ae26", "03a97ef2")
+    g = oracle.Rng(0)
+    assert [g.rand_u() for _ in range(5)] == [0.55850877496413887, 0.12064291047863662, 0.58295862120576203,
+                                              0.68001799611374736, 0.45020412676967681]
+    g = oracle.Rng(0)
+    assert g.rand_g() == 0.78381228502204603
+    assert g.rand_r() == 1.0388831219960963
+    assert g.rand_u2() == 0.68001799623016268
+
+
+def test_initial_guess_matches_reference():
+    for name in ("c1", "missing"):
+        fx, data, params = load_case(name)
+        job = oracle.Job(params, data)
+        mu, sg, st, pt = job.hypo_priors(0, 0)
+        assert np.array_equal(mu[0::3], fx["probe_xy_mu"][:, 0])
+        assert np.array_equal(mu[1::3], fx["probe_xy_mu"][:, 1])
+        assert set(pt[2::3].tolist()) == {1} and set(pt[0::3].tolist()) == {0}
