@@ -1,0 +1,312 @@
+// htm_device.hpp -- gfx950 device code for the HypoTremorMCMC likelihood inner loop.
+//
+// Written for CDNA4 only: 64-wide wavefronts, DPP cross-lane reductions (row_bcast forms of the GFX9 DPP
+// encoding), fp64 VALU.  No MFMA: the path is elementwise geometry + reductions.
+//
+// Mapping: lane <-> station, wave <-> event (full evaluation) or wave <-> chain (partial
+// update); the station table is staged in LDS once per workgroup and then held in registers, the four
+// observation streams t_obs/t_prec/a_obs/a_prec are read with coalesced 512-B wave loads in the
+// reference's own (n_sta, n_events) column-major layout.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace htm {
+
+constexpr double kPi = 3.141592653589793;        // acos(-1.d0)
+constexpr double kPi2 = 6.283185307179586;       // 2.d0 * acos(-1.d0)   (mod_random.f90:33)
+constexpr double kFreq = 5.0;                    // cls_forward.f90:190
+constexpr double kEps = 2.220446049250313e-16;   // epsilon(1.d0)
+constexpr int kMaxChains = 64;                   // chains per rank held by one k_step workgroup
+constexpr int kMaxWindow = 512;                  // raw RNG draws staged per iteration (>= 6*kMaxChains+64)
+
+// ---------------------------------------------------------------------------------------------------
+// wave-level fp64 sum over 64 lanes, DPP only (no LDS traffic, fixed order => deterministic)
+// ---------------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_mov_f64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double readlane63_f64(double v)
+{
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+
+// N independent sums, interleaved step by step so that the DPP latencies overlap.
+// Must be called with all 64 lanes active; inactive stations contribute 0.
+template <int N>
+__device__ __forceinline__ void wave_sum(double (&v)[N])
+{
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] += dpp_mov_f64<0xB1, 0xF>(v[k]);   // quad_perm [1,0,3,2]
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] += dpp_mov_f64<0x4E, 0xF>(v[k]);   // quad_perm [2,3,0,1]
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] += dpp_mov_f64<0x141, 0xF>(v[k]);  // row_half_mirror
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] += dpp_mov_f64<0x140, 0xF>(v[k]);  // row_mirror
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] += dpp_mov_f64<0x142, 0xA>(v[k]);  // row_bcast:15 -> rows 1,3
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] += dpp_mov_f64<0x143, 0xC>(v[k]);  // row_bcast:31 -> rows 2,3
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = readlane63_f64(v[k]);
+}
+
+__device__ __forceinline__ double wave_sum1(double a)
+{
+    double v[1] = {a};
+    wave_sum<1>(v);
+    return v[0];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// mod_random on the device (reference src/mod_random.f90:60-112)
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t xs128_next(uint32_t &x, uint32_t &y, uint32_t &z, uint32_t &w)
+{
+    uint32_t t = x ^ (x << 11);
+    x = y; y = z; z = w;
+    w = (w ^ (w >> 19)) ^ (t ^ (t >> 8));
+    return w;
+}
+__device__ __forceinline__ double u_of(uint32_t raw)   // rand_u  :72
+{
+    return ((double)(int32_t)raw + 2147483648.0) / 4294967296.0;
+}
+__device__ __forceinline__ double u2_of(uint32_t raw)  // rand_u2 :90
+{
+    return ((double)(int32_t)raw + 2147483648.0 + 0.5) / 4294967296.0;
+}
+__device__ __forceinline__ double g_of(uint32_t raw1, uint32_t raw2)  // rand_g :98-100
+{
+    return sqrt(-2.0 * log(u2_of(raw1))) * cos(kPi2 * u2_of(raw2));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// forward model (reference src/cls_forward.f90)
+// ---------------------------------------------------------------------------------------------------
+struct FwdDev {
+    int S, E, use_time, use_amp;
+    const double *sx, *sy, *sz;                        // [S]
+    const double *t_obs, *t_prec, *a_obs, *a_prec;     // [E][S]  (station fastest)
+    const double *psum_t, *psum_a;                     // [E]  sum_j prec(j,i), summed in station order
+    double const_sum;   // sum over used data types of sum_{j,i} (log_2pi_half + log_stdv(j,i))
+};
+
+template <int NCH>
+struct StaRegs {
+    double sx[NCH], sy[NCH], sz[NCH], tc[NCH], ac[NCH];
+};
+
+// Evaluate NPOS candidate hypocentres of ONE event against all stations of this wave's lanes.
+// Returns per lane: sum over its stations of [time misfit + amp misfit] for each position, where
+// misfit = (obs - (syn - mean))^2 * prec / 2 -- i.e. cls_forward.f90:115-118,:125-132,:283-285 (time) and
+// :201-204,:210-217,:294-296 (amplitude).  The per-event weighted means need one wave reduction per data
+// type and position; those are issued together.  All 64 lanes must call.
+template <int NCH, int NPOS>
+__device__ __forceinline__ void event_misfit(const FwdDev &f, int ev, int lane, const StaRegs<NCH> &st,
+                                             const double (&px)[NPOS], const double (&py)[NPOS],
+                                             const double (&pz)[NPOS], double beta, double q,
+                                             double (&out)[NPOS])
+{
+    const size_t base = (size_t)ev * (size_t)f.S;
+    const double qbeta = q * beta;
+    double tob[NCH], tpr[NCH], aob[NCH], apr[NCH];
+    double ts[NPOS][NCH], as[NPOS][NCH];
+    double red[2 * NPOS];
+#pragma unroll
+    for (int k = 0; k < 2 * NPOS; ++k) red[k] = 0.0;
+
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int j = lane + 64 * c;
+        const bool valid = j < f.S;
+        tob[c] = tpr[c] = aob[c] = apr[c] = 0.0;
+        if (valid) {
+            if (f.use_time) { tob[c] = f.t_obs[base + j]; tpr[c] = f.t_prec[base + j]; }
+            if (f.use_amp)  { aob[c] = f.a_obs[base + j]; apr[c] = f.a_prec[base + j]; }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < NPOS; ++p) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const bool valid = (lane + 64 * c) < f.S;
+            const double dx = px[p] - st.sx[c], dy = py[p] - st.sy[c], dz = pz[p] - st.sz[c];
+            double d = sqrt(dx * dx + dy * dy + dz * dz);
+            if (!valid) d = 1.0;
+            ts[p][c] = 0.0; as[p][c] = 0.0;
+            if (f.use_time) {
+                ts[p][c] = d / beta - st.tc[c];
+                red[2 * p] += valid ? tpr[c] * (ts[p][c] - tob[c]) : 0.0;
+            }
+            if (f.use_amp) {
+                as[p][c] = -(d * kPi * kFreq / qbeta) - log(d) - st.ac[c];
+                red[2 * p + 1] += valid ? apr[c] * (as[p][c] - aob[c]) : 0.0;
+            }
+        }
+    }
+    wave_sum<2 * NPOS>(red);
+    const double pst = f.use_time ? f.psum_t[ev] : 1.0;
+    const double psa = f.use_amp ? f.psum_a[ev] : 1.0;
+#pragma unroll
+    for (int p = 0; p < NPOS; ++p) {
+        const double t_mean = red[2 * p] / pst;
+        const double a_mean = red[2 * p + 1] / psa;
+        double m = 0.0;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const bool valid = (lane + 64 * c) < f.S;
+            if (f.use_time) {
+                const double r = tob[c] - (ts[p][c] - t_mean);
+                m += valid ? r * r * (0.5 * tpr[c]) : 0.0;
+            }
+            if (f.use_amp) {
+                const double r = aob[c] - (as[p][c] - a_mean);
+                m += valid ? r * r * (0.5 * apr[c]) : 0.0;
+            }
+        }
+        out[p] = m;
+    }
+}
+
+// Generic-S fallback (n_sta > 64*4): strides over stations, recomputing the synthetics in the second
+// pass instead of holding them in registers.
+template <int NPOS>
+__device__ __forceinline__ void event_misfit_generic(const FwdDev &f, int ev, int lane,
+                                                     const double *s_sx, const double *s_sy,
+                                                     const double *s_sz, const double *tc,
+                                                     const double *ac, int ov_kind, int ov_idx,
+                                                     double ov_val, const double (&px)[NPOS],
+                                                     const double (&py)[NPOS], const double (&pz)[NPOS],
+                                                     double beta, double q, double (&out)[NPOS])
+{
+    const size_t base = (size_t)ev * (size_t)f.S;
+    const double qbeta = q * beta;
+    double red[2 * NPOS];
+#pragma unroll
+    for (int k = 0; k < 2 * NPOS; ++k) red[k] = 0.0;
+    for (int j = lane; j < f.S; j += 64) {
+        const double tcj = (ov_kind == 2 && ov_idx == j) ? ov_val : tc[j];
+        const double acj = (ov_kind == 4 && ov_idx == j) ? ov_val : ac[j];
+#pragma unroll
+        for (int p = 0; p < NPOS; ++p) {
+            const double dx = px[p] - s_sx[j], dy = py[p] - s_sy[j], dz = pz[p] - s_sz[j];
+            const double d = sqrt(dx * dx + dy * dy + dz * dz);
+            if (f.use_time) red[2 * p] += f.t_prec[base + j] * ((d / beta - tcj) - f.t_obs[base + j]);
+            if (f.use_amp)
+                red[2 * p + 1] += f.a_prec[base + j] *
+                                  ((-(d * kPi * kFreq / qbeta) - log(d) - acj) - f.a_obs[base + j]);
+        }
+    }
+    wave_sum<2 * NPOS>(red);
+    const double pst = f.use_time ? f.psum_t[ev] : 1.0;
+    const double psa = f.use_amp ? f.psum_a[ev] : 1.0;
+#pragma unroll
+    for (int p = 0; p < NPOS; ++p) out[p] = 0.0;
+    for (int j = lane; j < f.S; j += 64) {
+        const double tcj = (ov_kind == 2 && ov_idx == j) ? ov_val : tc[j];
+        const double acj = (ov_kind == 4 && ov_idx == j) ? ov_val : ac[j];
+#pragma unroll
+        for (int p = 0; p < NPOS; ++p) {
+            const double dx = px[p] - s_sx[j], dy = py[p] - s_sy[j], dz = pz[p] - s_sz[j];
+            const double d = sqrt(dx * dx + dy * dy + dz * dz);
+            if (f.use_time) {
+                const double r = f.t_obs[base + j] - ((d / beta - tcj) - red[2 * p] / pst);
+                out[p] += r * r * (0.5 * f.t_prec[base + j]);
+            }
+            if (f.use_amp) {
+                const double r = f.a_obs[base + j] -
+                                 ((-(d * kPi * kFreq / qbeta) - log(d) - acj) - red[2 * p + 1] / psa);
+                out[p] += r * r * (0.5 * f.a_prec[base + j]);
+            }
+        }
+    }
+}
+
+template <int NCH>
+__device__ __forceinline__ void load_sta_regs(StaRegs<NCH> &st, int S, int lane, const double *s_sx,
+                                              const double *s_sy, const double *s_sz, const double *tc,
+                                              const double *ac, int ov_kind, int ov_idx, double ov_val)
+{
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int j = lane + 64 * c;
+        const bool valid = j < S;
+        st.sx[c] = valid ? s_sx[j] : 0.0;
+        st.sy[c] = valid ? s_sy[j] : 0.0;
+        st.sz[c] = valid ? s_sz[j] : 0.0;
+        st.tc[c] = valid ? tc[j] : 0.0;
+        st.ac[c] = valid ? ac[j] : 0.0;
+        if (valid && ov_idx == j) {
+            if (ov_kind == 2) st.tc[c] = ov_val;   // proposed t_corr(id)
+            if (ov_kind == 4) st.ac[c] = ov_val;   // proposed a_corr(id)
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// chain-set state in HBM
+// ---------------------------------------------------------------------------------------------------
+struct ModelDev {            // one reference `type model` group for all chains of the rank
+    double *x, *mu, *sigma, *step;   // [n_chains][nx]
+    int32_t *ptype;                  // [n_chains][nx]
+    int nx;
+};
+
+enum Stage : int { ST_IDLE = 0, ST_WAIT_FULL = 1, ST_WAIT_SWAP = 2 };
+enum Mode : int { MODE_RUN = 0, MODE_ADVANCE = 1, MODE_FINISH = 2, MODE_APPLY = 3 };
+
+struct Proposal {            // everything random about one chain step, resolved at the start of the iteration
+    int    type;             // 1 vs, 2 t_corr, 3 qs, 4 a_corr, 5..7 hypo (5 + icmp), cls_mcmc.f90:139-165
+    int    idx;              // 0-based element inside the perturbed model
+    int    evt;              // 1-based event id or -999
+    int    prior_ok;
+    int    need_full;
+    int    accepted;
+    double x_new, lpr;       // cls_model.f90:172-186
+    double r_judge, logr_judge;   // the rand_u() of cls_mcmc.f90:197 and its log (only drawn if prior_ok)
+    double L_new;
+};
+
+struct Ctrl {
+    int iter_done, iter_target, stage, n_full;
+    int err, stop, n_lik, n_smp;
+    uint32_t rng[4];         // mod_random state after everything committed so far
+    uint32_t rng_plus1[4];   // lock-step: state if this rank also consumes the judge_swap draw
+    int swap_i1, swap_i2;    // cls_parallel.f90:226-230 (global chain indices)
+    double swap_r, swap_logr;
+    int slog_n, slog_cap;
+    long long n_full_evals, n_partial_evals;
+};
+
+struct ChainsDev {
+    int n_chains, n_procs, rank;
+    int S, E;
+    ModelDev hypo, tc, vs, ac, qs;
+    double *temp, *L;                // [n_chains]
+    int32_t *n_propose, *n_accept;   // [n_chains][7]
+    double th1, th2, th3, th4;       // cumulative proposal thresholds, cls_mcmc.f90:139-153
+    int n_burn, n_interval;
+    Proposal *prop;                  // [n_chains]
+    int *full_list;                  // [n_chains]
+    double *partial;                 // [n_chains][n_wg]
+    int n_wg;
+    Ctrl *ctrl;
+    // records
+    int cap_lik, cap_smp;
+    int32_t *lik_iter, *lik_chain; double *lik_val;
+    int32_t *smp_iter, *smp_chain; double *smp_data;   // [cap_smp][3E + 2S + 2]
+    int32_t *slog_i; double *slog_d;
+    double *swap_rec;                // [4 + 2*n_chains] this rank's record (8-byte words)
+};
+
+}  // namespace htm

@@ -1,0 +1,879 @@
+// htm_hip.hip -- C ABI (include/htm_hip.h) over the gfx950 kernels in htm_kernels.hpp.
+//
+// Host code is plain C++17 + the HIP runtime: no torch, no third-party dependency.  There is no CPU
+// fallback on purpose: every entry point needs a usable HIP device and fails with HTM_ENODEVICE otherwise.
+#include "htm_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "htm_kernels.hpp"
+
+using namespace htm;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(HTM_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__,     \
+                        __LINE__);                                                                     \
+    } while (0)
+
+int use_device(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(HTM_ENODEVICE, "no HIP device available (%s); libhtm_hip has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(HTM_EINVAL, "device %d out of range (0..%d)", device, n - 1);
+    HIPCHK(hipSetDevice(device));
+    return HTM_OK;
+}
+
+template <typename T>
+int dev_alloc(std::vector<void *> &pool, T **p, size_t n)
+{
+    void *q = nullptr;
+    HIPCHK(hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)));
+    pool.push_back(q);
+    *p = static_cast<T *>(q);
+    return HTM_OK;
+}
+
+template <typename T>
+int dev_upload(std::vector<void *> &pool, T **p, const T *src, size_t n)
+{
+    int rc = dev_alloc(pool, p, n);
+    if (rc) return rc;
+    if (n) HIPCHK(hipMemcpy(*p, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return HTM_OK;
+}
+
+int nch_for(int S) { return S <= 64 ? 1 : S <= 128 ? 2 : S <= 256 ? 4 : 0; }
+
+}  // namespace
+
+struct htm_forward {
+    int device = 0, S = 0, E = 0, nch = 1;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    FwdDev dev{};
+    std::vector<void *> pool;
+    int n_wg = 0, epw = 1;
+    // scratch for the host-pointer entry points (one model)
+    double *d_hypo = nullptr, *d_tc = nullptr, *d_ac = nullptr, *d_scal = nullptr, *d_partial = nullptr;
+    double *d_syn = nullptr;
+    // scratch for batches
+    double *d_bpartial = nullptr; size_t bpartial_cap = 0;
+    double *d_bmodels = nullptr;  size_t bmodels_cap = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+struct htm_chains {
+    htm_forward *fwd = nullptr;
+    ChainsDev dev{};
+    Ctrl h_ctrl{};
+    std::vector<void *> pool;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    int pairs = 32;
+    int nw = 1;
+    size_t step_smem = 0;
+    int h_target = 0;          // host copy of the iteration target
+    int rec_len = 0;
+    std::vector<int32_t> lik_iter, lik_chain, smp_iter, smp_chain;
+    std::vector<double> lik_val, smp_data;
+    double last_device_us = 0.0;
+    int last_graph_launches = 0;
+    long long run_full0 = 0, run_part0 = 0, last_full = 0, last_part = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace {
+
+int launch_full(htm_forward *h, const FullJob &jb, int gy)
+{
+    dim3 grid(h->n_wg, gy), block(256);
+    const size_t smem = (3 * (size_t)h->S + 4) * sizeof(double);
+    switch (h->nch) {
+    case 1: hipLaunchKernelGGL(k_full<1>, grid, block, smem, h->stream, h->dev, jb); break;
+    case 2: hipLaunchKernelGGL(k_full<2>, grid, block, smem, h->stream, h->dev, jb); break;
+    case 4: hipLaunchKernelGGL(k_full<4>, grid, block, smem, h->stream, h->dev, jb); break;
+    default: hipLaunchKernelGGL(k_full<0>, grid, block, smem, h->stream, h->dev, jb); break;
+    }
+    HIPCHK(hipGetLastError());
+    return HTM_OK;
+}
+
+int launch_step(htm_chains *hc, int mode, int target, const double *gathered)
+{
+    htm_forward *h = hc->fwd;
+    dim3 grid(1), block(64 * hc->nw);
+    switch (h->nch) {
+    case 1: hipLaunchKernelGGL(k_step<1>, grid, block, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered); break;
+    case 2: hipLaunchKernelGGL(k_step<2>, grid, block, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered); break;
+    default: hipLaunchKernelGGL(k_step<0>, grid, block, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered); break;
+    }
+    HIPCHK(hipGetLastError());
+    return HTM_OK;
+}
+
+FullJob chain_full_job(htm_chains *hc)
+{
+    FullJob jb{};
+    const ChainsDev &d = hc->dev;
+    jb.hypo = d.hypo.x; jb.hypo_stride = d.hypo.nx;
+    jb.tc = d.tc.x; jb.tc_stride = d.S;
+    jb.ac = d.ac.x; jb.ac_stride = d.S;
+    jb.vs = d.vs.x; jb.qs = d.qs.x;
+    jb.prop = d.prop; jb.list = d.full_list; jb.ctrl = d.ctrl;
+    jb.n_models = d.n_chains;
+    jb.partial = d.partial; jb.n_wg = hc->fwd->n_wg; jb.epw = hc->fwd->epw;
+    return jb;
+}
+
+int ensure_batch_scratch(htm_forward *h, int n_models)
+{
+    const size_t need = (size_t)n_models * h->n_wg;
+    if (need > h->bpartial_cap) {
+        if (h->d_bpartial) HIPCHK(hipFree(h->d_bpartial));
+        h->d_bpartial = nullptr;
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&h->d_bpartial), need * sizeof(double)));
+        h->bpartial_cap = need;
+    }
+    return HTM_OK;
+}
+
+int full_batch_dev(htm_forward *h, int n_models, const double *d_hypo, const double *d_tc, const double *d_vs,
+                   const double *d_ac, const double *d_qs, double *d_L)
+{
+    int rc = ensure_batch_scratch(h, n_models);
+    if (rc) return rc;
+    FullJob jb{};
+    jb.hypo = d_hypo; jb.hypo_stride = 3L * h->E;
+    jb.tc = d_tc; jb.tc_stride = h->S;
+    jb.ac = d_ac; jb.ac_stride = h->S;
+    jb.vs = d_vs; jb.qs = d_qs;
+    jb.n_models = n_models;
+    jb.partial = h->d_bpartial; jb.n_wg = h->n_wg; jb.epw = h->epw;
+    const int gy = std::max(1, std::min(n_models, 2048 / std::max(1, h->n_wg)));
+    rc = launch_full(h, jb, gy);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_sum_partials, dim3(n_models), dim3(64), 0, h->stream, h->d_bpartial, h->n_wg,
+                       h->dev.const_sum, d_L);
+    HIPCHK(hipGetLastError());
+    return HTM_OK;
+}
+
+}  // namespace
+
+// ====================================================================================================
+extern "C" {
+
+const char *htm_last_error(void) { return g_err.c_str(); }
+int htm_abi_version(void) { return 1; }
+
+int htm_device_count(int *n)
+{
+    if (!n) return fail(HTM_EINVAL, "n is NULL");
+    *n = 0;
+    hipError_t e = hipGetDeviceCount(n);
+    if (e != hipSuccess) { *n = 0; return fail(HTM_ENODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    return HTM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+int htm_forward_create(int n_sta, int n_events, const double *sta_x, const double *sta_y, const double *sta_z,
+                       const double *t_obs, const double *t_stdv, const double *a_obs, const double *a_stdv,
+                       int use_time, int use_amp, int device, htm_forward **out)
+{
+    if (!out) return fail(HTM_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (n_sta <= 0 || n_events <= 0) return fail(HTM_EINVAL, "n_sta and n_events must be positive");
+    if (!sta_x || !sta_y || !sta_z || !t_obs || !t_stdv || !a_obs || !a_stdv)
+        return fail(HTM_EINVAL, "NULL input array");
+    int rc = use_device(device);
+    if (rc) return rc;
+
+    htm_forward *h = new htm_forward();
+    h->device = device; h->S = n_sta; h->E = n_events; h->nch = nch_for(n_sta);
+    const size_t n = (size_t)n_sta * n_events;
+
+    // init_forward, cls_forward.f90:76-92: precision, log-stdv and the missing-data rule (keyed on t_stdv
+    // only; log-stdv := 1.0 (sic), stdv := 1, precision := 1 for BOTH data types)
+    std::vector<double> tpr(n), apr(n), pst(n_events), psa(n_events);
+    const double log_2pi_half = 0.5 * std::log(2.0 * std::acos(-1.0));
+    double const_t = 0.0, const_a = 0.0;
+    for (int i = 0; i < n_events; ++i) {
+        double st = 0.0, sa = 0.0;
+        for (int j = 0; j < n_sta; ++j) {
+            const size_t k = (size_t)i * n_sta + j;
+            double lts, las;
+            if (t_stdv[k] > 1.e-16) {
+                lts = std::log(t_stdv[k]); tpr[k] = 1.0 / (t_stdv[k] * t_stdv[k]);
+                las = std::log(a_stdv[k]); apr[k] = 1.0 / (a_stdv[k] * a_stdv[k]);
+            } else {
+                lts = 1.0; tpr[k] = 1.0; las = 1.0; apr[k] = 1.0;
+            }
+            st += tpr[k]; sa += apr[k];
+            const_t += log_2pi_half + lts;
+            const_a += log_2pi_half + las;
+        }
+        pst[i] = st; psa[i] = sa;
+    }
+
+    auto cleanup = [&](int code) { htm_forward_destroy(h); return code; };
+    double *p = nullptr;
+#define UP(dst, src, cnt)                                          \
+    if ((rc = dev_upload(h->pool, &p, (src), (cnt)))) return cleanup(rc); \
+    dst = p;
+    UP(h->dev.sx, sta_x, n_sta) UP(h->dev.sy, sta_y, n_sta) UP(h->dev.sz, sta_z, n_sta)
+    UP(h->dev.t_obs, t_obs, n) UP(h->dev.t_prec, tpr.data(), n)
+    UP(h->dev.a_obs, a_obs, n) UP(h->dev.a_prec, apr.data(), n)
+    UP(h->dev.psum_t, pst.data(), n_events) UP(h->dev.psum_a, psa.data(), n_events)
+#undef UP
+    h->dev.S = n_sta; h->dev.E = n_events; h->dev.use_time = use_time ? 1 : 0; h->dev.use_amp = use_amp ? 1 : 0;
+    h->dev.const_sum = (use_time ? const_t : 0.0) + (use_amp ? const_a : 0.0);
+
+    h->epw = std::max(1, (n_events + 4 * 1024 - 1) / (4 * 1024));
+    h->n_wg = (n_events + 4 * h->epw - 1) / (4 * h->epw);
+
+    if ((rc = dev_alloc(h->pool, &h->d_hypo, 3 * (size_t)n_events))) return cleanup(rc);
+    if ((rc = dev_alloc(h->pool, &h->d_tc, n_sta))) return cleanup(rc);
+    if ((rc = dev_alloc(h->pool, &h->d_ac, n_sta))) return cleanup(rc);
+    if ((rc = dev_alloc(h->pool, &h->d_scal, 16))) return cleanup(rc);
+    if ((rc = dev_alloc(h->pool, &h->d_partial, h->n_wg))) return cleanup(rc);
+    if ((rc = dev_alloc(h->pool, &h->d_syn, n))) return cleanup(rc);
+    hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) return cleanup(fail(HTM_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)));
+    h->stream = h->own_stream;
+    if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess)
+        return cleanup(fail(HTM_EHIP, "hipEventCreate failed"));
+    *out = h;
+    return HTM_OK;
+}
+
+int htm_forward_destroy(htm_forward *h)
+{
+    if (!h) return HTM_OK;
+    (void)hipSetDevice(h->device);
+    if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
+    for (void *p : h->pool) (void)hipFree(p);
+    if (h->d_bpartial) (void)hipFree(h->d_bpartial);
+    if (h->d_bmodels) (void)hipFree(h->d_bmodels);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+    return HTM_OK;
+}
+
+int htm_forward_set_stream(htm_forward *h, void *hip_stream)
+{
+    if (!h) return fail(HTM_EINVAL, "NULL handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->stream = static_cast<hipStream_t>(hip_stream);
+    return HTM_OK;
+}
+
+int htm_forward_reset_stream(htm_forward *h)
+{
+    if (!h) return fail(HTM_EINVAL, "NULL handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->stream = h->own_stream;
+    return HTM_OK;
+}
+
+int htm_forward_sync(htm_forward *h)
+{
+    if (!h) return fail(HTM_EINVAL, "NULL handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return HTM_OK;
+}
+
+int htm_forward_loglik_full(htm_forward *h, const double *hypo, const double *t_corr, double vs,
+                            const double *a_corr, double qs, double *log_likelihood)
+{
+    if (!h || !hypo || !t_corr || !a_corr || !log_likelihood) return fail(HTM_EINVAL, "NULL argument");
+    HIPCHK(hipSetDevice(h->device));
+    const double sc[2] = {vs, qs};
+    HIPCHK(hipMemcpyAsync(h->d_hypo, hypo, 3 * (size_t)h->E * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_tc, t_corr, h->S * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_ac, a_corr, h->S * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_scal, sc, sizeof(sc), hipMemcpyHostToDevice, h->stream));
+    int rc = full_batch_dev(h, 1, h->d_hypo, h->d_tc, h->d_scal, h->d_ac, h->d_scal + 1, h->d_scal + 2);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(log_likelihood, h->d_scal + 2, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return HTM_OK;
+}
+
+int htm_forward_loglik_partial(htm_forward *h, int evt_id, const double hypo_old_xyz[3],
+                               double log_likelihood_old, const double hypo_xyz[3], const double *t_corr,
+                               double vs, const double *a_corr, double qs, double *log_likelihood)
+{
+    if (!h || !hypo_old_xyz || !hypo_xyz || !t_corr || !a_corr || !log_likelihood)
+        return fail(HTM_EINVAL, "NULL argument");
+    if (evt_id < 1 || evt_id > h->E) return fail(HTM_EINVAL, "evt_id %d out of range 1..%d", evt_id, h->E);
+    HIPCHK(hipSetDevice(h->device));
+    const double sc[6] = {hypo_old_xyz[0], hypo_old_xyz[1], hypo_old_xyz[2], hypo_xyz[0], hypo_xyz[1], hypo_xyz[2]};
+    HIPCHK(hipMemcpyAsync(h->d_tc, t_corr, h->S * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_ac, a_corr, h->S * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_scal + 4, sc, sizeof(sc), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_partial_one, dim3(1), dim3(64), 0, h->stream, h->dev, evt_id - 1, h->d_scal + 4,
+                       h->d_scal + 7, h->d_tc, h->d_ac, vs, qs, log_likelihood_old, h->d_scal + 2);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(log_likelihood, h->d_scal + 2, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return HTM_OK;
+}
+
+static int syn_common(htm_forward *h, const double *hypo, const double *corr, double beta, double q, int which,
+                      int evt_id, double *out)
+{
+    if (!h || !hypo || !corr || !out) return fail(HTM_EINVAL, "NULL argument");
+    if (evt_id != 0 && (evt_id < 1 || evt_id > h->E))
+        return fail(HTM_EINVAL, "evt_id %d out of range 1..%d", evt_id, h->E);
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(h->d_hypo, hypo, 3 * (size_t)h->E * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_tc, corr, h->S * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    const int nblk = evt_id ? 1 : (h->E + 3) / 4;
+    hipLaunchKernelGGL(k_syn, dim3(nblk), dim3(256), 0, h->stream, h->dev, h->d_hypo, h->d_tc, beta, q, which,
+                       evt_id ? evt_id - 1 : -1, h->d_syn);
+    HIPCHK(hipGetLastError());
+    const size_t cnt = evt_id ? (size_t)h->S : (size_t)h->S * h->E;
+    HIPCHK(hipMemcpyAsync(out, h->d_syn, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return HTM_OK;
+}
+
+int htm_forward_travel_time(htm_forward *h, const double *hypo, const double *t_corr, double vs, double *t_syn)
+{ return syn_common(h, hypo, t_corr, vs, 1.0, 0, 0, t_syn); }
+int htm_forward_amp(htm_forward *h, const double *hypo, const double *a_corr, double qs, double vs, double *a_syn)
+{ return syn_common(h, hypo, a_corr, vs, qs, 1, 0, a_syn); }
+int htm_forward_travel_time_single(htm_forward *h, int evt_id, const double *hypo, const double *t_corr,
+                                   double vs, double *t_syn)
+{
+    if (h && (evt_id < 1 || evt_id > h->E)) return fail(HTM_EINVAL, "evt_id %d out of range", evt_id);
+    return syn_common(h, hypo, t_corr, vs, 1.0, 0, evt_id, t_syn);
+}
+int htm_forward_amp_single(htm_forward *h, int evt_id, const double *hypo, const double *a_corr, double qs,
+                           double vs, double *a_syn)
+{
+    if (h && (evt_id < 1 || evt_id > h->E)) return fail(HTM_EINVAL, "evt_id %d out of range", evt_id);
+    return syn_common(h, hypo, a_corr, vs, qs, 1, evt_id, a_syn);
+}
+
+int htm_forward_loglik_full_batch_dev(htm_forward *h, int n_models, const double *d_hypo, const double *d_t_corr,
+                                      const double *d_vs, const double *d_a_corr, const double *d_qs,
+                                      double *d_log_likelihood)
+{
+    if (!h || !d_hypo || !d_t_corr || !d_vs || !d_a_corr || !d_qs || !d_log_likelihood)
+        return fail(HTM_EINVAL, "NULL argument");
+    if (n_models <= 0) return fail(HTM_EINVAL, "n_models must be positive");
+    HIPCHK(hipSetDevice(h->device));
+    return full_batch_dev(h, n_models, d_hypo, d_t_corr, d_vs, d_a_corr, d_qs, d_log_likelihood);
+}
+
+int htm_forward_loglik_full_batch(htm_forward *h, int n_models, const double *hypo, const double *t_corr,
+                                  const double *vs, const double *a_corr, const double *qs, double *log_likelihood)
+{
+    if (!h || !hypo || !t_corr || !vs || !a_corr || !qs || !log_likelihood) return fail(HTM_EINVAL, "NULL argument");
+    if (n_models <= 0) return fail(HTM_EINVAL, "n_models must be positive");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t nh = 3 * (size_t)h->E, ns = h->S;
+    const size_t per = nh + 2 * ns + 3, need = per * n_models;
+    if (need > h->bmodels_cap) {
+        if (h->d_bmodels) HIPCHK(hipFree(h->d_bmodels));
+        h->d_bmodels = nullptr;
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&h->d_bmodels), need * sizeof(double)));
+        h->bmodels_cap = need;
+    }
+    double *dh = h->d_bmodels, *dt = dh + nh * n_models, *da = dt + ns * n_models, *dv = da + ns * n_models,
+           *dq = dv + n_models, *dL = dq + n_models;
+    HIPCHK(hipMemcpyAsync(dh, hypo, nh * n_models * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(dt, t_corr, ns * n_models * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(da, a_corr, ns * n_models * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(dv, vs, n_models * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(dq, qs, n_models * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    int rc = full_batch_dev(h, n_models, dh, dt, dv, da, dq, dL);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(log_likelihood, dL, n_models * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return HTM_OK;
+}
+
+int htm_forward_time_full_batch_dev(htm_forward *h, int n_models, const double *d_hypo, const double *d_t_corr,
+                                    const double *d_vs, const double *d_a_corr, const double *d_qs,
+                                    double *d_log_likelihood, int reps, double *avg_us)
+{
+    if (!h || !avg_us || reps <= 0) return fail(HTM_EINVAL, "bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    int rc = htm_forward_loglik_full_batch_dev(h, n_models, d_hypo, d_t_corr, d_vs, d_a_corr, d_qs, d_log_likelihood);
+    if (rc) return rc;   // warm-up, also sizes the scratch
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    for (int r = 0; r < reps; ++r) {
+        rc = full_batch_dev(h, n_models, d_hypo, d_t_corr, d_vs, d_a_corr, d_qs, d_log_likelihood);
+        if (rc) return rc;
+    }
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipEventSynchronize(h->ev1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    *avg_us = 1000.0 * ms / reps;
+    return HTM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// chains
+// ---------------------------------------------------------------------------------------------------
+static int upload_model(htm_chains *hc, ModelDev &m, const htm_model_init &in, int nx, int nc, const char *name)
+{
+    if (!in.x) return fail(HTM_EINVAL, "%s.x is NULL", name);
+    const size_t n = (size_t)nx * nc;
+    std::vector<double> zeros(n, 0.0);
+    std::vector<double> ones(n, 1.0);
+    std::vector<int32_t> izeros(n, 0);
+    int rc;
+    m.nx = nx;
+    if ((rc = dev_upload(hc->pool, &m.x, in.x, n))) return rc;
+    if ((rc = dev_upload(hc->pool, &m.mu, in.mu ? in.mu : zeros.data(), n))) return rc;
+    if ((rc = dev_upload(hc->pool, &m.sigma, in.sigma ? in.sigma : ones.data(), n))) return rc;
+    if ((rc = dev_upload(hc->pool, &m.step, in.step_size ? in.step_size : zeros.data(), n))) return rc;
+    if ((rc = dev_upload(hc->pool, &m.ptype, in.prior_type ? in.prior_type : izeros.data(), n))) return rc;
+    return HTM_OK;
+}
+
+int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **out)
+{
+    if (!out) return fail(HTM_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (!h || !init) return fail(HTM_EINVAL, "NULL argument");
+    const int nc = init->n_chains;
+    if (nc < 1 || nc > kMaxChains) return fail(HTM_EINVAL, "n_chains must be in 1..%d", kMaxChains);
+    if (init->n_procs < 1 || init->rank < 0 || init->rank >= init->n_procs) return fail(HTM_EINVAL, "bad rank/n_procs");
+    if (init->n_interval < 1) return fail(HTM_EINVAL, "n_interval must be >= 1");
+    if (!init->temp) return fail(HTM_EINVAL, "temp is NULL");
+    if (h->nch == 4) {
+        // k_step holds two candidate positions in registers; 256 stations exceed the budget -> generic path
+    }
+    HIPCHK(hipSetDevice(h->device));
+    htm_chains *hc = new htm_chains();
+    hc->fwd = h;
+    auto cleanup = [&](int code) { htm_chains_destroy(hc); return code; };
+    int rc;
+    ChainsDev &d = hc->dev;
+    d.n_chains = nc; d.n_procs = init->n_procs; d.rank = init->rank; d.S = h->S; d.E = h->E;
+    if ((rc = upload_model(hc, d.hypo, init->hypo, 3 * h->E, nc, "hypo"))) return cleanup(rc);
+    if ((rc = upload_model(hc, d.tc, init->t_corr, h->S, nc, "t_corr"))) return cleanup(rc);
+    if ((rc = upload_model(hc, d.vs, init->vs, 1, nc, "vs"))) return cleanup(rc);
+    if ((rc = upload_model(hc, d.ac, init->a_corr, h->S, nc, "a_corr"))) return cleanup(rc);
+    if ((rc = upload_model(hc, d.qs, init->qs, 1, nc, "qs"))) return cleanup(rc);
+    if ((rc = dev_upload(hc->pool, &d.temp, init->temp, nc))) return cleanup(rc);
+    std::vector<double> L0(nc, -9.e+300);   // cls_mcmc.f90:88
+    if ((rc = dev_upload(hc->pool, &d.L, L0.data(), nc))) return cleanup(rc);
+    std::vector<int32_t> z7(7 * (size_t)nc, 0);
+    if ((rc = dev_upload(hc->pool, &d.n_propose, z7.data(), z7.size()))) return cleanup(rc);
+    if ((rc = dev_upload(hc->pool, &d.n_accept, z7.data(), z7.size()))) return cleanup(rc);
+    // proposal probabilities, cls_mcmc.f90:91-106, and the cumulative sums of :139-153 in the same order
+    const double p_vs = init->solve_vs ? 0.025 : 0.0, p_tc = init->solve_t_corr ? 0.025 : 0.0;
+    const double p_qs = init->solve_qs ? 0.025 : 0.0, p_ac = init->solve_a_corr ? 0.025 : 0.0;
+    d.th1 = p_vs; d.th2 = p_vs + p_tc; d.th3 = p_vs + p_tc + p_qs; d.th4 = p_vs + p_tc + p_qs + p_ac;
+    d.n_burn = init->n_burn; d.n_interval = init->n_interval;
+    d.n_wg = h->n_wg;
+    if ((rc = dev_alloc(hc->pool, &d.prop, nc))) return cleanup(rc);
+    if ((rc = dev_alloc(hc->pool, &d.full_list, nc))) return cleanup(rc);
+    if ((rc = dev_alloc(hc->pool, &d.partial, (size_t)nc * h->n_wg))) return cleanup(rc);
+    if ((rc = dev_alloc(hc->pool, &d.swap_rec, 4 + 2 * (size_t)nc))) return cleanup(rc);
+    HIPCHK(hipMemset(d.prop, 0, nc * sizeof(Proposal)));
+    HIPCHK(hipMemset(d.swap_rec, 0, (4 + 2 * (size_t)nc) * sizeof(double)));
+
+    hc->rec_len = 3 * h->E + 2 * h->S + 2;
+    d.cap_lik = init->lik_capacity > 0 ? init->lik_capacity : 1 << 16;
+    if (init->sample_capacity > 0) d.cap_smp = init->sample_capacity;
+    else d.cap_smp = (int)std::max<size_t>(4 * (size_t)nc, std::min<size_t>(4096, (size_t(128) << 20) / (hc->rec_len * sizeof(double))));
+    if (d.cap_lik < 2 * nc || d.cap_smp < 2 * nc) return cleanup(fail(HTM_EINVAL, "record capacities must be >= 2*n_chains"));
+    if ((rc = dev_alloc(hc->pool, &d.lik_iter, d.cap_lik))) return cleanup(rc);
+    if ((rc = dev_alloc(hc->pool, &d.lik_chain, d.cap_lik))) return cleanup(rc);
+    if ((rc = dev_alloc(hc->pool, &d.lik_val, d.cap_lik))) return cleanup(rc);
+    if ((rc = dev_alloc(hc->pool, &d.smp_iter, d.cap_smp))) return cleanup(rc);
+    if ((rc = dev_alloc(hc->pool, &d.smp_chain, d.cap_smp))) return cleanup(rc);
+    if ((rc = dev_alloc(hc->pool, &d.smp_data, (size_t)d.cap_smp * hc->rec_len))) return cleanup(rc);
+    d.slog_i = nullptr; d.slog_d = nullptr;
+
+    Ctrl c{};
+    for (int k = 0; k < 4; ++k) c.rng[k] = init->rng_state[k];
+    c.stage = ST_IDLE;
+    hc->h_ctrl = c;
+    if ((rc = dev_upload(hc->pool, &d.ctrl, &c, 1))) return cleanup(rc);
+
+    hc->nw = std::min(nc, 8);
+    hc->step_smem = ((sizeof(StepShared) + 15) & ~size_t(15)) + 3 * (size_t)h->S * sizeof(double);
+    if (hc->step_smem > 64 * 1024) return cleanup(fail(HTM_EINVAL, "n_sta too large for k_step's LDS budget"));
+    if (hipEventCreate(&hc->ev0) != hipSuccess || hipEventCreate(&hc->ev1) != hipSuccess)
+        return cleanup(fail(HTM_EHIP, "hipEventCreate failed"));
+    *out = hc;
+    return HTM_OK;
+}
+
+int htm_chains_destroy(htm_chains *hc)
+{
+    if (!hc) return HTM_OK;
+    (void)hipSetDevice(hc->fwd->device);
+    (void)hipStreamSynchronize(hc->fwd->stream);
+    if (hc->gexec) (void)hipGraphExecDestroy(hc->gexec);
+    if (hc->graph) (void)hipGraphDestroy(hc->graph);
+    for (void *p : hc->pool) (void)hipFree(p);
+    if (hc->ev0) (void)hipEventDestroy(hc->ev0);
+    if (hc->ev1) (void)hipEventDestroy(hc->ev1);
+    delete hc;
+    return HTM_OK;
+}
+
+static int read_ctrl(htm_chains *hc)
+{
+    HIPCHK(hipMemcpyAsync(&hc->h_ctrl, hc->dev.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, hc->fwd->stream));
+    HIPCHK(hipStreamSynchronize(hc->fwd->stream));
+    return HTM_OK;
+}
+
+static int ctrl_error(const htm_chains *hc)
+{
+    switch (hc->h_ctrl.err) {
+    case 0: return HTM_OK;
+    case -4: return fail(HTM_ESTATE, "device RNG window exhausted (iteration %d)", hc->h_ctrl.iter_done + 1);
+    case -5: return fail(HTM_EOVERFLOW, "record buffer overflow in lock-step mode: call htm_chains_drain more often");
+    case -6: return fail(HTM_EDESYNC, "swap records of the ranks carry different iteration numbers");
+    default: return fail(HTM_ESTATE, "device error flag %d", hc->h_ctrl.err);
+    }
+}
+
+// move device record buffers to the host vectors; requires h_ctrl to be current and the stream idle
+static int drain_records(htm_chains *hc)
+{
+    const ChainsDev &d = hc->dev;
+    const int nl = hc->h_ctrl.n_lik, ns = hc->h_ctrl.n_smp;
+    if (nl > 0) {
+        const size_t o = hc->lik_iter.size();
+        hc->lik_iter.resize(o + nl); hc->lik_chain.resize(o + nl); hc->lik_val.resize(o + nl);
+        HIPCHK(hipMemcpy(hc->lik_iter.data() + o, d.lik_iter, nl * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(hc->lik_chain.data() + o, d.lik_chain, nl * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(hc->lik_val.data() + o, d.lik_val, nl * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    if (ns > 0) {
+        const size_t o = hc->smp_iter.size();
+        hc->smp_iter.resize(o + ns); hc->smp_chain.resize(o + ns); hc->smp_data.resize((o + ns) * hc->rec_len);
+        HIPCHK(hipMemcpy(hc->smp_iter.data() + o, d.smp_iter, ns * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(hc->smp_chain.data() + o, d.smp_chain, ns * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(hc->smp_data.data() + o * hc->rec_len, d.smp_data, (size_t)ns * hc->rec_len * sizeof(double),
+                         hipMemcpyDeviceToHost));
+    }
+    if (nl > 0 || ns > 0 || hc->h_ctrl.stop) {
+        hc->h_ctrl.n_lik = 0; hc->h_ctrl.n_smp = 0; hc->h_ctrl.stop = 0;
+        // stop, n_lik, n_smp are consecutive ints in Ctrl
+        HIPCHK(hipMemcpy(&hc->dev.ctrl->stop, &hc->h_ctrl.stop, 3 * sizeof(int), hipMemcpyHostToDevice));
+    }
+    return HTM_OK;
+}
+
+static int build_graph(htm_chains *hc)
+{
+    if (hc->gexec) return HTM_OK;
+    htm_forward *h = hc->fwd;
+    hipStream_t cap = nullptr;
+    HIPCHK(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
+    hipStream_t saved = h->stream;
+    h->stream = cap;
+    hipError_t e = hipStreamBeginCapture(cap, hipStreamCaptureModeRelaxed);
+    int rc = HTM_OK;
+    if (e != hipSuccess) rc = fail(HTM_EHIP, "hipStreamBeginCapture: %s", hipGetErrorString(e));
+    const FullJob jb = chain_full_job(hc);
+    for (int k = 0; k < hc->pairs && rc == HTM_OK; ++k) {
+        rc = launch_step(hc, MODE_RUN, -1, nullptr);
+        if (rc == HTM_OK) rc = launch_full(h, jb, 1);
+    }
+    hipGraph_t g = nullptr;
+    e = hipStreamEndCapture(cap, &g);
+    h->stream = saved;
+    if (rc == HTM_OK && e != hipSuccess) rc = fail(HTM_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+    if (rc == HTM_OK) {
+        hc->graph = g;
+        e = hipGraphInstantiate(&hc->gexec, g, nullptr, nullptr, 0);
+        if (e != hipSuccess) rc = fail(HTM_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+    }
+    (void)hipStreamDestroy(cap);
+    return rc;
+}
+
+int htm_chains_run(htm_chains *hc, int n_iter)
+{
+    if (!hc) return fail(HTM_EINVAL, "NULL handle");
+    if (n_iter < 0) return fail(HTM_EINVAL, "n_iter must be >= 0");
+    if (hc->dev.n_procs != 1)
+        return fail(HTM_ESTATE, "htm_chains_run is the single-rank driver; use step_begin/step_end for n_procs > 1");
+    htm_forward *h = hc->fwd;
+    HIPCHK(hipSetDevice(h->device));
+    int rc = read_ctrl(hc);
+    if (rc) return rc;
+    if (hc->h_ctrl.stage == ST_WAIT_SWAP) return fail(HTM_ESTATE, "a lock-step iteration is in flight");
+    if ((rc = build_graph(hc))) return rc;
+    hc->h_target = hc->h_ctrl.iter_done + n_iter;
+    HIPCHK(hipMemcpyAsync(&hc->dev.ctrl->iter_target, &hc->h_target, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    hc->run_full0 = hc->h_ctrl.n_full_evals; hc->run_part0 = hc->h_ctrl.n_partial_evals;
+    hc->last_graph_launches = 0;
+    HIPCHK(hipEventRecord(hc->ev0, h->stream));
+    double it_per_launch = 1.5 * hc->pairs;     // refined from what the device actually achieved
+    while (true) {
+        const int remaining = hc->h_target - hc->h_ctrl.iter_done;
+        if (remaining <= 0 && hc->h_ctrl.stage == ST_IDLE) break;
+        int g = (int)(0.8 * remaining / it_per_launch);
+        g = std::max(1, std::min(g, 512));
+        const int before = hc->h_ctrl.iter_done;
+        for (int k = 0; k < g; ++k) HIPCHK(hipGraphLaunch(hc->gexec, h->stream));
+        hc->last_graph_launches += g;
+        if ((rc = read_ctrl(hc))) return rc;
+        if ((rc = ctrl_error(hc))) return rc;
+        if (hc->h_ctrl.stop) { if ((rc = drain_records(hc))) return rc; }
+        else if (hc->h_ctrl.iter_done > before)
+            it_per_launch = std::max(1.0, double(hc->h_ctrl.iter_done - before) / g);
+    }
+    HIPCHK(hipEventRecord(hc->ev1, h->stream));
+    HIPCHK(hipEventSynchronize(hc->ev1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, hc->ev0, hc->ev1));
+    hc->last_device_us = 1000.0 * ms;
+    hc->last_full = hc->h_ctrl.n_full_evals - hc->run_full0;
+    hc->last_part = hc->h_ctrl.n_partial_evals - hc->run_part0;
+    return drain_records(hc);
+}
+
+int htm_chains_step_begin(htm_chains *hc)
+{
+    if (!hc) return fail(HTM_EINVAL, "NULL handle");
+    htm_forward *h = hc->fwd;
+    HIPCHK(hipSetDevice(h->device));
+    hc->h_target += 1;
+    int rc = launch_step(hc, MODE_ADVANCE, hc->h_target, nullptr);
+    if (rc) return rc;
+    if ((rc = launch_full(h, chain_full_job(hc), 1))) return rc;
+    return launch_step(hc, MODE_FINISH, hc->h_target, nullptr);
+}
+
+int htm_chains_swap_record(htm_chains *hc, void **d_record, size_t *record_bytes)
+{
+    if (!hc || !d_record || !record_bytes) return fail(HTM_EINVAL, "NULL argument");
+    *d_record = hc->dev.swap_rec;
+    *record_bytes = (4 + 2 * (size_t)hc->dev.n_chains) * sizeof(double);
+    return HTM_OK;
+}
+
+int htm_chains_step_end(htm_chains *hc, const void *d_gathered_records)
+{
+    if (!hc) return fail(HTM_EINVAL, "NULL handle");
+    if (!d_gathered_records) return fail(HTM_EINVAL, "gathered records pointer is NULL");
+    HIPCHK(hipSetDevice(hc->fwd->device));
+    return launch_step(hc, MODE_APPLY, hc->h_target, static_cast<const double *>(d_gathered_records));
+}
+
+int htm_chains_sync(htm_chains *hc)
+{
+    if (!hc) return fail(HTM_EINVAL, "NULL handle");
+    HIPCHK(hipSetDevice(hc->fwd->device));
+    int rc = read_ctrl(hc);
+    if (rc) return rc;
+    return ctrl_error(hc);
+}
+
+int htm_chains_drain(htm_chains *hc)
+{
+    int rc = htm_chains_sync(hc);
+    if (rc) return rc;
+    return drain_records(hc);
+}
+
+int htm_chains_iterations_done(htm_chains *hc, int *n)
+{
+    if (!hc || !n) return fail(HTM_EINVAL, "NULL argument");
+    int rc = htm_chains_sync(hc);
+    if (rc) return rc;
+    *n = hc->h_ctrl.iter_done;
+    return HTM_OK;
+}
+
+int htm_chains_get_state(htm_chains *hc, int chain, double *hypo, double *t_corr, double *vs, double *a_corr,
+                         double *qs, double *temp, double *log_likelihood, int32_t n_propose[7], int32_t n_accept[7])
+{
+    if (!hc) return fail(HTM_EINVAL, "NULL handle");
+    const ChainsDev &d = hc->dev;
+    if (chain < 0 || chain >= d.n_chains) return fail(HTM_EINVAL, "chain %d out of range", chain);
+    int rc = htm_chains_sync(hc);
+    if (rc) return rc;
+    const size_t c = chain;
+    if (hypo) HIPCHK(hipMemcpy(hypo, d.hypo.x + c * d.hypo.nx, d.hypo.nx * sizeof(double), hipMemcpyDeviceToHost));
+    if (t_corr) HIPCHK(hipMemcpy(t_corr, d.tc.x + c * d.S, d.S * sizeof(double), hipMemcpyDeviceToHost));
+    if (a_corr) HIPCHK(hipMemcpy(a_corr, d.ac.x + c * d.S, d.S * sizeof(double), hipMemcpyDeviceToHost));
+    if (vs) HIPCHK(hipMemcpy(vs, d.vs.x + c, sizeof(double), hipMemcpyDeviceToHost));
+    if (qs) HIPCHK(hipMemcpy(qs, d.qs.x + c, sizeof(double), hipMemcpyDeviceToHost));
+    if (temp) HIPCHK(hipMemcpy(temp, d.temp + c, sizeof(double), hipMemcpyDeviceToHost));
+    if (log_likelihood) HIPCHK(hipMemcpy(log_likelihood, d.L + c, sizeof(double), hipMemcpyDeviceToHost));
+    if (n_propose) HIPCHK(hipMemcpy(n_propose, d.n_propose + 7 * c, 7 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (n_accept) HIPCHK(hipMemcpy(n_accept, d.n_accept + 7 * c, 7 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return HTM_OK;
+}
+
+int htm_chains_get_rng(htm_chains *hc, uint32_t state[4])
+{
+    if (!hc || !state) return fail(HTM_EINVAL, "NULL argument");
+    int rc = htm_chains_sync(hc);
+    if (rc) return rc;
+    for (int k = 0; k < 4; ++k) state[k] = hc->h_ctrl.rng[k];
+    return HTM_OK;
+}
+
+int htm_chains_lik_count(htm_chains *hc, int *n)
+{
+    if (!hc || !n) return fail(HTM_EINVAL, "NULL argument");
+    *n = (int)hc->lik_iter.size();
+    return HTM_OK;
+}
+
+int htm_chains_lik_read(htm_chains *hc, int32_t *iter, int32_t *chain, double *log_likelihood)
+{
+    if (!hc) return fail(HTM_EINVAL, "NULL handle");
+    const size_t n = hc->lik_iter.size();
+    if (iter) memcpy(iter, hc->lik_iter.data(), n * sizeof(int32_t));
+    if (chain) memcpy(chain, hc->lik_chain.data(), n * sizeof(int32_t));
+    if (log_likelihood) memcpy(log_likelihood, hc->lik_val.data(), n * sizeof(double));
+    return HTM_OK;
+}
+
+int htm_chains_sample_count(htm_chains *hc, int *n)
+{
+    if (!hc || !n) return fail(HTM_EINVAL, "NULL argument");
+    *n = (int)hc->smp_iter.size();
+    return HTM_OK;
+}
+
+int htm_chains_sample_read(htm_chains *hc, int k, int32_t *iter, int32_t *chain, double *vs, double *qs,
+                           double *hypo, double *t_corr, double *a_corr)
+{
+    if (!hc) return fail(HTM_EINVAL, "NULL handle");
+    if (k < 0 || k >= (int)hc->smp_iter.size()) return fail(HTM_EINVAL, "sample %d out of range", k);
+    const int nh = hc->dev.hypo.nx, S = hc->dev.S;
+    const double *r = hc->smp_data.data() + (size_t)k * hc->rec_len;
+    if (iter) *iter = hc->smp_iter[k];
+    if (chain) *chain = hc->smp_chain[k];
+    if (hypo) memcpy(hypo, r, nh * sizeof(double));
+    if (t_corr) memcpy(t_corr, r + nh, S * sizeof(double));
+    if (a_corr) memcpy(a_corr, r + nh + S, S * sizeof(double));
+    if (vs) *vs = r[nh + 2 * S];
+    if (qs) *qs = r[nh + 2 * S + 1];
+    return HTM_OK;
+}
+
+int htm_chains_clear_records(htm_chains *hc)
+{
+    if (!hc) return fail(HTM_EINVAL, "NULL handle");
+    hc->lik_iter.clear(); hc->lik_chain.clear(); hc->lik_val.clear();
+    hc->smp_iter.clear(); hc->smp_chain.clear(); hc->smp_data.clear();
+    return HTM_OK;
+}
+
+int htm_chains_enable_steplog(htm_chains *hc, int capacity)
+{
+    if (!hc || capacity < 0) return fail(HTM_EINVAL, "bad argument");
+    int rc = htm_chains_sync(hc);
+    if (rc) return rc;
+    if (capacity > 0) {
+        if ((rc = dev_alloc(hc->pool, &hc->dev.slog_i, 8 * (size_t)capacity))) return rc;
+        if ((rc = dev_alloc(hc->pool, &hc->dev.slog_d, 4 * (size_t)capacity))) return rc;
+    }
+    // the graph bakes ChainsDev by value: rebuild it with the new pointers
+    if (hc->gexec) { (void)hipGraphExecDestroy(hc->gexec); hc->gexec = nullptr; }
+    if (hc->graph) { (void)hipGraphDestroy(hc->graph); hc->graph = nullptr; }
+    hc->h_ctrl.slog_n = 0; hc->h_ctrl.slog_cap = capacity;
+    HIPCHK(hipMemcpy(&hc->dev.ctrl->slog_n, &hc->h_ctrl.slog_n, 2 * sizeof(int), hipMemcpyHostToDevice));
+    return HTM_OK;
+}
+
+int htm_chains_steplog_read(htm_chains *hc, int *n, int32_t *irows, double *drows)
+{
+    if (!hc || !n) return fail(HTM_EINVAL, "NULL argument");
+    int rc = htm_chains_sync(hc);
+    if (rc) return rc;
+    const int rows = std::min(hc->h_ctrl.slog_n, hc->h_ctrl.slog_cap);
+    *n = rows;
+    if (rows > 0 && irows) HIPCHK(hipMemcpy(irows, hc->dev.slog_i, 8 * (size_t)rows * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (rows > 0 && drows) HIPCHK(hipMemcpy(drows, hc->dev.slog_d, 4 * (size_t)rows * sizeof(double), hipMemcpyDeviceToHost));
+    return HTM_OK;
+}
+
+int htm_chains_last_run_stats(htm_chains *hc, double *device_us, int *graph_launches, int64_t *full_evals,
+                              int64_t *partial_evals)
+{
+    if (!hc) return fail(HTM_EINVAL, "NULL handle");
+    if (device_us) *device_us = hc->last_device_us;
+    if (graph_launches) *graph_launches = hc->last_graph_launches;
+    if (full_evals) *full_evals = hc->last_full;
+    if (partial_evals) *partial_evals = hc->last_part;
+    return HTM_OK;
+}
+
+int htm_selftest(int device)
+{
+    int rc = use_device(device);
+    if (rc) return rc;
+    std::vector<double> in(128);
+    uint32_t s = 12345u;
+    for (auto &v : in) { s = s * 1664525u + 1013904223u; v = (double)(int32_t)s / 65536.0 / 7.0; }
+    double *d_in = nullptr, *d_o = nullptr;
+    uint32_t *d_r = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_in), 128 * sizeof(double)));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_o), 16 * sizeof(double)));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_r), 8 * sizeof(uint32_t)));
+    HIPCHK(hipMemcpy(d_in, in.data(), 128 * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_selftest, dim3(1), dim3(64), 0, 0, d_in, d_o, d_o + 2, d_r, d_o + 4);
+    HIPCHK(hipGetLastError());
+    double o[16];
+    uint32_t r[8];
+    HIPCHK(hipMemcpy(o, d_o, sizeof(o), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(r, d_r, sizeof(r), hipMemcpyDeviceToHost));
+    (void)hipFree(d_in); (void)hipFree(d_o); (void)hipFree(d_r);
+    if (memcmp(&o[0], &o[2], 2 * sizeof(double)) != 0)
+        return fail(HTM_ESTATE, "DPP wave_sum mismatch: %.17g vs %.17g / %.17g vs %.17g", o[0], o[2], o[1], o[3]);
+    // SURVEY.md §8a golden vector: first five rand_u() of rank 0
+    const double want[5] = {0.55850877496413887, 0.12064291047863662, 0.58295862120576203, 0.68001799611374736,
+                            0.45020412676967681};
+    for (int i = 0; i < 5; ++i)
+        if (o[4 + i] != want[i]) return fail(HTM_ESTATE, "device rand_u[%d] = %.17g, want %.17g", i, o[4 + i], want[i]);
+    if (std::fabs(o[12] - 0.78381228502204603) > 1e-15)
+        return fail(HTM_ESTATE, "device rand_g = %.17g, want 0.78381228502204603", o[12]);
+    return HTM_OK;
+}
+
+}  // extern "C"

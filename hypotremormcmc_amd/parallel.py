@@ -1,0 +1,109 @@
+"""Multi-rank lock-step execution: the build's counterpart of `parallel%swap_temperature`
+(reference src/cls_parallel.f90:100-216) and `parallel%output_proposal` (:244-281).
+
+One process per GPU.  The reference exchanges a 4-int broadcast plus two 2-double messages per iteration
+over MPI; here every rank contributes ONE small record {pair chosen by rank 0, its pending judge_swap
+draw, (T, L) of all its chains} to a single all-gather per iteration (RCCL over xGMI via
+torch.distributed's "nccl" backend, gloo on CPU for tests) and every rank evaluates the identical swap
+decision from the gathered records on its device.
+
+`LocalWorld` runs all ranks of a job inside one process on one device (record exchange = device copies);
+it exists for parity tests on a single GPU.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .chains import ChainSet
+
+
+class _DevBuf:
+    """Zero-copy view of a raw device pointer for torch.as_tensor (CUDA array interface, version 2)."""
+
+    def __init__(self, ptr: int, n_f64: int):
+        self.__cuda_array_interface__ = {"shape": (n_f64,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+
+def record_tensor(cs: ChainSet):
+    import torch
+
+    ptr, nbytes = cs.swap_record()
+    return torch.as_tensor(_DevBuf(ptr, nbytes // 8), device=f"cuda:{cs.fwd.device}")
+
+
+class TorchWorld:
+    """One rank of a torch.distributed job (already initialised, backend nccl = RCCL)."""
+
+    def __init__(self, cs: ChainSet, group=None):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist, self.cs, self.group = torch, dist, cs, group
+        self.world = dist.get_world_size(group)
+        assert self.world == cs.n_procs and dist.get_rank(group) == cs.rank
+        torch.cuda.set_device(cs.fwd.device)
+        # our kernels and the collective must share one stream order
+        cs.fwd.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.rec = record_tensor(cs)
+        self.gathered = torch.zeros(self.world * self.rec.numel(), dtype=torch.float64, device=self.rec.device)
+        # records a rank may hold between drains: n_chains per iteration at most
+        self.drain_every = 4096
+
+    def step(self):
+        self.cs.step_begin()
+        self.dist.all_gather_into_tensor(self.gathered, self.rec, group=self.group)
+        self.cs.step_end(self.gathered.data_ptr())
+
+    def run(self, n_iter: int):
+        for k in range(n_iter):
+            self.step()
+            if (k + 1) % self.drain_every == 0:
+                self.cs.drain()
+        self.cs.drain()
+
+    def reduce_counts(self):
+        npr, nac = self.cs.counts()
+        t = self.torch.tensor(np.concatenate([npr, nac]), device=self.rec.device)
+        self.dist.all_reduce(t, group=self.group)
+        t = t.cpu().numpy()
+        return t[:7], t[7:]
+
+
+class LocalWorld:
+    """All ranks of a job in one process, on one device (test harness for the lock-step path)."""
+
+    def __init__(self, chain_sets):
+        import torch
+
+        self.torch = torch
+        self.sets = list(chain_sets)
+        self.world = len(self.sets)
+        dev = self.sets[0].fwd.device
+        torch.cuda.set_device(dev)
+        stream = torch.cuda.current_stream().cuda_stream
+        seen = set()
+        for cs in self.sets:
+            if id(cs.fwd) not in seen:
+                cs.fwd.set_stream(stream)
+                seen.add(id(cs.fwd))
+        self.recs = [record_tensor(cs) for cs in self.sets]
+        n = self.recs[0].numel()
+        self.gathered = torch.zeros(self.world * n, dtype=torch.float64, device=self.recs[0].device)
+        self.n = n
+
+    def step(self):
+        for cs in self.sets:
+            cs.step_begin()
+        for r, rec in enumerate(self.recs):
+            self.gathered[r * self.n:(r + 1) * self.n].copy_(rec)
+        for cs in self.sets:
+            cs.step_end(self.gathered.data_ptr())
+
+    def run(self, n_iter: int, drain_every: int = 1024):
+        for k in range(n_iter):
+            self.step()
+            if (k + 1) % drain_every == 0:
+                for cs in self.sets:
+                    cs.drain()
+        for cs in self.sets:
+            cs.drain()

@@ -1,0 +1,200 @@
+/*
+ * htm_hip.h -- C ABI of libhtm_hip.so: the MI355X (gfx950) implementation of HypoTremorMCMC's
+ * per-proposal likelihood inner loop (step 5, `hypo_tremor_mcmc`).
+ *
+ * The reference has no FFI for this path: the boundary is the Fortran derived type `forward`
+ * (reference src/cls_forward.f90:6-41) plus the chain bookkeeping of `mcmc` / `parallel`
+ * (src/cls_mcmc.f90:7-53, src/cls_parallel.f90:7-22) driven by `program main`
+ * (src/hypo_tremor_mcmc.f90:236-284).  Each entry point below names the reference interface it
+ * replaces.  The Fortran ISO_C_BINDING module that re-creates `type forward` on top of these symbols is
+ * hypotremormcmc_amd/fortran/htm_forward_mod.f90 (shown in INTEGRATION.md).
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every function returns 0 on success, a negative HTM_E* code otherwise;
+ *     htm_last_error() gives the message of the last failure on the calling thread.
+ *   - all floating-point data is IEEE fp64; integers are 32-bit unless stated.
+ *   - 2-D observation arrays are (n_sta, n_events) column-major exactly as in the reference
+ *     (src/cls_forward.f90:62-69): element (j, i) at [i * n_sta + j], station index fastest.
+ *   - hypocentre vectors are xyz-interleaved, 3 * n_events long (src/cls_forward.f90:109-111).
+ *   - event ids (evt_id) are 1-based like the reference.
+ *   - host pointers unless a parameter name starts with d_ (device pointer, same device as the handle).
+ *   - a handle is not thread-safe; calls are synchronous unless stated (the reference is single-threaded
+ *     per rank with strictly synchronous calls).
+ *   - there is NO CPU fallback: every entry point fails with HTM_ENODEVICE when no gfx950 device is usable.
+ */
+#ifndef HTM_HIP_H
+#define HTM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HTM_OK          0
+#define HTM_EINVAL     -1   /* bad argument */
+#define HTM_ENODEVICE  -2   /* no usable HIP device */
+#define HTM_EHIP       -3   /* a HIP runtime call failed */
+#define HTM_ESTATE     -4   /* call not valid in the handle's current state */
+#define HTM_EOVERFLOW  -5   /* a record buffer overflowed (lock-step mode without drain) */
+#define HTM_EDESYNC    -6   /* ranks disagree on the iteration number in the swap exchange */
+
+typedef struct htm_forward htm_forward;
+typedef struct htm_chains  htm_chains;
+
+const char *htm_last_error(void);
+int         htm_abi_version(void);          /* bumped when this header changes incompatibly */
+int         htm_device_count(int *n);       /* number of visible HIP devices */
+
+/* ------------------------------------------------------------------------------------------------
+ * `type forward`                                                  reference: src/cls_forward.f90
+ * ---------------------------------------------------------------------------------------------- */
+
+/* constructor `forward(n_sta, n_events, sta_x, sta_y, sta_z, obs, use_amp, use_time)`  (:40-96).
+ * `obs` is passed as its four arrays (what obs%get_t_obs() .. get_a_stdv() return, :71-74).  All inputs
+ * are copied (the reference deep-copies too, :50-74); the missing-data rule of :76-92 is applied here. */
+int htm_forward_create(int n_sta, int n_events,
+                       const double *sta_x, const double *sta_y, const double *sta_z,
+                       const double *t_obs, const double *t_stdv,
+                       const double *a_obs, const double *a_stdv,
+                       int use_time, int use_amp, int device, htm_forward **out);
+int htm_forward_destroy(htm_forward *h);
+
+/* Run all work of this handle (and of chain sets created from it) on the caller's HIP stream, e.g.
+ * torch's current stream so that RCCL collectives enqueued by torch.distributed order with our kernels.
+ * hip_stream is used as given: NULL is HIP's default (null) stream -- which is what torch's default
+ * stream is.  htm_forward_reset_stream goes back to the handle's own non-blocking stream. */
+int htm_forward_set_stream(htm_forward *h, void *hip_stream);
+int htm_forward_reset_stream(htm_forward *h);
+
+/* `calc_log_likelihood(hypo, t_corr, vs, a_corr, qs, log_likelihood)`  (:268-303) */
+int htm_forward_loglik_full(htm_forward *h, const double *hypo, const double *t_corr, double vs,
+                            const double *a_corr, double qs, double *log_likelihood);
+
+/* `partially_update_log_likelihood(evt_id, hypo_old, log_likelihood_old, hypo, t_corr, vs, a_corr, qs,
+ * log_likelihood)`  (:307-362).  Only event evt_id of hypo_old / hypo is read by the reference, so the two
+ * models are passed as that event's xyz triplets. */
+int htm_forward_loglik_partial(htm_forward *h, int evt_id, const double hypo_old_xyz[3],
+                               double log_likelihood_old, const double hypo_xyz[3],
+                               const double *t_corr, double vs, const double *a_corr, double qs,
+                               double *log_likelihood);
+
+/* `calc_travel_time` (:100-138) / `calc_amp` (:183-222): out arrays are (n_sta, n_events), demeaned */
+int htm_forward_travel_time(htm_forward *h, const double *hypo, const double *t_corr, double vs,
+                            double *t_syn);
+int htm_forward_amp(htm_forward *h, const double *hypo, const double *a_corr, double qs, double vs,
+                    double *a_syn);
+/* `calc_travel_time_single` (:142-179) / `calc_amp_single` (:226-264): out arrays are n_sta long */
+int htm_forward_travel_time_single(htm_forward *h, int evt_id, const double *hypo, const double *t_corr,
+                                   double vs, double *t_syn);
+int htm_forward_amp_single(htm_forward *h, int evt_id, const double *hypo, const double *a_corr,
+                           double qs, double vs, double *a_syn);
+
+/* Batched full evaluation: n_models independent (hypo, t_corr, vs, a_corr, qs) sets in ONE launch --
+ * what a chain-parallel caller needs instead of n_models calls of :268-303.  Stacked model-major:
+ * hypo [n_models][3E], t_corr/a_corr [n_models][S], vs/qs/out [n_models]. */
+int htm_forward_loglik_full_batch(htm_forward *h, int n_models, const double *hypo, const double *t_corr,
+                                  const double *vs, const double *a_corr, const double *qs,
+                                  double *log_likelihood);
+/* Same with every array already resident in HBM (device pointers).  Asynchronous on the handle's stream;
+ * d_log_likelihood is valid after htm_forward_sync().  This is the kernel bench.py prices against the
+ * HBM roofline. */
+int htm_forward_loglik_full_batch_dev(htm_forward *h, int n_models, const double *d_hypo,
+                                      const double *d_t_corr, const double *d_vs, const double *d_a_corr,
+                                      const double *d_qs, double *d_log_likelihood);
+int htm_forward_sync(htm_forward *h);
+
+/* Wall-clock-free timing of the last htm_forward_loglik_full_batch_dev launches: brackets `reps`
+ * launches with HIP events on the handle's stream and returns the average kernel time in microseconds. */
+int htm_forward_time_full_batch_dev(htm_forward *h, int n_models, const double *d_hypo,
+                                    const double *d_t_corr, const double *d_vs, const double *d_a_corr,
+                                    const double *d_qs, double *d_log_likelihood, int reps,
+                                    double *avg_us);
+
+/* ------------------------------------------------------------------------------------------------
+ * Device-resident chains: `type mcmc` x n_chains inside `type parallel`
+ *                          reference: src/cls_mcmc.f90, src/cls_parallel.f90, src/hypo_tremor_mcmc.f90
+ * ---------------------------------------------------------------------------------------------- */
+
+/* One `type model` (src/cls_model.f90:5-27) per parameter group, stacked chain-major.  Every pointer is
+ * [n_chains][nx] with nx = 3*n_events (hypo), n_sta (t_corr, a_corr) or 1 (vs, qs).  mu/sigma/step_size/
+ * prior_type may be NULL for a group that is never perturbed (solve_* = 0; the reference leaves them
+ * unset too, src/hypo_tremor_mcmc.f90:133-137). */
+typedef struct {
+    const double  *x;
+    const double  *mu;
+    const double  *sigma;
+    const double  *step_size;
+    const int32_t *prior_type;   /* 0 Gaussian, 1 Rayleigh (src/cls_model.f90:9) */
+} htm_model_init;
+
+typedef struct {
+    int            n_chains;      /* chains on this rank            (para%get_n_chains()) */
+    int            n_procs;       /* ranks in the job               (mpi_comm_size)       */
+    int            rank;          /* this rank                      (mpi_comm_rank)       */
+    htm_model_init hypo, t_corr, vs, a_corr, qs;
+    const double  *temp;          /* [n_chains] initial temperatures (src/hypo_tremor_mcmc.f90:202-208) */
+    int            solve_vs, solve_t_corr, solve_qs, solve_a_corr;   /* -> proposal mix, src/cls_mcmc.f90:91-108 */
+    uint32_t       rng_state[4];  /* mod_random's (x, y, z, w) after the rank's set-up draws */
+    int            n_burn;        /* parameters are recorded only for i > n_burn (src/hypo_tremor_mcmc.f90:272) */
+    int            n_interval;    /* record when mod(i, n_interval) == 1          (:271) */
+    int            lik_capacity;  /* record-buffer sizes (records held on the device between drains); */
+    int            sample_capacity; /* 0 = defaults */
+} htm_chains_init;
+
+int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **out);
+int htm_chains_destroy(htm_chains *hc);
+
+/* Single-rank job (n_procs == 1): run n_iter iterations of the main loop
+ * (src/hypo_tremor_mcmc.f90:236-284: propose -> forward -> judge per chain, then swap_temperature),
+ * entirely on the device.  Synchronous; records are drained into host memory as needed. */
+int htm_chains_run(htm_chains *hc, int n_iter);
+
+/* Lock-step multi-rank iteration (n_procs >= 1).  step_begin enqueues propose -> forward -> judge for all
+ * chains of this rank and fills this rank's swap record; the caller all-gathers the records of all ranks
+ * (RCCL through torch.distributed, or MPI) into a device buffer [n_procs][record_bytes] and hands it to
+ * step_end, which enqueues the temperature swap of src/cls_parallel.f90:100-216.  Nothing here blocks the
+ * host; all work is stream-ordered. */
+int htm_chains_step_begin(htm_chains *hc);
+int htm_chains_swap_record(htm_chains *hc, void **d_record, size_t *record_bytes);
+int htm_chains_step_end(htm_chains *hc, const void *d_gathered_records);
+int htm_chains_sync(htm_chains *hc);        /* wait + raise device-side error flags */
+int htm_chains_drain(htm_chains *hc);       /* sync + move device record buffers to host memory */
+
+int htm_chains_iterations_done(htm_chains *hc, int *n);
+
+/* chain state (`pt%get_mc(j)` + getters of src/cls_mcmc.f90:252-420); chain is 0-based; NULLs skipped */
+int htm_chains_get_state(htm_chains *hc, int chain, double *hypo, double *t_corr, double *vs,
+                         double *a_corr, double *qs, double *temp, double *log_likelihood,
+                         int32_t n_propose[7], int32_t n_accept[7]);
+int htm_chains_get_rng(htm_chains *hc, uint32_t state[4]);
+
+/* What the reference streams to likelihoodRR.out (src/hypo_tremor_mcmc.f90:279): (iteration, value) in
+ * file order, plus the chain index that produced it. */
+int htm_chains_lik_count(htm_chains *hc, int *n);
+int htm_chains_lik_read(htm_chains *hc, int32_t *iter, int32_t *chain, double *log_likelihood);
+/* What goes to vs/hypo/t_corr/qs/a_corr.RR.out (:273-277), sample k in file order */
+int htm_chains_sample_count(htm_chains *hc, int *n);
+int htm_chains_sample_read(htm_chains *hc, int k, int32_t *iter, int32_t *chain, double *vs, double *qs,
+                           double *hypo, double *t_corr, double *a_corr);
+int htm_chains_clear_records(htm_chains *hc);
+
+/* Per-step trace for parity debugging: rows {iter, chain, type(1..7), index(1-based), prior_ok, accepted,
+ * used_full, 0} and {x_new, loglik_proposed, loglik_after, temp}.  capacity 0 disables. */
+int htm_chains_enable_steplog(htm_chains *hc, int capacity);
+int htm_chains_steplog_read(htm_chains *hc, int *n, int32_t *irows, double *drows);
+
+/* Kernel timing collected with HIP events inside htm_chains_run (stream-ordered, no extra syncs):
+ * total device time of the last run in microseconds and the number of graph replays issued. */
+int htm_chains_last_run_stats(htm_chains *hc, double *device_us, int *graph_launches,
+                              int64_t *full_evals, int64_t *partial_evals);
+
+/* self-test of the wave-level reduction and RNG device code against straightforward device loops;
+ * returns 0 when they agree bit for bit */
+int htm_selftest(int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HTM_HIP_H */

@@ -609,6 +609,9 @@ static int judge_swap(double temp1, double temp2, double l1, double l2, orc_rng 
 static void swap_temperature(orc_job *job)
 {
     const int n_proc = job->p.n_procs, n_chain = job->p.n_chains;
+    /* with a single chain in the whole job the reference's select_pair never terminates
+     * (src/cls_parallel.f90:226-230).  Defined here (and in the HIP path) as: no swap, no draws. */
+    if (n_proc * n_chain < 2) return;
     orc_rng *rng0 = &job->ranks[0].rng;
     int i1 = (int)(orc_rand_u(rng0) * n_proc * n_chain);
     int i2;

@@ -1,0 +1,174 @@
+"""GPU parity: device-resident chains (propose -> forward -> judge -> swap on the MI355X) against the
+reference's own output (golden fixtures) and against the oracle.
+
+Criterion (north_star / SURVEY §8d): log-likelihood traces within 1e-9 relative per record, identical
+accept/reject decisions (=> identical proposal_count.txt), identical RNG consumption (=> identical final
+RNG state)."""
+import numpy as np
+import pytest
+
+from tests.helpers import load_case, tf
+
+pytestmark = pytest.mark.gpu
+
+RTOL_TRACE = 1e-9
+
+
+def _obs(data):
+    from hypotremormcmc_amd.obs_data import ObsData
+
+    return ObsData.from_arrays(data.sta_x, data.sta_y, data.t_obs, data.t_stdv, data.a_obs, data.a_stdv)
+
+
+def _build_world(data, params, **caps):
+    from hypotremormcmc_amd import driver
+
+    obs = _obs(data)
+    n_procs = int(params["n_procs"])
+    fwd, sets = None, []
+    for r in range(n_procs):
+        fwd, cs = driver.build_rank(params, data.sta_x, data.sta_y, data.sta_z, obs, r, n_procs=n_procs, fwd=fwd, **caps)
+        sets.append(cs)
+    return fwd, sets
+
+
+def _check_against_fixture(fx, params, sets):
+    n_procs = int(params["n_procs"])
+    npr = np.zeros(7, np.int64); nac = np.zeros(7, np.int64)
+    for r in range(n_procs):
+        it, ch, lk = sets[r].likelihood_trace()
+        assert np.array_equal(it, fx[f"lik_iter_{r}"]), f"rank {r}: recorded iterations differ"
+        np.testing.assert_allclose(lk, fx[f"lik_{r}"], rtol=RTOL_TRACE, atol=0)
+        smp = sets[r].samples()
+        assert np.array_equal(smp["iter"], fx[f"vs_iter_{r}"])
+        np.testing.assert_allclose(smp["vs"], fx[f"vs_{r}"][:, 0], rtol=1e-12)
+        np.testing.assert_allclose(smp["qs"], fx[f"qs_{r}"][:, 0], rtol=1e-12)
+        np.testing.assert_allclose(smp["t_corr"], fx[f"t_corr_{r}"], rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(smp["a_corr"], fx[f"a_corr_{r}"], rtol=1e-11, atol=1e-13)
+        n_h = len(fx[f"hypo_{r}"])
+        if n_h:
+            np.testing.assert_allclose(smp["hypo"][-n_h:], fx[f"hypo_{r}"], rtol=1e-11, atol=1e-12)
+        a, b = sets[r].counts()
+        npr += a; nac += b
+    assert np.array_equal(npr, fx["n_propose"])
+    assert np.array_equal(nac, fx["n_accept"])
+
+
+@pytest.mark.parametrize("name", ["c2", "missing", "c3"])
+def test_single_rank_run_matches_reference_trace(name):
+    fx, data, params = load_case(name)
+    fwd, sets = _build_world(data, params)
+    sets[0].run(int(params["n_iter"]))
+    assert sets[0].iterations_done == int(params["n_iter"])
+    _check_against_fixture(fx, params, sets)
+
+
+@pytest.mark.parametrize("name", ["c1", "timeonly", "fixedcorr"])
+def test_multi_rank_lockstep_matches_reference_trace(name):
+    """2-3 simulated ranks on one GPU; the record exchange is a device copy instead of the RCCL all-gather"""
+    from hypotremormcmc_amd.parallel import LocalWorld
+
+    fx, data, params = load_case(name)
+    fwd, sets = _build_world(data, params)
+    LocalWorld(sets).run(int(params["n_iter"]))
+    _check_against_fixture(fx, params, sets)
+
+
+def test_final_state_rng_and_steps_vs_oracle():
+    """every step of every chain against the oracle: proposal type/index, prior_ok, accept, full/partial"""
+    from oracle import oracle
+
+    fx, data, params = load_case("c2")
+    n_iter = 1500
+    job = oracle.Job(params, data)
+    job.enable_steplog(n_iter * 2)
+    job.run(n_iter)
+    fwd, sets = _build_world(data, params)
+    cs = sets[0]
+    cs.enable_steplog(n_iter * 2)
+    cs.run(n_iter)
+    assert cs.rng_state() == job.rng_state(0)              # same number of draws consumed
+    oi, od = job.steplog()
+    gi, gd = cs.steplog()
+    assert len(gi) == len(oi) == n_iter * 2
+    # oracle rows: iter, rank, chain, type, idx, prior_ok, accepted, used_full ; gpu rows: iter, chain, type, ...
+    assert np.array_equal(gi[:, 0], oi[:, 0]) and np.array_equal(gi[:, 1], oi[:, 2])
+    assert np.array_equal(gi[:, 2:7], oi[:, 3:8])
+    ok = oi[:, 5] == 1
+    np.testing.assert_allclose(gd[:, 0], od[:, 0], rtol=1e-12, atol=1e-13)          # x_new
+    np.testing.assert_allclose(gd[ok, 1], od[ok, 1], rtol=RTOL_TRACE)              # proposed log-likelihood
+    np.testing.assert_allclose(gd[:, 2], od[:, 2], rtol=RTOL_TRACE)                # current log-likelihood
+    assert np.array_equal(gd[:, 3], od[:, 3])                                      # temperatures (swaps)
+    for c in range(2):
+        s, o = cs.state(c), job.chain(0, c)
+        np.testing.assert_allclose(s.hypo, o["hypo"], rtol=1e-11, atol=1e-12)
+        np.testing.assert_allclose(s.t_corr, o["t_corr"], rtol=1e-11, atol=1e-13)
+        assert s.temp == o["temp"]
+        assert np.array_equal(s.n_propose, o["n_propose"]) and np.array_equal(s.n_accept, o["n_accept"])
+
+
+def test_lockstep_equals_single_rank_driver_bitwise():
+    """n_procs = 1: step_begin/step_end (the multi-rank code path) and htm_chains_run (graph + in-kernel
+    swap) must produce identical bits"""
+    from hypotremormcmc_amd.parallel import LocalWorld
+
+    fx, data, params = load_case("c2")
+    n_iter = 700
+    _, a = _build_world(data, params)
+    a[0].run(n_iter)
+    _, b = _build_world(data, params)
+    LocalWorld(b).run(n_iter)
+    ia, ca, la = a[0].likelihood_trace(); ib, cb, lb = b[0].likelihood_trace()
+    assert np.array_equal(ia, ib) and np.array_equal(la, lb)
+    assert a[0].rng_state() == b[0].rng_state()
+    for c in range(2):
+        assert np.array_equal(a[0].state(c).hypo, b[0].state(c).hypo)
+
+
+def test_run_in_pieces_and_small_record_buffers():
+    """run(n) == run(a) + run(b); tiny device record buffers force mid-run drains without changing results"""
+    fx, data, params = load_case("missing")
+    n_iter = int(params["n_iter"])
+    _, a = _build_world(data, params)
+    a[0].run(n_iter)
+    _, b = _build_world(data, params, lik_capacity=8, sample_capacity=6)
+    b[0].run(1000); b[0].run(1); b[0].run(n_iter - 1001)
+    ia, _, la = a[0].likelihood_trace(); ib, _, lb = b[0].likelihood_trace()
+    assert np.array_equal(ia, ib) and np.array_equal(la, lb)
+    sa, sb = a[0].samples(), b[0].samples()
+    assert np.array_equal(sa["iter"], sb["iter"]) and np.array_equal(sa["hypo"], sb["hypo"])
+    _check_against_fixture(fx, params, b)
+
+
+def test_single_chain_job_has_no_swap():
+    """quirk 1: the reference hangs for n_procs*n_chains == 1; defined as 'no swap, no draws' (oracle too)"""
+    from oracle import oracle
+
+    fx, data, params = load_case("c2")
+    params = dict(params, n_chains="1")
+    job = oracle.Job(params, data); job.run(800)
+    _, sets = _build_world(data, params)
+    sets[0].run(800)
+    it, lk = job.likelihood_trace(0)
+    gi, _, gl = sets[0].likelihood_trace()
+    assert np.array_equal(gi, it)
+    np.testing.assert_allclose(gl, lk, rtol=RTOL_TRACE)
+    assert sets[0].rng_state() == job.rng_state(0)
+
+
+def test_many_chains_per_rank():
+    """more chains than k_step has waves (8): chains are processed in rounds"""
+    from oracle import oracle
+
+    fx, data, params = load_case("c1")
+    params = dict(params, n_procs="1", n_chains="19", n_cool="3", n_iter="1200", n_burn="100", n_interval="7")
+    job = oracle.Job(params, data); job.run(1200)
+    _, sets = _build_world(data, params)
+    sets[0].run(1200)
+    it, lk = job.likelihood_trace(0)
+    gi, _, gl = sets[0].likelihood_trace()
+    assert np.array_equal(gi, it)
+    np.testing.assert_allclose(gl, lk, rtol=RTOL_TRACE)
+    assert sets[0].rng_state() == job.rng_state(0)
+    a, b = sets[0].counts(); oa, ob = job.counts()
+    assert np.array_equal(a, oa) and np.array_equal(b, ob)
