@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- MCMC proposal steps/s of the HIP likelihood inner loop on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2], the one the metric is quoted on): 1 000 synthetic events x 64 stations
+(seed 1), 8 chains per GPU, n_cool = 1, temp_high = 200, all solve_* / use_* = T, priors and step sizes of
+sample/hypo_tremor.in.  N > 1: one rank per GPU, 8 chains each (weak scaling, BASELINE configs[3] at N = 8),
+temperature swap between ANY two chains of the job every iteration, exchanged with one RCCL all-gather.
+
+A "step" for --steps/--warmup is one MCMC iteration of a rank = n_chains proposal steps (propose ->
+forward -> judge for every chain, then swap_temperature).  `value` = proposal steps per second over all
+ranks; inputs are resident in HBM before the timed region starts.
+
+Besides the driver contract the JSON line carries
+  roofline      k_full, the batched full-evaluation kernel (moves >99 % of the path's algorithmic bytes),
+                timed live with HIP events on its stream; peak = 8 TB/s HBM3E
+  kernels       live HIP-event averages for both kernels of the loop (k_step dominates TIME at 8 chains/GPU:
+                the configuration is latency-bound)
+  cpu_baseline  the CPU restatement (oracle/) timed on one host core on a bounded sample of the same workload
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_EVENTS, N_STA, N_CHAINS, SEED = 1000, 64, 8, 1
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes(E, S, w=8):
+    """bytes per full evaluation and per single-event partial update."""
+    b_full = 4 * w * S * E + 3 * w * E + 5 * w * S + w
+    b_part = 4 * w * S + 6 * w + 5 * w * S + 2 * w
+    return b_full, b_part
+
+
+def cpu_baseline(params, data, seconds_target=12.0):
+    """oracle/ (kind = port) on ONE host core: same workload, bounded sample."""
+    from oracle import oracle
+
+    job = oracle.Job(params, data)
+    job.run(200)                                  # includes the all-full first iteration; not timed
+    t0 = time.perf_counter(); job.run(500); dt = time.perf_counter() - t0
+    n_it = max(500, int(500 * seconds_target / max(dt, 1e-3)))
+    t0 = time.perf_counter(); job.run(n_it); dt = time.perf_counter() - t0
+    n_chains = int(params["n_chains"])
+    return {"value": n_it * n_chains / dt, "unit": "proposal steps/s", "cores": 1, "kind": "port",
+            "sample": f"{n_it} iterations x {n_chains} chains of the same {data.n_events}x{data.n_sta} workload "
+                      f"on 1 core ({dt:.1f} s), oracle/htm_oracle.c (gcc -O2, no fast-math)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20000)
+    ap.add_argument("--warmup", type=int, default=2000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--chains", type=int, default=N_CHAINS)
+    ap.add_argument("--events", type=int, default=N_EVENTS)
+    ap.add_argument("--stations", type=int, default=N_STA)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N > 1 with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    import torch  # device plumbing + torch.distributed only
+
+    from hypotremormcmc_amd import driver, synth
+    from hypotremormcmc_amd.obs_data import ObsData
+
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    E, S, nc = args.events, args.stations, args.chains
+    data = synth.make_synthetic(E, S, SEED)
+    params = dict(synth.DEFAULT_PARAMS, n_procs=world, n_chains=nc, n_cool=1,
+                  n_iter=args.steps + args.warmup + 10 ** 6, n_burn=10 ** 9, n_interval=1000)
+    obs = ObsData.from_arrays(data.sta_x, data.sta_y, data.t_obs, data.t_stdv, data.a_obs, data.a_stdv)
+    fwd, cs = driver.build_rank(params, data.sta_x, data.sta_y, data.sta_z, obs, rank, n_procs=world,
+                                device=local_rank)
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if world == 1:
+        run = cs.run
+    else:
+        from hypotremormcmc_amd.parallel import TorchWorld
+
+        tw = TorchWorld(cs)
+        run = tw.run
+
+    run(args.warmup)
+    sync_all()
+    t0 = time.perf_counter()
+    run(args.steps)
+    cs.sync()
+    sync_all()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert cs.iterations_done == args.warmup + args.steps
+
+    value = world * nc * args.steps / dt
+    b_full, b_part = algorithmic_bytes(E, S)
+    out = {
+        "metric": "MCMC proposal steps/sec (whole node), 1k events x 64 stn",
+        "value": value, "unit": "proposal steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{E} events x {S} stations, {nc} chains/GPU x {world} GPU(s), swap every "
+                               f"iteration, all solve_*/use_* = T (BASELINE configs[{2 if world == 1 else 3}])",
+                   "chains_per_gpu": nc, "n_events": E, "n_sta": S, "seed": SEED,
+                   "step_definition": "one MCMC iteration of a rank = n_chains proposal steps",
+                   "parallelism": f"chains sharded over {world} rank(s); one all-gather of "
+                                  f"{8 * (4 + 2 * nc)} B per rank per iteration" if world > 1 else "single rank"},
+    }
+
+    if rank == 0 and world == 1:
+        # ---- live per-kernel timings (HIP events on the kernels' stream), same chains, continuing the run
+        n_prof = min(4000, max(500, args.steps // 5))
+        prof = cs.profile(n_prof)
+        full_avg_us = prof["full_us"] / max(1, prof["full_launches"])
+        step_avg_us = prof["step_us"] / max(1, prof["step_launches"])
+        evals_per_launch = prof["full_evals"] / max(1, prof["full_launches"])
+        bytes_per_launch = evals_per_launch * b_full
+        achieved = bytes_per_launch / (full_avg_us * 1e-6) / 1e9
+        out["roofline"] = {
+            "bound": "hbm", "kernel": "k_full<1> (batched full log-likelihood)",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "bytes_per_launch": bytes_per_launch, "evals_per_launch": evals_per_launch,
+            "avg_launch_us": full_avg_us, "launches": prof["full_launches"],
+            "note": "algorithmic bytes = 2 074 568 B per full evaluation (SURVEY 8d) x evaluations per launch; "
+                    "a launch in the MCMC loop carries only the chains whose proposal needs a full evaluation",
+        }
+        out["kernels"] = {
+            "k_step": {"avg_launch_us": step_avg_us, "launches": prof["step_launches"],
+                       "partial_evals": prof["partial_evals"],
+                       "algorithmic_bytes": prof["partial_evals"] * b_part},
+            "k_full": {"avg_launch_us": full_avg_us, "launches": prof["full_launches"],
+                       "full_evals": prof["full_evals"], "algorithmic_bytes": prof["full_evals"] * b_full},
+            "time_share_k_step": prof["step_us"] / max(1e-9, prof["step_us"] + prof["full_us"]),
+            "iterations_profiled": n_prof,
+        }
+        # whole-loop algorithmic traffic of the timed region (steps/s x expected bytes per step)
+        st = cs.last_run_stats()
+        out["loop_algorithmic_GBps"] = None
+        # ---- standalone batched full evaluation: 64 models resident in HBM, the kernel's own ceiling
+        nb = 64
+        g = torch.Generator(device="cpu").manual_seed(3)
+        hyp = torch.tensor(data.ev_xyz.reshape(-1), dtype=torch.float64).repeat(nb, 1)
+        hyp = (hyp + torch.randn(hyp.shape, generator=g, dtype=torch.float64)).cuda()
+        tc = (0.2 * torch.randn(nb, S, generator=g, dtype=torch.float64)).cuda()
+        ac = (0.02 * torch.randn(nb, S, generator=g, dtype=torch.float64)).cuda()
+        vs = (3.0 + 0.2 * torch.randn(nb, generator=g, dtype=torch.float64)).cuda()
+        qs = (250.0 + 30.0 * torch.randn(nb, generator=g, dtype=torch.float64)).cuda()
+        L = torch.empty(nb, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        us = fwd.time_full_batch_dev(nb, hyp.data_ptr(), tc.data_ptr(), vs.data_ptr(), ac.data_ptr(),
+                                     qs.data_ptr(), L.data_ptr(), reps=200)
+        gbs = nb * b_full / (us * 1e-6) / 1e9
+        out["full_eval_batch64"] = {"avg_launch_us": us, "achieved_GBps": gbs, "frac_of_peak": gbs / HBM_PEAK_GBS,
+                                    "evals_per_s": nb / (us * 1e-6),
+                                    "note": "k_full + k_sum_partials, 64 models per launch, HIP events"}
+        out["loop_algorithmic_GBps"] = (st["full_evals"] * b_full + st["partial_evals"] * b_part) / dt / 1e9
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(dict(params, n_procs=1), data)
+    elif rank == 0:
+        b_step = 0.1 * b_full + 0.9 * b_part
+        ach = value * b_step / 1e9 / world
+        out["roofline"] = {"bound": "hbm", "kernel": "whole loop (per GPU)", "achieved": ach, "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "note": "N > 1: steps/s x 211 662 B expected algorithmic bytes per step / n_gpus; "
+                                   "per-kernel figures are reported by the N = 1 run"}
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -178,6 +178,14 @@ class ChainSet:
                                                     dr.ctypes.data_as(dp)))
         return ir, dr
 
+    def profile(self, n_iter: int):
+        """Run n_iter iterations with every kernel launch bracketed by HIP events (see htm_chains_profile)."""
+        su = C.c_double(); fu = C.c_double(); sn = C.c_int(); fn = C.c_int(); fe = C.c_int64(); pe = C.c_int64()
+        check(self._lib.htm_chains_profile(self.handle, int(n_iter), C.byref(su), C.byref(sn), C.byref(fu),
+                                           C.byref(fn), C.byref(fe), C.byref(pe)))
+        return dict(step_us=su.value, step_launches=sn.value, full_us=fu.value, full_launches=fn.value,
+                    full_evals=fe.value, partial_evals=pe.value)
+
     def last_run_stats(self):
         us = C.c_double(); g = C.c_int(); f = C.c_int64(); p = C.c_int64()
         check(self._lib.htm_chains_last_run_stats(self.handle, C.byref(us), C.byref(g), C.byref(f), C.byref(p)))

@@ -672,6 +672,53 @@ int htm_chains_run(htm_chains *hc, int n_iter)
     return drain_records(hc);
 }
 
+int htm_chains_profile(htm_chains *hc, int n_iter, double *step_us, int *step_launches, double *full_us,
+                       int *full_launches, int64_t *full_evals, int64_t *partial_evals)
+{
+    if (!hc || n_iter < 0) return fail(HTM_EINVAL, "bad argument");
+    if (hc->dev.n_procs != 1) return fail(HTM_ESTATE, "htm_chains_profile is single-rank");
+    htm_forward *h = hc->fwd;
+    HIPCHK(hipSetDevice(h->device));
+    int rc = read_ctrl(hc);
+    if (rc) return rc;
+    hc->h_target = hc->h_ctrl.iter_done + n_iter;
+    HIPCHK(hipMemcpyAsync(&hc->dev.ctrl->iter_target, &hc->h_target, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    const long long f0 = hc->h_ctrl.n_full_evals, p0 = hc->h_ctrl.n_partial_evals;
+    constexpr int B = 64;                       // launch pairs between host checks
+    std::vector<hipEvent_t> ev(3 * B);
+    for (auto &e : ev) HIPCHK(hipEventCreate(&e));
+    const FullJob jb = chain_full_job(hc);
+    double s_us = 0.0, f_us = 0.0;
+    int s_n = 0, f_n = 0;
+    while (true) {
+        if (hc->h_target - hc->h_ctrl.iter_done <= 0 && hc->h_ctrl.stage == ST_IDLE) break;
+        for (int k = 0; k < B; ++k) {
+            HIPCHK(hipEventRecord(ev[3 * k], h->stream));
+            if ((rc = launch_step(hc, MODE_RUN, -1, nullptr))) return rc;
+            HIPCHK(hipEventRecord(ev[3 * k + 1], h->stream));
+            if ((rc = launch_full(h, jb, 1))) return rc;
+            HIPCHK(hipEventRecord(ev[3 * k + 2], h->stream));
+        }
+        if ((rc = read_ctrl(hc))) return rc;
+        if ((rc = ctrl_error(hc))) return rc;
+        for (int k = 0; k < B; ++k) {
+            float a = 0.f, b = 0.f;
+            HIPCHK(hipEventElapsedTime(&a, ev[3 * k], ev[3 * k + 1]));
+            HIPCHK(hipEventElapsedTime(&b, ev[3 * k + 1], ev[3 * k + 2]));
+            s_us += 1000.0 * a; f_us += 1000.0 * b; s_n++; f_n++;
+        }
+        if (hc->h_ctrl.stop && (rc = drain_records(hc))) return rc;
+    }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    if (step_us) *step_us = s_us;
+    if (step_launches) *step_launches = s_n;
+    if (full_us) *full_us = f_us;
+    if (full_launches) *full_launches = f_n;
+    if (full_evals) *full_evals = hc->h_ctrl.n_full_evals - f0;
+    if (partial_evals) *partial_evals = hc->h_ctrl.n_partial_evals - p0;
+    return drain_records(hc);
+}
+
 int htm_chains_step_begin(htm_chains *hc)
 {
     if (!hc) return fail(HTM_EINVAL, "NULL handle");

@@ -31,39 +31,68 @@ def record_tensor(cs: ChainSet):
     return torch.as_tensor(_DevBuf(ptr, nbytes // 8), device=f"cuda:{cs.fwd.device}")
 
 
-class TorchWorld:
-    """One rank of a torch.distributed job (already initialised, backend nccl = RCCL)."""
+class DeviceRank:
+    """Adapter: one rank's ChainSet on its GPU, in the shape TorchWorld drives."""
 
-    def __init__(self, cs: ChainSet, group=None):
+    def __init__(self, cs: ChainSet):
         import torch
-        import torch.distributed as dist
 
-        self.torch, self.dist, self.cs, self.group = torch, dist, cs, group
-        self.world = dist.get_world_size(group)
-        assert self.world == cs.n_procs and dist.get_rank(group) == cs.rank
+        self.cs = cs
+        self.n_procs, self.rank = cs.n_procs, cs.rank
         torch.cuda.set_device(cs.fwd.device)
         # our kernels and the collective must share one stream order
         cs.fwd.set_stream(torch.cuda.current_stream().cuda_stream)
-        self.rec = record_tensor(cs)
+        self.record = record_tensor(cs)
+
+    def step_begin(self):
+        self.cs.step_begin()
+
+    def step_end(self, gathered):
+        self.cs.step_end(gathered.data_ptr())
+
+    def drain(self):
+        self.cs.drain()
+
+    def counts(self):
+        return self.cs.counts()
+
+
+class TorchWorld:
+    """One rank of a torch.distributed job (already initialised; backend "nccl" = RCCL over xGMI on the GPUs,
+    "gloo" for the CPU tests).  `rank_obj` is a DeviceRank (or a ChainSet, wrapped here); anything with
+    .n_procs .rank .record (a float64 tensor viewing the rank's swap record) .step_begin() .step_end(gathered)
+    .drain() .counts() works, which is how the CPU tests drive the protocol without a GPU."""
+
+    def __init__(self, rank_obj, group=None):
+        import torch
+        import torch.distributed as dist
+
+        if isinstance(rank_obj, ChainSet):
+            rank_obj = DeviceRank(rank_obj)
+        self.torch, self.dist, self.r, self.group = torch, dist, rank_obj, group
+        self.world = dist.get_world_size(group)
+        if self.world != rank_obj.n_procs or dist.get_rank(group) != rank_obj.rank:
+            raise ValueError("torch.distributed world/rank do not match the chain set's n_procs/rank")
+        self.rec = rank_obj.record
         self.gathered = torch.zeros(self.world * self.rec.numel(), dtype=torch.float64, device=self.rec.device)
         # records a rank may hold between drains: n_chains per iteration at most
         self.drain_every = 4096
 
     def step(self):
-        self.cs.step_begin()
+        self.r.step_begin()
         self.dist.all_gather_into_tensor(self.gathered, self.rec, group=self.group)
-        self.cs.step_end(self.gathered.data_ptr())
+        self.r.step_end(self.gathered)
 
     def run(self, n_iter: int):
         for k in range(n_iter):
             self.step()
             if (k + 1) % self.drain_every == 0:
-                self.cs.drain()
-        self.cs.drain()
+                self.r.drain()
+        self.r.drain()
 
     def reduce_counts(self):
-        npr, nac = self.cs.counts()
-        t = self.torch.tensor(np.concatenate([npr, nac]), device=self.rec.device)
+        npr, nac = self.r.counts()
+        t = self.torch.tensor(np.concatenate([npr, nac]).astype(np.int64), device=self.rec.device)
         self.dist.all_reduce(t, group=self.group)
         t = t.cpu().numpy()
         return t[:7], t[7:]

@@ -190,6 +190,14 @@ int htm_chains_steplog_read(htm_chains *hc, int *n, int32_t *irows, double *drow
 int htm_chains_last_run_stats(htm_chains *hc, double *device_us, int *graph_launches,
                               int64_t *full_evals, int64_t *partial_evals);
 
+/* Same work as htm_chains_run, but every kernel is launched eagerly and bracketed by its own pair of HIP
+ * events on the handle's stream, so that the average duration of each kernel comes from the run itself:
+ * k_step (proposals + partial updates + judge + swap; may cover several iterations per launch) and k_full
+ * (batched full evaluations).  Returns sums in microseconds and launch counts; the chains advance by
+ * n_iter iterations exactly as with htm_chains_run. */
+int htm_chains_profile(htm_chains *hc, int n_iter, double *step_us, int *step_launches, double *full_us,
+                       int *full_launches, int64_t *full_evals, int64_t *partial_evals);
+
 /* self-test of the wave-level reduction and RNG device code against straightforward device loops;
  * returns 0 when they agree bit for bit */
 int htm_selftest(int device);

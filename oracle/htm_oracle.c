@@ -358,6 +358,7 @@ typedef struct {
     /* hypo.RR.out & friends */
     int         n_smp, cap_smp;
     orc_sample *smp;
+    int         iter;      /* per-rank lock-step mode: iterations completed by this rank */
 } orc_rank;
 
 struct orc_job {
@@ -639,6 +640,62 @@ void orc_job_run(orc_job *job, int n)
             for (int j = 0; j < job->p.n_chains; ++j) chain_step(job, r, j, i);
         swap_temperature(job);
     }
+}
+
+int orc_job_record_words(const orc_job *job) { return 4 + 2 * job->p.n_chains; }
+
+void orc_job_rank_begin(orc_job *job, int rank, double *rec)
+{
+    orc_rank *rk = &job->ranks[rank];
+    const int n_proc = job->p.n_procs, n_chain = job->p.n_chains;
+    const int i = rk->iter + 1;
+    for (int j = 0; j < n_chain; ++j) chain_step(job, rank, j, i);
+    rec[0] = rec[1] = -1.0;
+    rec[2] = 0.0;
+    rec[3] = (double)i;
+    if (n_proc * n_chain > 1) {
+        if (rank == 0) { /* select_pair, src/cls_parallel.f90:226-230 */
+            int i1 = (int)(orc_rand_u(&rk->rng) * n_proc * n_chain), i2;
+            for (;;) {
+                i2 = (int)(orc_rand_u(&rk->rng) * n_proc * n_chain);
+                if (i1 != i2) break;
+            }
+            rec[0] = (double)i1;
+            rec[1] = (double)i2;
+        }
+        orc_rng peek = rk->rng; /* the rand_u() of judge_swap (:294), not consumed yet */
+        rec[2] = orc_rand_u(&peek);
+    }
+    for (int c = 0; c < n_chain; ++c) {
+        rec[4 + 2 * c] = rk->chains[c].temp;
+        rec[5 + 2 * c] = rk->chains[c].log_likelihood;
+    }
+}
+
+int orc_job_rank_end(orc_job *job, int rank, const double *g)
+{
+    orc_rank *rk = &job->ranks[rank];
+    const int n_proc = job->p.n_procs, n_chain = job->p.n_chains, RW = 4 + 2 * n_chain;
+    const int i = rk->iter + 1;
+    if (n_proc * n_chain > 1) {
+        for (int r = 0; r < n_proc; ++r)
+            if ((int)g[(size_t)r * RW + 3] != i) return -6;
+        const int i1 = (int)g[0], i2 = (int)g[1];
+        const int rank1 = i1 / n_chain, chain1 = i1 % n_chain, rank2 = i2 / n_chain, chain2 = i2 % n_chain;
+        const double T1 = g[(size_t)rank1 * RW + 4 + 2 * chain1], L1 = g[(size_t)rank1 * RW + 5 + 2 * chain1];
+        const double T2 = g[(size_t)rank2 * RW + 4 + 2 * chain2], L2 = g[(size_t)rank2 * RW + 5 + 2 * chain2];
+        const double r = g[(size_t)rank1 * RW + 2];
+        const double del_s = (L2 - L1) * (1.0 / T1 - 1.0 / T2);
+        int acc = 0;
+        if (r >= EPS) { if (log(r) <= del_s) acc = 1; }
+        if (acc) {
+            if (rank == rank1) rk->chains[chain1].temp = T2;
+            if (rank == rank2) rk->chains[chain2].temp = T1;
+        }
+        if (rank == rank1) (void)orc_rand_u(&rk->rng);
+    }
+    rk->iter = i;
+    return 0;
 }
 
 int orc_job_n_lik(const orc_job *job, int rank) { return job->ranks[rank].n_lik; }

@@ -81,6 +81,15 @@ void     orc_job_destroy(orc_job *job);
 /* Runs iterations i = i_done+1 .. i_done+n (main loop src/hypo_tremor_mcmc.f90:236-284). */
 void     orc_job_run(orc_job *job, int n);
 
+/* Per-rank lock-step mode: the same job advanced one rank at a time with the swap decided from
+ * all-gathered records -- the protocol the HIP path uses across GPUs.  Record layout, 8-byte
+ * words: [0] i1, [1] i2 (global chain indices chosen by rank 0, -1 elsewhere), [2] this rank's pending
+ * judge_swap draw (peeked, consumed only if the rank turns out to be rank1), [3] iteration,
+ * [4+2c] temperature and [5+2c] log-likelihood of chain c.  Do not mix with orc_job_run on one job. */
+int      orc_job_record_words(const orc_job *job);
+void     orc_job_rank_begin(orc_job *job, int rank, double *record);
+int      orc_job_rank_end(orc_job *job, int rank, const double *gathered); /* 0 ok, -6 iteration mismatch */
+
 /* Recorded output (what the reference writes to likelihoodRR.out / hypo.RR.out / ...) */
 int      orc_job_n_lik(const orc_job *job, int rank);
 void     orc_job_get_lik(const orc_job *job, int rank, int32_t *iter, double *lik);

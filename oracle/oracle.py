@@ -73,6 +73,9 @@ def lib():
     L.orc_job_create.argtypes = [C.POINTER(OrcParams), C.c_int, C.c_int] + [dp] * 7
     L.orc_job_destroy.argtypes = [vp]
     L.orc_job_run.argtypes = [vp, C.c_int]
+    L.orc_job_record_words.argtypes = [vp]
+    L.orc_job_rank_begin.argtypes = [vp, C.c_int, dp]
+    L.orc_job_rank_end.argtypes = [vp, C.c_int, dp]
     L.orc_job_n_lik.argtypes = [vp, C.c_int]
     L.orc_job_get_lik.argtypes = [vp, C.c_int, ip, dp]
     L.orc_job_n_samples.argtypes = [vp, C.c_int]
@@ -211,6 +214,18 @@ class Job:
 
     def run(self, n: int):
         lib().orc_job_run(self.h, int(n))
+
+    # per-rank lock-step mode (the multi-GPU protocol on the CPU)
+    def record_words(self) -> int:
+        return lib().orc_job_record_words(self.h)
+
+    def rank_begin(self, rank: int, record: np.ndarray):
+        assert record.dtype == np.float64 and record.flags.c_contiguous
+        lib().orc_job_rank_begin(self.h, int(rank), record.ctypes.data_as(C.POINTER(C.c_double)))
+
+    def rank_end(self, rank: int, gathered: np.ndarray) -> int:
+        assert gathered.dtype == np.float64 and gathered.flags.c_contiguous
+        return lib().orc_job_rank_end(self.h, int(rank), gathered.ctypes.data_as(C.POINTER(C.c_double)))
 
     def likelihood_trace(self, rank: int):
         n = lib().orc_job_n_lik(self.h, rank)

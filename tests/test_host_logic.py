@@ -1,0 +1,98 @@
+"""CPU: host-side mirrors of the reference interfaces -- RNG, model set-up order, parameter-file grammar,
+opt_data reader, output writers -- against the oracle / golden fixtures."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from hypotremormcmc_amd import driver, synth
+from hypotremormcmc_amd.mod_random import Xorshift128
+from hypotremormcmc_amd.obs_data import ObsData
+from hypotremormcmc_amd.param import Param, ParamError, parse_line
+from tests.helpers import load_case
+
+
+def test_host_rng_matches_reference_vectors():
+    fx, _, _ = load_case("c1")
+    for r in range(4):
+        g = Xorshift128(r)
+        v = [g.rand_u() for _ in range(8)] + [g.rand_u2(), g.rand_g(), g.rand_r(), g.rand_g()]
+        assert v == fx["probe_rng"][r].tolist()
+
+
+@pytest.mark.parametrize("name", ["c1", "fixedcorr", "timeonly"])
+def test_initial_models_match_oracle_setup(name):
+    """same draws in the same order as src/hypo_tremor_mcmc.f90:120-211 => identical initial state + RNG"""
+    from oracle import oracle
+
+    fx, data, params = load_case(name)
+    job = oracle.Job(params, data)
+    obs = ObsData.from_arrays(data.sta_x, data.sta_y, data.t_obs, data.t_stdv, data.a_obs, data.a_stdv)
+    x_mu, y_mu = obs.make_initial_guess()
+    for rank in range(int(params["n_procs"])):
+        models, temps, rng = driver.build_initial_models(params, data.n_sta, data.n_events, x_mu, y_mu, rank)
+        assert rng.state == job.rng_state(rank)
+        for c, m in enumerate(models):
+            st = job.chain(rank, c)
+            assert np.array_equal(m["hypo"].x, st["hypo"])
+            assert np.array_equal(m["t_corr"].x, st["t_corr"]) and np.array_equal(m["a_corr"].x, st["a_corr"])
+            assert m["vs"].x[0] == st["vs"] and m["qs"].x[0] == st["qs"] and temps[c] == st["temp"]
+            mu, sg, stp, pt = job.hypo_priors(rank, c)
+            assert np.array_equal(m["hypo"].mu, mu) and np.array_equal(m["hypo"].sigma, sg)
+            assert np.array_equal(m["hypo"].step_size, stp) and np.array_equal(m["hypo"].prior_type, pt)
+
+
+def test_param_grammar(tmp_path):
+    assert parse_line("n_iter = 4000000   # comment") == ("n_iter", "4000000")
+    assert parse_line("filename_format = $STA + / + $ID + . + $CMP ") == ("filename_format", "$STA+/+$ID+.+$CMP")
+    assert parse_line("# only a comment") is None and parse_line("novalue =") is None and parse_line("= 3") is None
+    d = synth.make_synthetic(3, 4, 0)
+    synth.write_dataset(str(tmp_path), d)
+    synth.write_param_file(str(tmp_path / "p.in"), temp_high="200.d0", solve_vs=".true.", n_chains=5)
+    p = Param(str(tmp_path / "p.in"))
+    assert p.get_temp_high() == 200.0 and p.get_solve_vs() is True and p.get_n_chains() == 5
+    assert p.get_prior_t_corr() == 0.0 and p.get_n_stations() == 4            # defaults, station file
+    assert np.array_equal(p.get_sta_x(), d.sta_x)
+    with open(tmp_path / "bad.in", "w") as f:
+        f.write(open(tmp_path / "p.in").read() + "no_such_key = 1\n")
+    with pytest.raises(ParamError, match="Invalid parameter name"):
+        Param(str(tmp_path / "bad.in"))
+    with open(tmp_path / "short.in", "w") as f:
+        f.write("station_file = station_xy.list\nn_procs = 1\n")
+    with pytest.raises(ParamError, match="is not given"):
+        Param(str(tmp_path / "short.in"))
+
+
+def test_reference_sample_parameter_file_is_accepted(tmp_path):
+    """the reference's own sample file parses unchanged (only the station file it names must exist)"""
+    ref = "/root/reference/sample/hypo_tremor.in"
+    if not os.path.exists(ref):
+        pytest.skip("reference tree not present (GPU box)")
+    d = synth.make_synthetic(2, 3, 0)
+    synth.write_dataset(str(tmp_path), d)
+    dst = tmp_path / "hypo_tremor.in"
+    dst.write_text(open(ref).read())
+    p = Param(str(dst))
+    assert p.get_n_procs() == 20 and p.get_n_chains() == 5 and p.get_n_iter() == 4000000
+    assert p.get_temp_high() == 200.0 and p.get_prior_qs() == 250.0 and p.get_use_amp() is True
+
+
+def test_obs_reader_roundtrip(tmp_path):
+    d = synth.make_synthetic(6, 5, 9, n_missing=2)
+    synth.write_dataset(str(tmp_path), d)
+    ids = driver.read_selected_win(str(tmp_path / "selected_win.dat"))
+    assert ids == list(range(1, 7))
+    obs = ObsData(ids, 5, d.sta_x, d.sta_y, directory=str(tmp_path))
+    assert np.array_equal(obs.t_obs, d.t_obs) and np.array_equal(obs.t_stdv, d.t_stdv)
+    assert np.array_equal(obs.a_obs, d.a_obs) and np.array_equal(obs.a_stdv, d.a_stdv)
+    with pytest.raises(SystemExit):
+        ObsData([99], 5, d.sta_x, d.sta_y, directory=str(tmp_path))
+
+
+def test_proposal_count_format(tmp_path):
+    p = tmp_path / "proposal_count.txt"
+    driver.write_proposal_count(str(p), [984, 985, 1001, 1021, 12041, 12124, 11844], [50, 736, 599, 906, 9326, 1358, 1852])
+    lines = p.read_text().splitlines()
+    assert lines[0] == '"vs   "       984        50' and lines[1] == '"t_cor"       985       736'
+    assert lines[4] == '"x    "     12041      9326'
