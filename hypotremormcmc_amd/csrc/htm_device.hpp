@@ -17,8 +17,7 @@ constexpr double kPi = 3.141592653589793;        // acos(-1.d0)
 constexpr double kPi2 = 6.283185307179586;       // 2.d0 * acos(-1.d0)   (mod_random.f90:33)
 constexpr double kFreq = 5.0;                    // cls_forward.f90:190
 constexpr double kEps = 2.220446049250313e-16;   // epsilon(1.d0)
-constexpr int kMaxChains = 64;                   // chains per rank held by one k_step workgroup
-constexpr int kMaxWindow = 512;                  // raw RNG draws staged per iteration (>= 6*kMaxChains+64)
+constexpr int kMaxChains = 32;                   // chains per rank held by one k_step workgroup
 
 // ---------------------------------------------------------------------------------------------------
 // wave-level fp64 sum over 64 lanes, DPP only (no LDS traffic, fixed order => deterministic)
@@ -272,6 +271,8 @@ struct Proposal {            // everything random about one chain step, resolved
     int    prior_ok;
     int    need_full;
     int    accepted;
+    int    cool;             // temperature < 1 + eps at judge time (counters, cls_mcmc.f90:186,:215)
+    int    pad_;
     double x_new, lpr;       // cls_model.f90:172-186
     double r_judge, logr_judge;   // the rand_u() of cls_mcmc.f90:197 and its log (only drawn if prior_ok)
     double L_new;
@@ -307,6 +308,7 @@ struct ChainsDev {
     int32_t *smp_iter, *smp_chain; double *smp_data;   // [cap_smp][3E + 2S + 2]
     int32_t *slog_i; double *slog_d;
     double *swap_rec;                // [4 + 2*n_chains] this rank's record (8-byte words)
+    unsigned long long *stamps;      // diagnostic builds (-DHTM_STAMPS) only, else nullptr
 };
 
 }  // namespace htm

@@ -99,7 +99,8 @@ struct htm_chains {
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
     int pairs = 32;
-    int nw = 1;
+    int nw = 1;                // chain waves of k_step (one more wave is the RNG producer)
+    int ring_size = 512, wmax = 64;
     size_t step_smem = 0;
     int h_target = 0;          // host copy of the iteration target
     int rec_len = 0;
@@ -130,11 +131,11 @@ int launch_full(htm_forward *h, const FullJob &jb, int gy)
 int launch_step(htm_chains *hc, int mode, int target, const double *gathered)
 {
     htm_forward *h = hc->fwd;
-    dim3 grid(1), block(64 * hc->nw);
+    dim3 grid(1), block(64 * (hc->nw + 1));
     switch (h->nch) {
-    case 1: hipLaunchKernelGGL(k_step<1>, grid, block, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered); break;
-    case 2: hipLaunchKernelGGL(k_step<2>, grid, block, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered); break;
-    default: hipLaunchKernelGGL(k_step<0>, grid, block, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered); break;
+    case 1: hipLaunchKernelGGL(k_step<1>, grid, block, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax); break;
+    case 2: hipLaunchKernelGGL(k_step<2>, grid, block, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax); break;
+    default: hipLaunchKernelGGL(k_step<0>, grid, block, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax); break;
     }
     HIPCHK(hipGetLastError());
     return HTM_OK;
@@ -525,6 +526,11 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
     if ((rc = dev_alloc(hc->pool, &d.smp_chain, d.cap_smp))) return cleanup(rc);
     if ((rc = dev_alloc(hc->pool, &d.smp_data, (size_t)d.cap_smp * hc->rec_len))) return cleanup(rc);
     d.slog_i = nullptr; d.slog_d = nullptr;
+    d.stamps = nullptr;
+#ifdef HTM_STAMPS
+    if ((rc = dev_alloc(hc->pool, &d.stamps, 64))) return cleanup(rc);
+    HIPCHK(hipMemset(d.stamps, 0, 64 * sizeof(unsigned long long)));
+#endif
 
     Ctrl c{};
     for (int k = 0; k < 4; ++k) c.rng[k] = init->rng_state[k];
@@ -533,7 +539,12 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
     if ((rc = dev_upload(hc->pool, &d.ctrl, &c, 1))) return cleanup(rc);
 
     hc->nw = std::min(nc, 8);
-    hc->step_smem = ((sizeof(StepShared) + 15) & ~size_t(15)) + 3 * (size_t)h->S * sizeof(double);
+    // RNG ring: a chain step draws <= 6 numbers, select_pair/judge_swap a few more (cls_parallel.f90:226-230)
+    hc->wmax = ((6 * nc + 16 + 63) / 64) * 64;
+    hc->ring_size = 512;
+    while (hc->ring_size < 2 * hc->wmax + 200) hc->ring_size *= 2;
+    hc->step_smem = ((sizeof(StepShared) + 15) & ~size_t(15)) + (size_t)hc->ring_size * (3 * sizeof(double) + 8) +
+                    3 * (size_t)h->S * sizeof(double);
     if (hc->step_smem > 64 * 1024) return cleanup(fail(HTM_EINVAL, "n_sta too large for k_step's LDS budget"));
     if (hipEventCreate(&hc->ev0) != hipSuccess || hipEventCreate(&hc->ev1) != hipSuccess)
         return cleanup(fail(HTM_EHIP, "hipEventCreate failed"));
@@ -891,6 +902,15 @@ int htm_chains_last_run_stats(htm_chains *hc, double *device_us, int *graph_laun
     return HTM_OK;
 }
 
+#ifdef HTM_STAMPS
+int htm_chains_read_stamps(htm_chains *hc, unsigned long long out[64])
+{
+    HIPCHK(hipStreamSynchronize(hc->fwd->stream));
+    HIPCHK(hipMemcpy(out, hc->dev.stamps, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return HTM_OK;
+}
+#endif
+
 int htm_selftest(int device)
 {
     int rc = use_device(device);
@@ -918,6 +938,7 @@ int htm_selftest(int device)
                             0.45020412676967681};
     for (int i = 0; i < 5; ++i)
         if (o[4 + i] != want[i]) return fail(HTM_ESTATE, "device rand_u[%d] = %.17g, want %.17g", i, o[4 + i], want[i]);
+    if (o[13] != 0.0) return fail(HTM_ESTATE, "DPP wave_incl_scan disagrees with the serial prefix sum");
     if (std::fabs(o[12] - 0.78381228502204603) > 1e-15)
         return fail(HTM_ESTATE, "device rand_g = %.17g, want 0.78381228502204603", o[12]);
     return HTM_OK;

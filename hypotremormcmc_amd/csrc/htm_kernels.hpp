@@ -75,10 +75,12 @@ __global__ __launch_bounds__(256) void k_full(FwdDev f, FullJob jb)
             for (int e = 0; e < jb.epw; ++e) {
                 const int ev = (blockIdx.x * jb.epw + e) * 4 + wave;
                 if (ev < f.E) {
-                    double px[1] = {hyp[3 * ev]}, py[1] = {hyp[3 * ev + 1]}, pz[1] = {hyp[3 * ev + 2]};
-                    if (ev == ov_evt) {
-                        if (ov_cmp == 0) px[0] = ov_val; else if (ov_cmp == 1) py[0] = ov_val; else pz[0] = ov_val;
-                    }
+                    // plain selects: an if/else-if/else chain of stores into these arrays was miscompiled
+                    // by hipcc 7.2 at -O3 (the final else-store was dropped), see DESIGN.md §7
+                    const bool ov = ev == ov_evt;
+                    const double px[1] = {(ov && ov_cmp == 0) ? ov_val : hyp[3 * ev]};
+                    const double py[1] = {(ov && ov_cmp == 1) ? ov_val : hyp[3 * ev + 1]};
+                    const double pz[1] = {(ov && ov_cmp == 2) ? ov_val : hyp[3 * ev + 2]};
                     double out[1];
                     event_misfit<NCH, 1>(f, ev, lane, st, px, py, pz, beta, q, out);
                     lane_acc += out[0];
@@ -88,10 +90,12 @@ __global__ __launch_bounds__(256) void k_full(FwdDev f, FullJob jb)
             for (int e = 0; e < jb.epw; ++e) {
                 const int ev = (blockIdx.x * jb.epw + e) * 4 + wave;
                 if (ev < f.E) {
-                    double px[1] = {hyp[3 * ev]}, py[1] = {hyp[3 * ev + 1]}, pz[1] = {hyp[3 * ev + 2]};
-                    if (ev == ov_evt) {
-                        if (ov_cmp == 0) px[0] = ov_val; else if (ov_cmp == 1) py[0] = ov_val; else pz[0] = ov_val;
-                    }
+                    // plain selects: an if/else-if/else chain of stores into these arrays was miscompiled
+                    // by hipcc 7.2 at -O3 (the final else-store was dropped), see DESIGN.md §7
+                    const bool ov = ev == ov_evt;
+                    const double px[1] = {(ov && ov_cmp == 0) ? ov_val : hyp[3 * ev]};
+                    const double py[1] = {(ov && ov_cmp == 1) ? ov_val : hyp[3 * ev + 1]};
+                    const double pz[1] = {(ov && ov_cmp == 2) ? ov_val : hyp[3 * ev + 2]};
                     double out[1];
                     event_misfit_generic<1>(f, ev, lane, s_sx, s_sy, s_sz, tc, ac, ov_kind, ov_idx, ov_val,
                                             px, py, pz, beta, q, out);
@@ -167,387 +171,9 @@ __global__ __launch_bounds__(64) void k_partial_one(FwdDev f, int ev, const doub
     if (lane == 0) *L_out = L_old + tot;
 }
 
-// ---------------------------------------------------------------------------------------------------
-// k_step
-// ---------------------------------------------------------------------------------------------------
-struct StepShared {           // fixed-size part of k_step's LDS (the station table follows it)
-    uint32_t raw[4 + kMaxWindow + 4];
-    double U[kMaxWindow], LOGU[kMaxWindow], G[kMaxWindow];
-    Proposal prop[kMaxChains];
-    double temp[kMaxChains], L[kMaxChains];
-    int pos[kMaxChains + 1];
-    int slot_l[kMaxChains], slot_s[kMaxChains];
-    uint32_t gen[4];          // generator state after raw[.. wg]
-    int wg;                   // transforms valid for positions < wg; raws valid for <= wg
-    int anyfail;
-    Ctrl c;
-};
-
-__device__ __forceinline__ ModelDev pick_model(const ChainsDev &cs, int type)
-{
-    ModelDev m;
-    const bool v = type == 1, t = type == 2, q = type == 3, a = type == 4;
-    m.x = v ? cs.vs.x : t ? cs.tc.x : q ? cs.qs.x : a ? cs.ac.x : cs.hypo.x;
-    m.mu = v ? cs.vs.mu : t ? cs.tc.mu : q ? cs.qs.mu : a ? cs.ac.mu : cs.hypo.mu;
-    m.sigma = v ? cs.vs.sigma : t ? cs.tc.sigma : q ? cs.qs.sigma : a ? cs.ac.sigma : cs.hypo.sigma;
-    m.step = v ? cs.vs.step : t ? cs.tc.step : q ? cs.qs.step : a ? cs.ac.step : cs.hypo.step;
-    m.ptype = v ? cs.vs.ptype : t ? cs.tc.ptype : q ? cs.qs.ptype : a ? cs.ac.ptype : cs.hypo.ptype;
-    m.nx = (v || q) ? 1 : (t || a) ? cs.S : cs.hypo.nx;
-    return m;
-}
-
-// thread-0 only: make position p (and the raw after it) available
-__device__ inline bool win_ensure(StepShared &sh, int p)
-{
-    while (p >= sh.wg) {
-        if (sh.wg + 1 >= kMaxWindow) return false;
-        uint32_t x = sh.gen[0], y = sh.gen[1], z = sh.gen[2], w = sh.gen[3];
-        const uint32_t r = xs128_next(x, y, z, w);
-        sh.gen[0] = x; sh.gen[1] = y; sh.gen[2] = z; sh.gen[3] = w;
-        const int k = sh.wg;              // raw[k] exists, raw[k+1] := r
-        sh.raw[4 + k + 1] = r;
-        const uint32_t r0 = sh.raw[4 + k];
-        const double u = u_of(r0);
-        sh.U[k] = u; sh.LOGU[k] = log(u); sh.G[k] = g_of(r0, r);
-        sh.wg = k + 1;
-    }
-    return true;
-}
-
-// cls_mcmc.f90:134-165 + cls_model.f90:162-190 for chain c starting at stream position pos.
-// Returns the number of draws this chain step consumes (judge draw included iff prior_ok).
-__device__ inline int propose_chain(const ChainsDev &cs, StepShared &sh, int c, int pos, bool may_extend)
-{
-    Proposal pr;
-    if (may_extend && !win_ensure(sh, pos + 6)) { sh.c.err = -4; }
-    const double a = sh.U[pos];
-    int gpos;
-    pr.evt = -999;
-    if (a < cs.th1) { pr.type = 1; pr.idx = 0; gpos = pos + 1; }
-    else if (a < cs.th2) { pr.type = 2; pr.idx = (int)(sh.U[pos + 1] * cs.S); gpos = pos + 2; }
-    else if (a < cs.th3) { pr.type = 3; pr.idx = 0; gpos = pos + 1; }
-    else if (a < cs.th4) { pr.type = 4; pr.idx = (int)(sh.U[pos + 1] * cs.S); gpos = pos + 2; }
-    else {
-        const int id = (int)(sh.U[pos + 1] * cs.E) + 1;
-        const int icmp = (int)(sh.U[pos + 2] * 3);
-        pr.idx = 3 * id - icmp - 1; pr.type = 5 + icmp; pr.evt = id; gpos = pos + 3;
-    }
-    const ModelDev M = pick_model(cs, pr.type);
-    const size_t o = (size_t)c * M.nx + pr.idx;
-    const double x_old = M.x[o], mu = M.mu[o], sigma = M.sigma[o], step = M.step[o];
-    const double x_new = x_old + sh.G[gpos] * step;
-    const double da = x_new - mu, db = x_old - mu;
-    double lpr = -(da * da - db * db) / (2.0 * sigma * sigma);
-    int ok = 1;
-    if (M.ptype[o] == 1) {
-        if (x_new <= mu) { lpr = (double)-1.0e+30f; ok = 0; }
-        else lpr = lpr + log(x_new - mu) - log(x_old - mu);
-    }
-    pr.x_new = x_new; pr.lpr = lpr; pr.prior_ok = ok; pr.need_full = 0; pr.accepted = 0; pr.L_new = 0.0;
-    const int jpos = gpos + 2;
-    pr.r_judge = ok ? sh.U[jpos] : 0.0;
-    pr.logr_judge = ok ? sh.LOGU[jpos] : 0.0;
-    sh.prop[c] = pr;
-    return (jpos - pos) + ok;
-}
-
-__device__ inline int draws_if_ok(const ChainsDev &cs, double a)
-{
-    if (a < cs.th1) return 4;
-    if (a < cs.th2) return 5;
-    if (a < cs.th3) return 4;
-    if (a < cs.th4) return 5;
-    return 6;
-}
-
-template <int NCH>
-__global__ __launch_bounds__(512) void k_step(FwdDev f, ChainsDev cs, int mode, int target_arg,
-                                               const double *gathered)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    StepShared &sh = *reinterpret_cast<StepShared *>(smem);
-    double *s_sx = reinterpret_cast<double *>(smem + ((sizeof(StepShared) + 15) & ~size_t(15)));
-    double *s_sy = s_sx + f.S;
-    double *s_sz = s_sy + f.S;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int NW = blockDim.x >> 6;
-    const int nc = cs.n_chains;
-    const bool lockstep = (mode != MODE_RUN);
-    const int n_all = cs.n_procs * nc;
-    const int RW = 4 + 2 * nc;     // swap-record words
-
-    if (tid == 0) {
-        sh.c = *cs.ctrl;
-        if (target_arg >= 0) sh.c.iter_target = target_arg;
-    }
-    for (int j = tid; j < f.S; j += blockDim.x) { s_sx[j] = f.sx[j]; s_sy[j] = f.sy[j]; s_sz[j] = f.sz[j]; }
-    for (int c = tid; c < nc; c += blockDim.x) { sh.temp[c] = cs.temp[c]; sh.L[c] = cs.L[c]; }
-    __syncthreads();
-
-    // ---------------- MODE_APPLY: cls_parallel.f90:118-213 from the all-gathered records -------------
-    if (mode == MODE_APPLY) {
-        if (tid == 0 && sh.c.stage == ST_WAIT_SWAP && sh.c.err == 0) {
-            const int iter = sh.c.iter_done + 1;
-            if (n_all > 1) {
-                for (int r = 0; r < cs.n_procs; ++r)
-                    if ((int)gathered[(size_t)r * RW + 3] != iter) sh.c.err = -6;
-                const int i1 = (int)gathered[0], i2 = (int)gathered[1];
-                const int rank1 = i1 / nc, chain1 = i1 % nc, rank2 = i2 / nc, chain2 = i2 % nc;
-                const double T1 = gathered[(size_t)rank1 * RW + 4 + 2 * chain1];
-                const double L1 = gathered[(size_t)rank1 * RW + 5 + 2 * chain1];
-                const double T2 = gathered[(size_t)rank2 * RW + 4 + 2 * chain2];
-                const double L2 = gathered[(size_t)rank2 * RW + 5 + 2 * chain2];
-                const double r = gathered[(size_t)rank1 * RW + 2];
-                const double del_s = (L2 - L1) * (1.0 / T1 - 1.0 / T2);
-                bool acc = false;
-                if (r >= kEps) { if (log(r) <= del_s) acc = true; }
-                if (acc) {
-                    if (cs.rank == rank1) cs.temp[chain1] = T2;
-                    if (cs.rank == rank2) cs.temp[chain2] = T1;
-                }
-                if (cs.rank == rank1)
-                    for (int k = 0; k < 4; ++k) sh.c.rng[k] = sh.c.rng_plus1[k];
-            }
-            sh.c.iter_done = iter;
-            sh.c.stage = ST_IDLE;
-            *cs.ctrl = sh.c;
-        }
-        return;
-    }
-
-    bool resume_full = (sh.c.stage == ST_WAIT_FULL);
-    if (mode == MODE_FINISH && !resume_full) return;
-    if (sh.c.stage == ST_WAIT_SWAP) return;          // nothing to do until the swap is applied
-    if (resume_full)
-        for (int c = tid; c < nc; c += blockDim.x) sh.prop[c] = cs.prop[c];
-    __syncthreads();
-
-    for (;;) {
-        int iter = sh.c.iter_done + 1;
-        if (!resume_full) {
-            // ---------------- S0: anything left to do? ------------------------------------------------
-            if (sh.c.iter_done >= sh.c.iter_target || sh.c.stop || sh.c.err) break;
-            if (sh.c.n_lik + nc > cs.cap_lik || sh.c.n_smp + nc > cs.cap_smp) {
-                __syncthreads();
-                if (tid == 0) { if (lockstep) sh.c.err = -5; else sh.c.stop = 1; }
-                __syncthreads();
-                break;
-            }
-            // ---------------- S0a: raw window (thread 0), mod_random.f90:63-71 -------------------------
-            int W = ((6 * nc + 8 + 63) / 64) * 64;
-            if (W > kMaxWindow - 8) W = kMaxWindow - 8;
-            if (tid == 0) {
-                uint32_t x = sh.c.rng[0], y = sh.c.rng[1], z = sh.c.rng[2], w = sh.c.rng[3];
-                sh.raw[0] = x; sh.raw[1] = y; sh.raw[2] = z; sh.raw[3] = w;
-                for (int p = 0; p <= W; ++p) sh.raw[4 + p] = xs128_next(x, y, z, w);
-                sh.gen[0] = x; sh.gen[1] = y; sh.gen[2] = z; sh.gen[3] = w;
-                sh.wg = W;
-                sh.anyfail = 0;
-            }
-            __syncthreads();
-            // ---------------- S0b: U / log U / Box-Muller for every window position, in parallel --------
-            for (int p = tid; p < W; p += blockDim.x) {
-                const uint32_t r0 = sh.raw[4 + p], r1 = sh.raw[4 + p + 1];
-                const double u = u_of(r0);
-                sh.U[p] = u; sh.LOGU[p] = log(u); sh.G[p] = g_of(r0, r1);
-            }
-            __syncthreads();
-            // ---------------- S0c: optimistic scan of stream positions (assumes prior_ok) ---------------
-            if (tid == 0) {
-                int pos = 0;
-                for (int c = 0; c < nc; ++c) {
-                    sh.pos[c] = pos;
-                    if (!win_ensure(sh, pos + 6)) sh.c.err = -4;
-                    pos += draws_if_ok(cs, sh.U[pos]);
-                }
-                sh.pos[nc] = pos;
-            }
-            __syncthreads();
-            for (int c = wave; c < nc; c += NW)
-                if (lane == 0) {
-                    propose_chain(cs, sh, c, sh.pos[c], false);
-                    if (!sh.prop[c].prior_ok) atomicOr(&sh.anyfail, 1);
-                }
-            __syncthreads();
-            if (sh.anyfail) {   // rare: a Rayleigh prior rejected => later chains start one draw earlier
-                if (tid == 0) {
-                    int pos = 0;
-                    for (int c = 0; c < nc; ++c) { sh.pos[c] = pos; pos += propose_chain(cs, sh, c, pos, true); }
-                    sh.pos[nc] = pos;
-                }
-                __syncthreads();
-            }
-            // ---------------- S0d: swap plan + RNG commit (cls_parallel.f90:226-230,:294) ---------------
-            if (tid == 0) {
-                int pos = sh.pos[nc];
-                sh.c.swap_i1 = -1; sh.c.swap_i2 = -1; sh.c.swap_r = 0.0; sh.c.swap_logr = 0.0;
-                if (n_all > 1) {
-                    if (cs.rank == 0) {
-                        if (!win_ensure(sh, pos + 2)) sh.c.err = -4;
-                        const int i1 = (int)(sh.U[pos++] * cs.n_procs * nc);
-                        int i2;
-                        for (;;) {
-                            if (!win_ensure(sh, pos + 2)) { sh.c.err = -4; i2 = (i1 + 1) % n_all; break; }
-                            i2 = (int)(sh.U[pos++] * cs.n_procs * nc);
-                            if (i1 != i2) break;
-                        }
-                        sh.c.swap_i1 = i1; sh.c.swap_i2 = i2;
-                    }
-                    if (!win_ensure(sh, pos + 2)) sh.c.err = -4;
-                    sh.c.swap_r = sh.U[pos]; sh.c.swap_logr = sh.LOGU[pos];
-                    for (int k = 0; k < 4; ++k) sh.c.rng_plus1[k] = sh.raw[pos + 1 + k];
-                    if (!lockstep) pos++;        // single rank: this rank is always rank1
-                }
-                for (int k = 0; k < 4; ++k) sh.c.rng[k] = sh.raw[pos + k];
-            }
-            __syncthreads();
-
-            // ---------------- S1: single-event partial update, wave <-> chain ---------------------------
-            for (int c = wave; c < nc; c += NW) {
-                const Proposal pr = sh.prop[c];
-                if (!pr.prior_ok) continue;
-                if (pr.evt > 0 && iter > 1) {
-                    const int ev = pr.evt - 1, cmp = pr.idx - 3 * ev;
-                    const double *hyp = cs.hypo.x + (size_t)c * cs.hypo.nx + 3 * ev;
-                    double px[2], py[2], pz[2];
-                    px[0] = px[1] = hyp[0]; py[0] = py[1] = hyp[1]; pz[0] = pz[1] = hyp[2];
-                    if (cmp == 0) px[1] = pr.x_new; else if (cmp == 1) py[1] = pr.x_new; else pz[1] = pr.x_new;
-                    const double beta = cs.vs.x[c], q = cs.qs.x[c];
-                    const double *tc = cs.tc.x + (size_t)c * cs.S, *ac = cs.ac.x + (size_t)c * cs.S;
-                    double out[2];
-                    if constexpr (NCH > 0) {
-                        StaRegs<NCH> st;
-                        load_sta_regs<NCH>(st, f.S, lane, s_sx, s_sy, s_sz, tc, ac, 0, -1, 0.0);
-                        event_misfit<NCH, 2>(f, ev, lane, st, px, py, pz, beta, q, out);
-                    } else {
-                        event_misfit_generic<2>(f, ev, lane, s_sx, s_sy, s_sz, tc, ac, 0, -1, 0.0, px, py, pz,
-                                                beta, q, out);
-                    }
-                    const double tot = wave_sum1(out[0] - out[1]);
-                    if (lane == 0) sh.prop[c].L_new = sh.L[c] + tot;
-                } else if (lane == 0) {
-                    sh.prop[c].need_full = 1;
-                }
-            }
-            __syncthreads();
-            if (tid == 0) {
-                int n = 0, np = 0;
-                for (int c = 0; c < nc; ++c) {
-                    if (sh.prop[c].need_full) cs.full_list[n++] = c;
-                    else if (sh.prop[c].prior_ok) np++;
-                }
-                sh.c.n_full = n;
-                sh.c.n_full_evals += n;
-                sh.c.n_partial_evals += np;
-            }
-            __syncthreads();
-            if (sh.c.n_full > 0) {        // hand over to k_full; resume at S2 in the next k_step launch
-                for (int c = tid; c < nc; c += blockDim.x) cs.prop[c] = sh.prop[c];
-                if (tid == 0) sh.c.stage = ST_WAIT_FULL;
-                __syncthreads();
-                break;
-            }
-        }
-        resume_full = false;
-
-        // ---------------- S2: collect k_full results, judge (cls_mcmc.f90:186-222) -----------------------
-        for (int c = wave; c < nc; c += NW) {
-            Proposal pr = sh.prop[c];
-            if (pr.need_full) {
-                double acc = 0.0;
-                for (int k = lane; k < cs.n_wg; k += 64) acc += cs.partial[(size_t)c * cs.n_wg + k];
-                const double tot = wave_sum1(acc);
-                pr.L_new = -tot - f.const_sum;
-            }
-            if (lane == 0) {
-                const double T = sh.temp[c];
-                const bool cool = T < 1.0 + kEps;
-                if (cool) cs.n_propose[c * 7 + pr.type - 1] += 1;
-                bool acc = false;
-                if (pr.prior_ok) {
-                    double ratio = (pr.L_new - sh.L[c]) / T;
-                    ratio = ratio + pr.lpr;
-                    if (pr.r_judge >= kEps) { if (pr.logr_judge <= ratio) acc = true; }
-                }
-                if (acc) {
-                    const ModelDev M = pick_model(cs, pr.type);
-                    M.x[(size_t)c * M.nx + pr.idx] = pr.x_new;
-                    sh.L[c] = pr.L_new;
-                    cs.L[c] = pr.L_new;
-                    if (cool) cs.n_accept[c * 7 + pr.type - 1] += 1;
-                }
-                const int row = sh.c.slog_n + c;
-                if (row < sh.c.slog_cap) {
-                    int32_t *ir = cs.slog_i + 8 * (size_t)row;
-                    double *dr = cs.slog_d + 4 * (size_t)row;
-                    ir[0] = iter; ir[1] = c; ir[2] = pr.type; ir[3] = pr.idx + 1; ir[4] = pr.prior_ok;
-                    ir[5] = acc ? 1 : 0; ir[6] = pr.need_full; ir[7] = 0;
-                    dr[0] = pr.x_new; dr[1] = pr.L_new; dr[2] = sh.L[c]; dr[3] = T;
-                }
-            }
-        }
-        __syncthreads();
-        // ---------------- recording (hypo_tremor_mcmc.f90:270-280), file order = chain order --------------
-        if (tid == 0) {
-            if (sh.c.slog_n < sh.c.slog_cap) sh.c.slog_n += nc;
-            for (int c = 0; c < nc; ++c) {
-                sh.slot_l[c] = -1; sh.slot_s[c] = -1;
-                if (sh.temp[c] < 1.0 + kEps && (iter % cs.n_interval) == 1) {
-                    if (iter > cs.n_burn) sh.slot_s[c] = sh.c.n_smp++;
-                    sh.slot_l[c] = sh.c.n_lik++;
-                }
-            }
-        }
-        __syncthreads();
-        for (int c = wave; c < nc; c += NW) {
-            const int sl = sh.slot_l[c], ss = sh.slot_s[c];
-            if (sl >= 0 && lane == 0) { cs.lik_iter[sl] = iter; cs.lik_chain[sl] = c; cs.lik_val[sl] = sh.L[c]; }
-            if (ss >= 0) {
-                const int nh = cs.hypo.nx, rec = nh + 2 * cs.S + 2;
-                double *dst = cs.smp_data + (size_t)ss * rec;
-                const double *hx = cs.hypo.x + (size_t)c * nh;
-                for (int k = lane; k < nh; k += 64) dst[k] = hx[k];
-                for (int k = lane; k < cs.S; k += 64) {
-                    dst[nh + k] = cs.tc.x[(size_t)c * cs.S + k];
-                    dst[nh + cs.S + k] = cs.ac.x[(size_t)c * cs.S + k];
-                }
-                if (lane == 0) {
-                    dst[nh + 2 * cs.S] = cs.vs.x[c]; dst[nh + 2 * cs.S + 1] = cs.qs.x[c];
-                    cs.smp_iter[ss] = iter; cs.smp_chain[ss] = c;
-                }
-            }
-        }
-        // ---------------- swap_temperature ------------------------------------------------------------
-        if (lockstep) {
-            if (tid == 0) {      // export this rank's record; the swap itself happens in MODE_APPLY
-                double *rec = cs.swap_rec;
-                rec[0] = (double)sh.c.swap_i1; rec[1] = (double)sh.c.swap_i2;
-                rec[2] = sh.c.swap_r; rec[3] = (double)iter;
-                for (int c = 0; c < nc; ++c) { rec[4 + 2 * c] = sh.temp[c]; rec[5 + 2 * c] = sh.L[c]; }
-                sh.c.stage = ST_WAIT_SWAP;
-            }
-            __syncthreads();
-            break;
-        }
-        if (tid == 0) {
-            if (n_all > 1) {     // both chains live on this rank: cls_parallel.f90:121-136 + :285-302
-                const int c1 = sh.c.swap_i1, c2 = sh.c.swap_i2;
-                const double T1 = sh.temp[c1], T2 = sh.temp[c2];
-                const double del_s = (sh.L[c2] - sh.L[c1]) * (1.0 / T1 - 1.0 / T2);
-                if (sh.c.swap_r >= kEps && sh.c.swap_logr <= del_s) {
-                    sh.temp[c1] = T2; sh.temp[c2] = T1;
-                    cs.temp[c1] = T2; cs.temp[c2] = T1;
-                }
-            }
-            sh.c.iter_done = iter;
-            sh.c.stage = ST_IDLE;
-        }
-        __syncthreads();
-    }
-    if (tid == 0) *cs.ctrl = sh.c;
-}
+}  // namespace htm
+#include "htm_step.hpp"
+namespace htm {
 
 // ---------------------------------------------------------------------------------------------------
 // self-test: DPP wave_sum against a serial loop of the same tree order; device RNG against host values
@@ -556,6 +182,14 @@ __global__ void k_selftest(const double *in, double *out_dpp, double *out_ref, u
                            double *rng_d)
 {
     const int lane = threadIdx.x;
+    {   // DPP inclusive scan vs a serial prefix sum (draw counts are 3..6, use a wider spread)
+        const int v = 3 + ((lane * 7 + 1) % 5);
+        const int sc = wave_incl_scan(v);
+        int ref = 0;
+        for (int i = 0; i <= lane; ++i) ref += 3 + ((i * 7 + 1) % 5);
+        const unsigned long long bad = __ballot(sc != ref);
+        if (lane == 0) rng_d[9] = bad ? 1.0 : 0.0;
+    }
     double v[2] = {in[lane], in[64 + lane]};
     wave_sum<2>(v);
     if (lane == 0) {

@@ -1,0 +1,36 @@
+"""Diagnostic: per-phase cycle shares of k_step from a -DHTM_STAMPS build (never used for timing claims).
+Build:  make -C hypotremormcmc_amd/csrc stamps ;  run on the GPU box:  python tools/stamps.py [n_chains]"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+from hypotremormcmc_amd import _lib
+
+_lib.LIB_PATH = os.path.join(ROOT, "hypotremormcmc_amd", "lib", "libhtm_hip_stamps.so")
+from hypotremormcmc_amd import driver, synth
+from hypotremormcmc_amd.obs_data import ObsData
+
+nc = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+data = synth.make_synthetic(1000, 64, 1)
+params = dict(synth.DEFAULT_PARAMS, n_procs=1, n_chains=nc, n_cool=1, n_iter=10**7, n_burn=10**9, n_interval=1000)
+obs = ObsData.from_arrays(data.sta_x, data.sta_y, data.t_obs, data.t_stdv, data.a_obs, data.a_stdv)
+fwd, cs = driver.build_rank(params, data.sta_x, data.sta_y, data.sta_z, obs, 0, n_procs=1)
+cs.run(2000)
+lib = _lib.load()
+lib.htm_chains_read_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+a = (C.c_uint64 * 16)()
+lib.htm_chains_read_stamps(cs.handle, a)
+base = list(a)
+n = 10000
+cs.run(n)
+lib.htm_chains_read_stamps(cs.handle, a)
+names = ["prologue", "P0 (ring fill / resume judge)", "passes (propose+partial+decide)", "validate+plan+finish",
+         "commit", "epilogue"]
+tot = sum(a[k] - base[k] for k in range(len(names)))
+for k, nm in enumerate(names):
+    d = a[k] - base[k]
+    print("%-34s %9.0f ticks/iter  %5.1f %%" % (nm, d / n, 100.0 * d / tot))
+st = cs.last_run_stats()
+print("total ticks/iter", tot / n, " device_us/iter", st["device_us"] / n, st)
