@@ -110,30 +110,43 @@ struct StaRegs {
 // misfit = (obs - (syn - mean))^2 * prec / 2 -- i.e. cls_forward.f90:115-118,:125-132,:283-285 (time) and
 // :201-204,:210-217,:294-296 (amplitude).  The per-event weighted means need one wave reduction per data
 // type and position; those are issued together.  All 64 lanes must call.
-template <int NCH, int NPOS>
-__device__ __forceinline__ void event_misfit(const FwdDev &f, int ev, int lane, const StaRegs<NCH> &st,
-                                             const double (&px)[NPOS], const double (&py)[NPOS],
-                                             const double (&pz)[NPOS], double beta, double q,
-                                             double (&out)[NPOS])
+// one event's observations for this lane's stations (the four coalesced HBM streams of the path)
+template <int NCH>
+struct ObsRegs {
+    double tob[NCH], tpr[NCH], aob[NCH], apr[NCH];
+    double pst, psa;     // sum_j precision(j, event), time and amplitude
+};
+
+template <int NCH>
+__device__ __forceinline__ void load_obs_regs(ObsRegs<NCH> &ob, const FwdDev &f, int ev, int lane)
 {
     const size_t base = (size_t)ev * (size_t)f.S;
-    const double qbeta = q * beta;
-    double tob[NCH], tpr[NCH], aob[NCH], apr[NCH];
-    double ts[NPOS][NCH], as[NPOS][NCH];
-    double red[2 * NPOS];
-#pragma unroll
-    for (int k = 0; k < 2 * NPOS; ++k) red[k] = 0.0;
-
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int j = lane + 64 * c;
         const bool valid = j < f.S;
-        tob[c] = tpr[c] = aob[c] = apr[c] = 0.0;
+        ob.tob[c] = ob.tpr[c] = ob.aob[c] = ob.apr[c] = 0.0;
         if (valid) {
-            if (f.use_time) { tob[c] = f.t_obs[base + j]; tpr[c] = f.t_prec[base + j]; }
-            if (f.use_amp)  { aob[c] = f.a_obs[base + j]; apr[c] = f.a_prec[base + j]; }
+            if (f.use_time) { ob.tob[c] = f.t_obs[base + j]; ob.tpr[c] = f.t_prec[base + j]; }
+            if (f.use_amp)  { ob.aob[c] = f.a_obs[base + j]; ob.apr[c] = f.a_prec[base + j]; }
         }
     }
+    ob.pst = f.use_time ? f.psum_t[ev] : 1.0;
+    ob.psa = f.use_amp ? f.psum_a[ev] : 1.0;
+}
+
+template <int NCH, int NPOS>
+__device__ __forceinline__ void event_misfit(const FwdDev &f, const ObsRegs<NCH> &ob, int lane,
+                                             const StaRegs<NCH> &st, const double (&px)[NPOS],
+                                             const double (&py)[NPOS], const double (&pz)[NPOS], double beta,
+                                             double q, double (&out)[NPOS])
+{
+    const double qbeta = q * beta;
+    const double (&tob)[NCH] = ob.tob, (&tpr)[NCH] = ob.tpr, (&aob)[NCH] = ob.aob, (&apr)[NCH] = ob.apr;
+    double ts[NPOS][NCH], as[NPOS][NCH];
+    double red[2 * NPOS];
+#pragma unroll
+    for (int k = 0; k < 2 * NPOS; ++k) red[k] = 0.0;
 #pragma unroll
     for (int p = 0; p < NPOS; ++p) {
 #pragma unroll
@@ -154,8 +167,7 @@ __device__ __forceinline__ void event_misfit(const FwdDev &f, int ev, int lane, 
         }
     }
     wave_sum<2 * NPOS>(red);
-    const double pst = f.use_time ? f.psum_t[ev] : 1.0;
-    const double psa = f.use_amp ? f.psum_a[ev] : 1.0;
+    const double pst = ob.pst, psa = ob.psa;
 #pragma unroll
     for (int p = 0; p < NPOS; ++p) {
         const double t_mean = red[2 * p] / pst;
@@ -281,12 +293,25 @@ struct Proposal {            // everything random about one chain step, resolved
 struct Ctrl {
     int iter_done, iter_target, stage, n_full;
     int err, stop, n_lik, n_smp;
-    uint32_t rng[4];         // mod_random state after everything committed so far
-    uint32_t rng_plus1[4];   // lock-step: state if this rank also consumes the judge_swap draw
+    long long spos;          // draws of the rank's mod_random stream consumed (committed) so far
     int swap_i1, swap_i2;    // cls_parallel.f90:226-230 (global chain indices)
     double swap_r, swap_logr;
     int slog_n, slog_cap;
     long long n_full_evals, n_partial_evals;
+};
+
+// The rank's random stream, produced AHEAD of consumption by k_rawgen / k_stream_* on a side stream.
+// Rings over the absolute stream position p (index = p & mask).  Nothing here depends on chain state.
+struct StreamDev {
+    uint32_t *raw;             // xorshift128 outputs (mod_random.f90:63-71)
+    double *U, *LOGU, *G;      // rand_u, log(rand_u), Box-Muller value starting at p
+    // for a chain step STARTING at p (cls_mcmc.f90:134-165 decoded ahead of time):
+    int4 *dec;                 // {type, 0-based index, event id or -999, draws consumed if prior_ok}
+    double *pg, *pr, *plogr;   // its Gaussian, its judge draw r and log r
+    int *hop;                  // [p][k-1] = position after k optimistic chain steps, k = 1..8
+    long long mask;            // capacity - 1
+    uint32_t *gen;             // [4] generator state after the last produced raw
+    long long *hop_end;        // every array is complete for positions < *hop_end
 };
 
 struct ChainsDev {
@@ -308,6 +333,7 @@ struct ChainsDev {
     int32_t *smp_iter, *smp_chain; double *smp_data;   // [cap_smp][3E + 2S + 2]
     int32_t *slog_i; double *slog_d;
     double *swap_rec;                // [4 + 2*n_chains] this rank's record (8-byte words)
+    StreamDev stream;
     unsigned long long *stamps;      // diagnostic builds (-DHTM_STAMPS) only, else nullptr
 };
 

@@ -110,6 +110,14 @@ struct htm_chains {
     int last_graph_launches = 0;
     long long run_full0 = 0, run_part0 = 0, last_full = 0, last_part = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // random-stream service (htm_stream.hpp): produced on a side stream ahead of consumption
+    hipStream_t side = nullptr;
+    hipEvent_t ev_side = nullptr;
+    long long cap = 0;                         // ring capacity (positions)
+    long long n_raw = 0, n_tr = 0, n_rec = 0, n_hop = 0;   // positions produced per stage (host view)
+    long long spos_lo = 0, spos_hi = 0;        // bounds on the consumed position since the last sync
+    uint32_t init_state[4] = {0, 0, 0, 0};     // mod_random state at stream position 0
+    double th[4] = {0, 0, 0, 0};
 };
 
 namespace {
@@ -138,6 +146,37 @@ int launch_step(htm_chains *hc, int mode, int target, const double *gathered)
     default: hipLaunchKernelGGL(k_step<0>, grid, block, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax); break;
     }
     HIPCHK(hipGetLastError());
+    return HTM_OK;
+}
+
+// Append n (multiple of 64) positions to the rank's random stream on the side stream.  Asynchronous; the
+// new coverage is published to the device (StreamDev::hop_end) by the last kernel of the sequence.
+int stream_produce(htm_chains *hc, long long n)
+{
+    if (n <= 0) return HTM_OK;
+    n = (n + 63) / 64 * 64;
+    const StreamDev &sd = hc->dev.stream;
+    // never overwrite positions that may still be needed: everything from (consumed - 4) on
+    const long long room = hc->cap - (hc->n_raw - (hc->spos_lo - 4));
+    if (n > room) n = room / 64 * 64;
+    if (n <= 0) return HTM_OK;
+    hipStream_t st = hc->side;
+    hipLaunchKernelGGL(k_rawgen, dim3(1), dim3(64), 0, st, sd, hc->n_raw, (int)n);
+    hc->n_raw += n;
+    auto blocks = [](long long cnt) { return dim3((unsigned)((cnt + 255) / 256)); };
+    long long e = hc->n_raw - 1;
+    if (e > hc->n_tr) { hipLaunchKernelGGL(k_stream_tr, blocks(e - hc->n_tr), dim3(256), 0, st, sd, hc->n_tr, e); hc->n_tr = e; }
+    e = hc->n_tr - kRecLag;
+    if (e > hc->n_rec) {
+        hipLaunchKernelGGL(k_stream_rec, blocks(e - hc->n_rec), dim3(256), 0, st, sd, hc->n_rec, e, hc->th[0], hc->th[1],
+                           hc->th[2], hc->th[3], hc->dev.S, hc->dev.E);
+        hc->n_rec = e;
+    }
+    e = hc->n_rec - kHopLag;
+    if (e > hc->n_hop) { hipLaunchKernelGGL(k_stream_hop, blocks(e - hc->n_hop), dim3(256), 0, st, sd, hc->n_hop, e); hc->n_hop = e; }
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, st, sd.hop_end, hc->n_hop);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(hc->ev_side, st));
     return HTM_OK;
 }
 
@@ -532,22 +571,58 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
     HIPCHK(hipMemset(d.stamps, 0, 64 * sizeof(unsigned long long)));
 #endif
 
+    // random-stream service
+    hc->th[0] = d.th1; hc->th[1] = d.th2; hc->th[2] = d.th3; hc->th[3] = d.th4;
+    for (int k = 0; k < 4; ++k) hc->init_state[k] = init->rng_state[k];
+    hc->cap = 1 << 20;     // stream positions kept in HBM (~100 B each)
+    {
+        StreamDev &sd = d.stream;
+        const size_t n = (size_t)hc->cap;
+        sd.mask = hc->cap - 1;
+        if ((rc = dev_alloc(hc->pool, &sd.raw, n))) return cleanup(rc);
+        if ((rc = dev_alloc(hc->pool, &sd.U, n))) return cleanup(rc);
+        if ((rc = dev_alloc(hc->pool, &sd.LOGU, n))) return cleanup(rc);
+        if ((rc = dev_alloc(hc->pool, &sd.G, n))) return cleanup(rc);
+        if ((rc = dev_alloc(hc->pool, &sd.pg, n))) return cleanup(rc);
+        if ((rc = dev_alloc(hc->pool, &sd.pr, n))) return cleanup(rc);
+        if ((rc = dev_alloc(hc->pool, &sd.plogr, n))) return cleanup(rc);
+        if ((rc = dev_alloc(hc->pool, &sd.dec, n))) return cleanup(rc);
+        if ((rc = dev_alloc(hc->pool, &sd.hop, n * kHops))) return cleanup(rc);
+        if ((rc = dev_upload(hc->pool, &sd.gen, hc->init_state, 4))) return cleanup(rc);
+        const long long zero = 0;
+        if ((rc = dev_upload(hc->pool, &sd.hop_end, &zero, 1))) return cleanup(rc);
+    }
+    {
+        hipError_t e1 = hipStreamCreateWithFlags(&hc->side, hipStreamNonBlocking);
+        hipError_t e2 = hipEventCreateWithFlags(&hc->ev_side, hipEventDisableTiming);
+        if (e1 != hipSuccess || e2 != hipSuccess) return cleanup(fail(HTM_EHIP, "side stream/event creation failed"));
+    }
+
     Ctrl c{};
-    for (int k = 0; k < 4; ++k) c.rng[k] = init->rng_state[k];
+    c.spos = 0;
     c.stage = ST_IDLE;
     hc->h_ctrl = c;
     if ((rc = dev_upload(hc->pool, &d.ctrl, &c, 1))) return cleanup(rc);
 
     hc->nw = std::min(nc, 8);
-    // RNG ring: a chain step draws <= 6 numbers, select_pair/judge_swap a few more (cls_parallel.f90:226-230)
+    // stream window: a chain step draws <= 6 numbers, select_pair/judge_swap a few more (cls_parallel.f90:226-230)
     hc->wmax = ((6 * nc + 16 + 63) / 64) * 64;
-    hc->ring_size = 512;
-    while (hc->ring_size < 2 * hc->wmax + 200) hc->ring_size *= 2;
-    hc->step_smem = ((sizeof(StepShared) + 15) & ~size_t(15)) + (size_t)hc->ring_size * (3 * sizeof(double) + 8) +
+    hc->ring_size = 256;
+    while (hc->ring_size < 3 * hc->wmax + 64) hc->ring_size *= 2;
+    // per LDS ring position: U, LOGU, pg, pr, plogr (5 doubles), dec (int4), hop (kHops ints)
+    hc->step_smem = ((sizeof(StepShared) + 15) & ~size_t(15)) +
+                    (size_t)hc->ring_size * (5 * sizeof(double) + sizeof(int4) + kHops * sizeof(int)) +
                     3 * (size_t)h->S * sizeof(double);
-    if (hc->step_smem > 64 * 1024) return cleanup(fail(HTM_EINVAL, "n_sta too large for k_step's LDS budget"));
+    if (hc->step_smem > 150 * 1024) return cleanup(fail(HTM_EINVAL, "n_chains / n_sta too large for k_step's LDS budget"));
+    if (hc->step_smem > 48 * 1024) {
+        const void *fn = h->nch == 1 ? (const void *)k_step<1> : h->nch == 2 ? (const void *)k_step<2> : (const void *)k_step<0>;
+        HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hc->step_smem));
+    }
     if (hipEventCreate(&hc->ev0) != hipSuccess || hipEventCreate(&hc->ev1) != hipSuccess)
         return cleanup(fail(HTM_EHIP, "hipEventCreate failed"));
+    // first stretch of the random stream (synchronous)
+    if ((rc = stream_produce(hc, 1 << 16))) return cleanup(rc);
+    HIPCHK(hipStreamSynchronize(hc->side));
     *out = hc;
     return HTM_OK;
 }
@@ -556,7 +631,10 @@ int htm_chains_destroy(htm_chains *hc)
 {
     if (!hc) return HTM_OK;
     (void)hipSetDevice(hc->fwd->device);
+    if (hc->side) (void)hipStreamSynchronize(hc->side);
     (void)hipStreamSynchronize(hc->fwd->stream);
+    if (hc->ev_side) (void)hipEventDestroy(hc->ev_side);
+    if (hc->side) (void)hipStreamDestroy(hc->side);
     if (hc->gexec) (void)hipGraphExecDestroy(hc->gexec);
     if (hc->graph) (void)hipGraphDestroy(hc->graph);
     for (void *p : hc->pool) (void)hipFree(p);
@@ -570,6 +648,7 @@ static int read_ctrl(htm_chains *hc)
 {
     HIPCHK(hipMemcpyAsync(&hc->h_ctrl, hc->dev.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, hc->fwd->stream));
     HIPCHK(hipStreamSynchronize(hc->fwd->stream));
+    hc->spos_lo = hc->spos_hi = hc->h_ctrl.spos;
     return HTM_OK;
 }
 
@@ -580,6 +659,7 @@ static int ctrl_error(const htm_chains *hc)
     case -4: return fail(HTM_ESTATE, "device RNG window exhausted (iteration %d)", hc->h_ctrl.iter_done + 1);
     case -5: return fail(HTM_EOVERFLOW, "record buffer overflow in lock-step mode: call htm_chains_drain more often");
     case -6: return fail(HTM_EDESYNC, "swap records of the ranks carry different iteration numbers");
+    case -7: return fail(HTM_ESTATE, "random stream underrun in lock-step mode (iteration %d)", hc->h_ctrl.iter_done + 1);
     default: return fail(HTM_ESTATE, "device error flag %d", hc->h_ctrl.err);
     }
 }
@@ -604,7 +684,7 @@ static int drain_records(htm_chains *hc)
         HIPCHK(hipMemcpy(hc->smp_data.data() + o * hc->rec_len, d.smp_data, (size_t)ns * hc->rec_len * sizeof(double),
                          hipMemcpyDeviceToHost));
     }
-    if (nl > 0 || ns > 0 || hc->h_ctrl.stop) {
+    if (nl > 0 || ns > 0 || hc->h_ctrl.stop) {   // stop: 1 = record buffers full, 2 = stream underrun
         hc->h_ctrl.n_lik = 0; hc->h_ctrl.n_smp = 0; hc->h_ctrl.stop = 0;
         // stop, n_lik, n_smp are consecutive ints in Ctrl
         HIPCHK(hipMemcpy(&hc->dev.ctrl->stop, &hc->h_ctrl.stop, 3 * sizeof(int), hipMemcpyHostToDevice));
@@ -663,15 +743,25 @@ int htm_chains_run(htm_chains *hc, int n_iter)
         const int remaining = hc->h_target - hc->h_ctrl.iter_done;
         if (remaining <= 0 && hc->h_ctrl.stage == ST_IDLE) break;
         int g = (int)(0.8 * remaining / it_per_launch);
+        // no more launches than the produced random stream can feed (an iteration draws < 6*n_chains + 4)
+        const long long fed = (hc->n_hop - hc->h_ctrl.spos) / (6 * hc->dev.n_chains + 4);
+        g = std::min<long long>(g, (long long)(0.9 * fed / it_per_launch));
         g = std::max(1, std::min(g, 512));
         const int before = hc->h_ctrl.iter_done;
         for (int k = 0; k < g; ++k) HIPCHK(hipGraphLaunch(hc->gexec, h->stream));
         hc->last_graph_launches += g;
         if ((rc = read_ctrl(hc))) return rc;
         if ((rc = ctrl_error(hc))) return rc;
-        if (hc->h_ctrl.stop) { if ((rc = drain_records(hc))) return rc; }
-        else if (hc->h_ctrl.iter_done > before)
+        if (hc->h_ctrl.iter_done > before && !hc->h_ctrl.stop)
             it_per_launch = std::max(1.0, double(hc->h_ctrl.iter_done - before) / g);
+        // keep the random stream about two batches ahead (asynchronous, on the side stream)
+        {
+            const long long want = hc->cap / 2;
+            const long long ahead = hc->n_hop - hc->h_ctrl.spos;
+            if (ahead < want && (rc = stream_produce(hc, std::min<long long>(want - ahead + 4096, 1 << 18)))) return rc;
+        }
+        if (hc->h_ctrl.stop == 2) HIPCHK(hipStreamSynchronize(hc->side));   // underrun: wait for the producer
+        if (hc->h_ctrl.stop) { if ((rc = drain_records(hc))) return rc; }
     }
     HIPCHK(hipEventRecord(hc->ev1, h->stream));
     HIPCHK(hipEventSynchronize(hc->ev1));
@@ -712,6 +802,8 @@ int htm_chains_profile(htm_chains *hc, int n_iter, double *step_us, int *step_la
         }
         if ((rc = read_ctrl(hc))) return rc;
         if ((rc = ctrl_error(hc))) return rc;
+        if (hc->n_hop - hc->h_ctrl.spos < 16384 && (rc = stream_produce(hc, 16384))) return rc;
+        if (hc->h_ctrl.stop == 2) HIPCHK(hipStreamSynchronize(hc->side));
         for (int k = 0; k < B; ++k) {
             float a = 0.f, b = 0.f;
             HIPCHK(hipEventElapsedTime(&a, ev[3 * k], ev[3 * k + 1]));
@@ -736,7 +828,17 @@ int htm_chains_step_begin(htm_chains *hc)
     htm_forward *h = hc->fwd;
     HIPCHK(hipSetDevice(h->device));
     hc->h_target += 1;
-    int rc = launch_step(hc, MODE_ADVANCE, hc->h_target, nullptr);
+    int rc;
+    // an iteration consumes at most wmax draws; keep the produced stream safely ahead of that bound
+    hc->spos_hi += hc->wmax;
+    if (hc->n_hop - hc->spos_hi < 4 * (long long)hc->wmax) {
+        if ((rc = read_ctrl(hc))) return rc;              // exact position (also frees ring capacity)
+        if ((rc = ctrl_error(hc))) return rc;
+        hc->spos_hi += hc->wmax;
+        if ((rc = stream_produce(hc, 1 << 16))) return rc;
+        HIPCHK(hipStreamWaitEvent(h->stream, hc->ev_side, 0));
+    }
+    rc = launch_step(hc, MODE_ADVANCE, hc->h_target, nullptr);
     if (rc) return rc;
     if ((rc = launch_full(h, chain_full_job(hc), 1))) return rc;
     return launch_step(hc, MODE_FINISH, hc->h_target, nullptr);
@@ -809,7 +911,14 @@ int htm_chains_get_rng(htm_chains *hc, uint32_t state[4])
     if (!hc || !state) return fail(HTM_EINVAL, "NULL argument");
     int rc = htm_chains_sync(hc);
     if (rc) return rc;
-    for (int k = 0; k < 4; ++k) state[k] = hc->h_ctrl.rng[k];
+    // mod_random state after spos draws = words spos..spos+3 of [x0, y0, z0, w0, out_0, out_1, ...]
+    const long long sp = hc->h_ctrl.spos;
+    for (int k = 0; k < 4; ++k) {
+        const long long word = sp + k;
+        if (word < 4) state[k] = hc->init_state[word];
+        else HIPCHK(hipMemcpy(&state[k], hc->dev.stream.raw + ((word - 4) & hc->dev.stream.mask), sizeof(uint32_t),
+                              hipMemcpyDeviceToHost));
+    }
     return HTM_OK;
 }
 

@@ -82,7 +82,9 @@ __global__ __launch_bounds__(256) void k_full(FwdDev f, FullJob jb)
                     const double py[1] = {(ov && ov_cmp == 1) ? ov_val : hyp[3 * ev + 1]};
                     const double pz[1] = {(ov && ov_cmp == 2) ? ov_val : hyp[3 * ev + 2]};
                     double out[1];
-                    event_misfit<NCH, 1>(f, ev, lane, st, px, py, pz, beta, q, out);
+                    ObsRegs<NCH> ob;
+                    load_obs_regs<NCH>(ob, f, ev, lane);
+                    event_misfit<NCH, 1>(f, ob, lane, st, px, py, pz, beta, q, out);
                     lane_acc += out[0];
                 }
             }

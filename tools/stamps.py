@@ -20,17 +20,20 @@ fwd, cs = driver.build_rank(params, data.sta_x, data.sta_y, data.sta_z, obs, 0, 
 cs.run(2000)
 lib = _lib.load()
 lib.htm_chains_read_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
-a = (C.c_uint64 * 16)()
+a = (C.c_uint64 * 64)()
 lib.htm_chains_read_stamps(cs.handle, a)
 base = list(a)
 n = 10000
 cs.run(n)
 lib.htm_chains_read_stamps(cs.handle, a)
-names = ["prologue", "P0 (ring fill / resume judge)", "passes (propose+partial+decide)", "validate+plan+finish",
+names = ["prologue", "P0 (window prefetch / resume judge)", "passes (propose+partial+decide)", "validate+plan+finish",
          "commit", "epilogue"]
 tot = sum(a[k] - base[k] for k in range(len(names)))
 for k, nm in enumerate(names):
     d = a[k] - base[k]
     print("%-34s %9.0f ticks/iter  %5.1f %%" % (nm, d / n, 100.0 * d / tot))
+cn = ["decode+load issue", "proposal arith (load wait)", "event_misfit", "final sum+decision", "LDS write-back"]
+for k, nm in enumerate(cn):
+    print("  chain_pass[last chain] %-28s %8.0f ticks/iter" % (nm, (a[32 + k] - base[32 + k]) / n))
 st = cs.last_run_stats()
 print("total ticks/iter", tot / n, " device_us/iter", st["device_us"] / n, st)
