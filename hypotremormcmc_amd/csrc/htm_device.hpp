@@ -286,6 +286,7 @@ struct Proposal {            // everything random about one chain step, resolved
     int    cool;             // temperature < 1 + eps at judge time (counters, cls_mcmc.f90:186,:215)
     int    pad_;
     double x_new, lpr;       // cls_model.f90:172-186
+    double x_old, L_old;     // what a speculative commit overwrote (restored if the pass is repeated)
     double r_judge, logr_judge;   // the rand_u() of cls_mcmc.f90:197 and its log (only drawn if prior_ok)
     double L_new;
 };
@@ -309,6 +310,7 @@ struct StreamDev {
     int4 *dec;                 // {type, 0-based index, event id or -999, draws consumed if prior_ok}
     double *pg, *pr, *plogr;   // its Gaussian, its judge draw r and log r
     int *hop;                  // [p][k-1] = position after k optimistic chain steps, k = 1..8
+    int4 *sw;                  // select_pair starting at p (rank 0): {i1, i2, draws used or -1, 0}
     long long mask;            // capacity - 1
     uint32_t *gen;             // [4] generator state after the last produced raw
     long long *hop_end;        // every array is complete for positions < *hop_end

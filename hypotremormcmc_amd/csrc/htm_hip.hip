@@ -139,7 +139,7 @@ int launch_full(htm_forward *h, const FullJob &jb, int gy)
 int launch_step(htm_chains *hc, int mode, int target, const double *gathered)
 {
     htm_forward *h = hc->fwd;
-    dim3 grid(1), block(64 * (hc->nw + 1));
+    dim3 grid(1), block(64 * hc->nw);
     switch (h->nch) {
     case 1: hipLaunchKernelGGL(k_step<1>, grid, block, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax); break;
     case 2: hipLaunchKernelGGL(k_step<2>, grid, block, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax); break;
@@ -169,7 +169,7 @@ int stream_produce(htm_chains *hc, long long n)
     e = hc->n_tr - kRecLag;
     if (e > hc->n_rec) {
         hipLaunchKernelGGL(k_stream_rec, blocks(e - hc->n_rec), dim3(256), 0, st, sd, hc->n_rec, e, hc->th[0], hc->th[1],
-                           hc->th[2], hc->th[3], hc->dev.S, hc->dev.E);
+                           hc->th[2], hc->th[3], hc->dev.S, hc->dev.E, hc->dev.n_procs, hc->dev.n_chains);
         hc->n_rec = e;
     }
     e = hc->n_rec - kHopLag;
@@ -588,6 +588,7 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
         if ((rc = dev_alloc(hc->pool, &sd.plogr, n))) return cleanup(rc);
         if ((rc = dev_alloc(hc->pool, &sd.dec, n))) return cleanup(rc);
         if ((rc = dev_alloc(hc->pool, &sd.hop, n * kHops))) return cleanup(rc);
+        if ((rc = dev_alloc(hc->pool, &sd.sw, n))) return cleanup(rc);
         if ((rc = dev_upload(hc->pool, &sd.gen, hc->init_state, 4))) return cleanup(rc);
         const long long zero = 0;
         if ((rc = dev_upload(hc->pool, &sd.hop_end, &zero, 1))) return cleanup(rc);
@@ -609,9 +610,9 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
     hc->wmax = ((6 * nc + 16 + 63) / 64) * 64;
     hc->ring_size = 256;
     while (hc->ring_size < 3 * hc->wmax + 64) hc->ring_size *= 2;
-    // per LDS ring position: U, LOGU, pg, pr, plogr (5 doubles), dec (int4), hop (kHops ints)
+    // per LDS ring position: U, LOGU, pg, pr, plogr (5 doubles), dec, sw (int4), hop (kHops ints)
     hc->step_smem = ((sizeof(StepShared) + 15) & ~size_t(15)) +
-                    (size_t)hc->ring_size * (5 * sizeof(double) + sizeof(int4) + kHops * sizeof(int)) +
+                    (size_t)hc->ring_size * (5 * sizeof(double) + 2 * sizeof(int4) + kHops * sizeof(int)) +
                     3 * (size_t)h->S * sizeof(double);
     if (hc->step_smem > 150 * 1024) return cleanup(fail(HTM_EINVAL, "n_chains / n_sta too large for k_step's LDS budget"));
     if (hc->step_smem > 48 * 1024) {

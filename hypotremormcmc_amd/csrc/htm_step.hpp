@@ -29,22 +29,73 @@ struct StepShared {
     int start_fix[kMaxChains];    // corrected starts for a repeat pass (written by wave 0)
     int cnt[kMaxChains];          // draws the step consumed (judge draw included iff prior_ok)
     int slot_l[kMaxChains], slot_s[kMaxChains];
-    int sw_do, sw_c1, sw_c2;      // swap decided by wave 0; applied by the waves owning the two chains
+    int np[kMaxChains * 7], na[kMaxChains * 7];   // proposal / acceptance counters of this launch
+    int sw_do, sw_c1, sw_c2;      // swap decided between the barriers; applied by the waves owning the chains
     double sw_T1, sw_T2;          // new temperatures of chains sw_c1 / sw_c2
     long long origin;             // absolute stream position of relative position 0 (= spos at launch)
     int avail;                    // the produced stream covers relative positions < avail
     int fill;                     // the LDS ring holds relative positions < fill
     int base;                     // relative position at which the current iteration starts
     int redo;                     // >= 0: chains >= redo repeat their pass; -1: validated; -2: aborted
+    int catchup;                  // written between the barriers: the LDS window must be extended first
     Ctrl c;
 };
 
 struct Ring {                     // LDS window of the stream rings, index = relative position & mask
     double *U, *LOGU, *pg, *pr, *plogr;
-    int4 *dec;
+    int4 *dec, *sw;
     int *hop;
     int mask;
 };
+
+// one stream position in flight from the global rings to the LDS window
+struct PfRegs {
+    double U, LOGU, pg, pr, plogr;
+    int4 dec, sw, h0, h1;
+    int p;                        // relative position, -1: nothing to store
+};
+
+__device__ __forceinline__ void pf_load(PfRegs &r, const ChainsDev &cs, const StepShared &sh, int p, int limit)
+{
+    r.p = -1;
+    if (p < limit) {
+        const StreamDev &sd = cs.stream;
+        const long long g = (sh.origin + p) & sd.mask;
+        r.U = sd.U[g]; r.LOGU = sd.LOGU[g]; r.pg = sd.pg[g]; r.pr = sd.pr[g]; r.plogr = sd.plogr[g];
+        r.dec = sd.dec[g]; r.sw = sd.sw[g];
+        const int4 *hs = reinterpret_cast<const int4 *>(sd.hop + g * kHops);
+        r.h0 = hs[0]; r.h1 = hs[1];
+        r.p = p;
+    }
+}
+
+__device__ __forceinline__ void pf_store(const PfRegs &r, const Ring &rg)
+{
+    if (r.p >= 0) {
+        const int l = r.p & rg.mask;
+        rg.U[l] = r.U; rg.LOGU[l] = r.LOGU; rg.pg[l] = r.pg; rg.pr[l] = r.pr; rg.plogr[l] = r.plogr;
+        rg.dec[l] = r.dec; rg.sw[l] = r.sw;
+        int4 *hd = reinterpret_cast<int4 *>(rg.hop + l * kHops);
+        hd[0] = r.h0; hd[1] = r.h1;
+    }
+}
+
+// every thread of the workgroup: extend the LDS window to cover relative positions < target
+// (kernel start; later only if a long select_pair redraw run ate the look-ahead)
+__device__ __forceinline__ void prefetch_all(const ChainsDev &cs, StepShared &sh, const Ring &rg, int target)
+{
+    if (target > sh.avail) target = sh.avail;
+    if (target > sh.base + rg.mask + 1 - 8) target = sh.base + rg.mask + 1 - 8;
+    const int fl = sh.fill;
+    for (int p = fl + (int)threadIdx.x; p < target; p += (int)blockDim.x) {
+        PfRegs r;
+        pf_load(r, cs, sh, p, target);
+        pf_store(r, rg);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && target > sh.fill) sh.fill = target;
+    __syncthreads();
+}
 
 __device__ __forceinline__ ModelDev pick_model(const ChainsDev &cs, int type)
 {
@@ -57,35 +108,6 @@ __device__ __forceinline__ ModelDev pick_model(const ChainsDev &cs, int type)
     m.ptype = v ? cs.vs.ptype : t ? cs.tc.ptype : q ? cs.qs.ptype : a ? cs.ac.ptype : cs.hypo.ptype;
     m.nx = (v || q) ? 1 : (t || a) ? cs.S : cs.hypo.nx;
     return m;
-}
-
-// prefetch wave (all 64 lanes): copy stream positions [fill, target) from the global rings into the LDS ring
-__device__ __forceinline__ void prefetch_until(const ChainsDev &cs, StepShared &sh, const Ring &rg, int target,
-                                               int lane)
-{
-    int fl = __builtin_amdgcn_readfirstlane(sh.fill);
-    const int avail = __builtin_amdgcn_readfirstlane(sh.avail);
-    const int base = __builtin_amdgcn_readfirstlane(sh.base);
-    if (target > avail) target = avail;
-    if (target > base + rg.mask + 1 - 8) target = base + rg.mask + 1 - 8;     // never overwrite the live window
-    const StreamDev &sd = cs.stream;
-    const long long org = sh.origin;
-    while (fl < target) {
-        const int p = fl + lane;
-        if (p < target) {
-            const long long g = (org + p) & sd.mask;
-            const int l = p & rg.mask;
-            rg.U[l] = sd.U[g]; rg.LOGU[l] = sd.LOGU[g];
-            rg.dec[l] = sd.dec[g];
-            rg.pg[l] = sd.pg[g]; rg.pr[l] = sd.pr[g]; rg.plogr[l] = sd.plogr[g];
-            const int4 *hs = reinterpret_cast<const int4 *>(sd.hop + g * kHops);
-            int4 *hd = reinterpret_cast<int4 *>(rg.hop + l * kHops);
-            hd[0] = hs[0]; hd[1] = hs[1];
-        }
-        fl += 64;
-    }
-    if (fl > target) fl = target;
-    if (lane == 0 && fl > sh.fill) sh.fill = fl;
 }
 
 // inclusive prefix sum over the 64 lanes (DPP row_shr scan + row_bcast, ints)
@@ -102,8 +124,17 @@ __device__ __forceinline__ int wave_incl_scan(int v)
 
 // Chain state (x vectors, temperatures, log-likelihoods) is rewritten by this kernel while it loops over
 // iterations.  hipcc turns uniform-address loads into scalar (K$) loads, and the scalar cache is not
-// coherent with vector stores, so mutable state is always read through a volatile (vector-memory) load.
-__device__ __forceinline__ double ld_state(const double *p) { return *reinterpret_cast<const volatile double *>(p); }
+// coherent with vector stores, so mutable state must be read with VECTOR loads.  `volatile` would do that but
+// also makes the backend wait for every single load (s_waitcnt vmcnt(0) after each), serialising ~700-cycle
+// latencies; instead the address gets a per-lane zero the compiler cannot see through, which keeps the loads
+// ordinary (L1-cached, freely overlapped) vector loads.
+__device__ __forceinline__ int opaque_zero()
+{
+    int z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    return z;
+}
+__device__ __forceinline__ double ld_state(const double *p, int vz) { return p[vz]; }
 
 __device__ __forceinline__ bool metropolis(double L_new, double L_cur, double T, double lpr, double r,
                                            double logr)
@@ -119,7 +150,9 @@ __device__ __forceinline__ bool metropolis(double L_new, double L_cur, double T,
 #define CSTAMP(k) do { } while (0)
 #endif
 
-// One chain step up to (and including, for hypocentre proposals) the Metropolis decision.
+// One chain step: proposal, single-event partial update, Metropolis decision and -- speculatively -- its
+// commit (cls_mcmc.f90:186-189,:207-219).  The commit is final unless the validation finds that an earlier
+// chain's Rayleigh prior rejected (then the step is undone and repeated one draw earlier, see undo_chain).
 // All 64 lanes execute with identical (uniform) values; lane <-> station only inside event_misfit.
 // Returns the stream position after this step.
 template <int NCH>
@@ -132,6 +165,7 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
     const bool stamp_me = cs.stamps && lane == 0 && c == cs.n_chains - 1;
     unsigned long long t_last = __builtin_amdgcn_s_memtime();
 #endif
+    const int vz = opaque_zero();
     const int4 dec = rg.dec[p & M];                 // decoded ahead of time (htm_stream.hpp)
     const int type = dec.x, idx = dec.y, evt = dec.z;
     const double g = rg.pg[p & M], r_ring = rg.pr[p & M], logr_ring = rg.plogr[p & M];
@@ -139,7 +173,7 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
     const ModelDev Mo = pick_model(cs, type);
     const size_t o = (size_t)c * Mo.nx + idx;
     // every global load of the step is issued here, before any dependent arithmetic
-    const double x_old = ld_state(Mo.x + o), mu = Mo.mu[o], sigma = Mo.sigma[o], step = Mo.step[o];
+    const double x_old = ld_state(Mo.x + o, vz), mu = Mo.mu[o], sigma = Mo.sigma[o], step = Mo.step[o];
     const int ptype = Mo.ptype[o];
     double hx = 0.0, hy = 0.0, hz = 0.0, beta = 1.0, q = 1.0;
     const int ev = partial ? evt - 1 : 0;
@@ -148,8 +182,8 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
     ObsRegs<(NCH > 0 ? NCH : 1)> ob;
     if (partial) {
         const double *hyp = cs.hypo.x + (size_t)c * cs.hypo.nx + 3 * ev;
-        hx = ld_state(hyp); hy = ld_state(hyp + 1); hz = ld_state(hyp + 2);
-        beta = ld_state(cs.vs.x + c); q = ld_state(cs.qs.x + c);
+        hx = ld_state(hyp, vz); hy = ld_state(hyp + 1, vz); hz = ld_state(hyp + 2, vz);
+        beta = ld_state(cs.vs.x + c, vz); q = ld_state(cs.qs.x + c, vz);
         if constexpr (NCH > 0) {
             load_sta_regs<NCH>(st, f.S, lane, s_sx, s_sy, s_sz, tc, ac, 0, -1, 0.0);
             load_obs_regs<NCH>(ob, f, ev, lane);      // in flight while the proposal is worked out
@@ -191,115 +225,164 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
         }
     }
     if (lane == 0) {
+        const int cool = (T < 1.0 + kEps) ? 1 : 0;
         Proposal &pr = sh.prop[c];
         pr.type = type; pr.idx = idx; pr.evt = evt; pr.prior_ok = ok; pr.need_full = need_full; pr.accepted = acc;
-        pr.cool = (T < 1.0 + kEps) ? 1 : 0; pr.pad_ = 0;
+        pr.cool = cool; pr.pad_ = 0;
         pr.x_new = x_new; pr.lpr = lpr; pr.r_judge = r; pr.logr_judge = logr; pr.L_new = L_new;
+        pr.x_old = x_old; pr.L_old = L_cur;
         sh.start[c] = p; sh.cnt[c] = cnt;
+        if (cool) sh.np[c * 7 + type - 1] += 1;                 // cls_mcmc.f90:186-189
+        if (acc) {                                              // :207-219
+            Mo.x[o] = x_new;
+            sh.L[c] = L_new;
+            cs.L[c] = L_new;
+            if (cool) sh.na[c * 7 + type - 1] += 1;
+        }
     }
-    CSTAMP(4);   // LDS write-back
+    CSTAMP(4);   // commit + LDS write-back
     return p + cnt;
 }
 
-// lanes <-> chains: record slots (hypo_tremor_mcmc.f90:270-280), step log, swap decision or record export.
-// Needs every chain's decision in sh.prop.  Runs between the two barriers of an iteration.  Split in two so
-// that two waves can share it: `records` (slots, step log, per-chain export) and `swap` (swap decision or
-// record header, iteration counter).  The two parts write disjoint fields and read nothing the other writes.
-__device__ __forceinline__ void finish_iteration(const ChainsDev &cs, StepShared &sh, int iter, bool lockstep,
-                                                 int lane, bool do_records, bool do_swap)
+// lane 0 of the owning wave: take back the speculative effects of chain c's step
+__device__ __forceinline__ void undo_chain(const ChainsDev &cs, StepShared &sh, int c)
 {
-    const int nc = cs.n_chains, n_all = cs.n_procs * nc;
-    if (do_records) {
-        const bool in = lane < nc;
-        const int c = in ? lane : 0;
-        const Proposal pr = sh.prop[c];
-        const double T = sh.temp[c];
-        const double L_post = pr.accepted ? pr.L_new : sh.L[c];
-        const bool rec_l = in && T < 1.0 + kEps && (iter % cs.n_interval) == 1;
-        const bool rec_s = rec_l && iter > cs.n_burn;
-        const unsigned long long ml = __ballot(rec_l), ms = __ballot(rec_s);
-        const unsigned long long below = (1ull << lane) - 1ull;
-        if (in) {
-            sh.slot_l[c] = rec_l ? sh.c.n_lik + __popcll(ml & below) : -1;
-            sh.slot_s[c] = rec_s ? sh.c.n_smp + __popcll(ms & below) : -1;
-            const int row = sh.c.slog_n + c;
-            if (row < sh.c.slog_cap) {
-                int32_t *ir = cs.slog_i + 8 * (size_t)row;
-                double *dr = cs.slog_d + 4 * (size_t)row;
-                ir[0] = iter; ir[1] = c; ir[2] = pr.type; ir[3] = pr.idx + 1; ir[4] = pr.prior_ok;
-                ir[5] = pr.accepted; ir[6] = pr.need_full; ir[7] = 0;
-                dr[0] = pr.x_new; dr[1] = pr.L_new; dr[2] = L_post; dr[3] = T;
-            }
-            if (lockstep) { cs.swap_rec[4 + 2 * c] = T; cs.swap_rec[5 + 2 * c] = L_post; }
-        }
-        if (lane == 0) {
-            sh.c.n_lik += __popcll(ml); sh.c.n_smp += __popcll(ms);
-            if (sh.c.slog_n < sh.c.slog_cap) sh.c.slog_n += nc;
-        }
+    Proposal &pr = sh.prop[c];
+    if (pr.cool) sh.np[c * 7 + pr.type - 1] -= 1;
+    if (pr.accepted) {
+        const ModelDev Mo = pick_model(cs, pr.type);
+        Mo.x[(size_t)c * Mo.nx + pr.idx] = pr.x_old;
+        sh.L[c] = pr.L_old;
+        cs.L[c] = pr.L_old;
+        if (pr.cool) sh.na[c * 7 + pr.type - 1] -= 1;
+        pr.accepted = 0;
     }
-    if (lane == 0 && do_swap) {
-        sh.sw_do = 0;
-        if (lockstep) {      // the swap itself happens in MODE_APPLY from the all-gathered records
-            cs.swap_rec[0] = (double)sh.c.swap_i1; cs.swap_rec[1] = (double)sh.c.swap_i2;
-            cs.swap_rec[2] = sh.c.swap_r; cs.swap_rec[3] = (double)iter;
-            sh.c.stage = ST_WAIT_SWAP;
-        } else {
-            if (n_all > 1) {  // both chains live on this rank: cls_parallel.f90:121-136 + :285-302
-                const int c1 = sh.c.swap_i1, c2 = sh.c.swap_i2;
-                const double T1 = sh.temp[c1], T2 = sh.temp[c2];
-                const double L1 = sh.prop[c1].accepted ? sh.prop[c1].L_new : sh.L[c1];
-                const double L2 = sh.prop[c2].accepted ? sh.prop[c2].L_new : sh.L[c2];
-                const double del_s = (L2 - L1) * (1.0 / T1 - 1.0 / T2);
-                if (sh.c.swap_r >= kEps && sh.c.swap_logr <= del_s) {   // applied in commit_chain
-                    sh.sw_do = 1; sh.sw_c1 = c1; sh.sw_c2 = c2; sh.sw_T1 = T2; sh.sw_T2 = T1;
-                }
-            }
-            sh.c.iter_done = iter;
-            sh.c.stage = ST_IDLE;
+}
+
+// ---- between the two barriers of an iteration: three roles on three waves (lanes <-> chains) ----------
+// Each role recomputes the cheap validation and reads only data no other role writes in this interval.
+struct Valid {
+    unsigned long long bad, mf;
+    int total, base;
+};
+__device__ __forceinline__ Valid validate(const StepShared &sh, int nc, int lane)
+{
+    Valid v;
+    const bool in = lane < nc;
+    const int my_cnt = in ? sh.cnt[lane] : 0, my_start = in ? sh.start[lane] : 0;
+    const int incl = wave_incl_scan(my_cnt);
+    v.base = sh.start[0];                       // chain 0 always starts at the iteration's base
+    v.bad = __ballot(in && v.base + incl - my_cnt != my_start);
+    v.mf = __ballot(in && sh.prop[lane].need_full != 0);
+    v.total = __builtin_amdgcn_readlane(incl, 63);
+    return v;
+}
+
+// role R: record slots (hypo_tremor_mcmc.f90:270-280), step log, per-chain part of the swap record
+__device__ __forceinline__ void role_records(const ChainsDev &cs, StepShared &sh, int iter, bool lockstep, int lane)
+{
+    const int nc = cs.n_chains;
+    const bool in = lane < nc;
+    const int c = in ? lane : 0;
+    const double T = sh.temp[c], L_post = sh.L[c];
+    const bool rec_l = in && T < 1.0 + kEps && (iter % cs.n_interval) == 1;
+    const bool rec_s = rec_l && iter > cs.n_burn;
+    const unsigned long long ml = __ballot(rec_l), ms = __ballot(rec_s);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (in) {
+        sh.slot_l[c] = rec_l ? sh.c.n_lik + __popcll(ml & below) : -1;
+        sh.slot_s[c] = rec_s ? sh.c.n_smp + __popcll(ms & below) : -1;
+        const int row = sh.c.slog_n + c;
+        if (row < sh.c.slog_cap) {
+            const Proposal pr = sh.prop[c];
+            int32_t *ir = cs.slog_i + 8 * (size_t)row;
+            double *dr = cs.slog_d + 4 * (size_t)row;
+            ir[0] = iter; ir[1] = c; ir[2] = pr.type; ir[3] = pr.idx + 1; ir[4] = pr.prior_ok;
+            ir[5] = pr.accepted; ir[6] = pr.need_full; ir[7] = 0;
+            dr[0] = pr.x_new; dr[1] = pr.L_new; dr[2] = L_post; dr[3] = T;
+        }
+        if (lockstep) { cs.swap_rec[4 + 2 * c] = T; cs.swap_rec[5 + 2 * c] = L_post; }
+    }
+    if (lane == 0) {
+        sh.c.n_lik += __popcll(ml); sh.c.n_smp += __popcll(ms);
+        if (sh.c.slog_n < sh.c.slog_cap) sh.c.slog_n += nc;
+    }
+}
+
+// role W: the temperature swap of cls_parallel.f90:121-136 + :285-302 (single rank) or the header of this
+// rank's record (lock-step).  Uniform over the wave; lane 0 writes.
+__device__ __forceinline__ void role_swap(const ChainsDev &cs, StepShared &sh, int iter, bool lockstep, int lane,
+                                          int i1, int i2, double sr, double slr)
+{
+    if (lane != 0) return;
+    sh.sw_do = 0;
+    if (lockstep) {
+        cs.swap_rec[0] = (double)i1; cs.swap_rec[1] = (double)i2; cs.swap_rec[2] = sr; cs.swap_rec[3] = (double)iter;
+    } else if (cs.n_procs * cs.n_chains > 1) {
+        const double T1 = sh.temp[i1], T2 = sh.temp[i2];
+        const double del_s = (sh.L[i2] - sh.L[i1]) * (1.0 / T1 - 1.0 / T2);
+        if (sr >= kEps && slr <= del_s) {       // applied after the barrier by the waves owning the chains
+            sh.sw_do = 1; sh.sw_c1 = i1; sh.sw_c2 = i2; sh.sw_T1 = T2; sh.sw_T2 = T1;
         }
     }
 }
 
-// chain wave: apply the decision (cls_mcmc.f90:186-189,:207-219) and write records.  The counters use the
-// temperature test of judge time (prop.cool), not the possibly just-swapped sh.temp.
-__device__ __forceinline__ void commit_chain(const ChainsDev &cs, StepShared &sh, int c, int iter, int lane)
+// select_pair + the judge_swap draw starting at relative position `end` (uniform over the wave).
+// Returns false if the look-ahead window does not cover it (p < 1e-40).
+__device__ __forceinline__ bool swap_plan(const ChainsDev &cs, const StepShared &sh, const Ring &rg, bool lockstep,
+                                          int end, int &pos_out, int &i1, int &i2, double &sr, double &slr)
 {
-    const Proposal pr = sh.prop[c];
-    const bool cool = pr.cool != 0;
+    const int nc = cs.n_chains, n_all = cs.n_procs * nc;
+    int pos = end;
+    i1 = -1; i2 = -1; sr = 0.0; slr = 0.0;
+    const int limit = sh.fill - 2;
+    if (n_all > 1) {
+        if (cs.rank == 0) {
+            const int4 sw = rg.sw[pos & rg.mask];           // precomputed in the stream (htm_stream.hpp)
+            if (sw.z > 0) { i1 = sw.x; i2 = sw.y; pos += sw.z; }
+            else {                                          // > 12 redraws: follow the stream here
+                i1 = (int)(rg.U[pos & rg.mask] * cs.n_procs * nc);
+                pos++;
+                for (;;) {
+                    if (pos >= limit) return false;
+                    i2 = (int)(rg.U[pos & rg.mask] * cs.n_procs * nc);
+                    pos++;
+                    if (i1 != i2) break;
+                }
+            }
+        }
+        if (pos >= limit) return false;
+        sr = rg.U[pos & rg.mask]; slr = rg.LOGU[pos & rg.mask];
+        if (!lockstep) pos++;                               // single rank: this rank is always rank1
+    }
+    pos_out = pos;
+    return true;
+}
+
+// chain wave, after the second barrier: this iteration's swap (if it touches chain c) and its records
+__device__ __forceinline__ void post_chain(const ChainsDev &cs, StepShared &sh, int c, int iter, int lane)
+{
     const int sl = sh.slot_l[c], ss = sh.slot_s[c];
     if (lane == 0) {
-        if (cool) atomicAdd(&cs.n_propose[c * 7 + pr.type - 1], 1);
-        if (pr.accepted) {
-            const ModelDev Mo = pick_model(cs, pr.type);
-            Mo.x[(size_t)c * Mo.nx + pr.idx] = pr.x_new;
-            sh.L[c] = pr.L_new;
-            cs.L[c] = pr.L_new;
-            if (cool) atomicAdd(&cs.n_accept[c * 7 + pr.type - 1], 1);
-        }
-        if (sh.sw_do) {     // this iteration's temperature swap, cls_parallel.f90:131-136
+        if (sh.sw_do) {     // cls_parallel.f90:131-136
             if (c == sh.sw_c1) { sh.temp[c] = sh.sw_T1; cs.temp[c] = sh.sw_T1; }
             if (c == sh.sw_c2) { sh.temp[c] = sh.sw_T2; cs.temp[c] = sh.sw_T2; }
         }
-        if (sl >= 0) {
-            cs.lik_iter[sl] = iter; cs.lik_chain[sl] = c;
-            cs.lik_val[sl] = pr.accepted ? pr.L_new : sh.L[c];
-        }
+        if (sl >= 0) { cs.lik_iter[sl] = iter; cs.lik_chain[sl] = c; cs.lik_val[sl] = sh.L[c]; }
     }
     if (ss >= 0) {
         const int nh = cs.hypo.nx, S = cs.S, rec = nh + 2 * S + 2;
         double *dst = cs.smp_data + (size_t)ss * rec;
         const double *hx = cs.hypo.x + (size_t)c * nh;
-        const bool acc = pr.accepted != 0;
-        // the element accepted in this very step is taken from the proposal, not re-read from memory
-        for (int k = lane; k < nh; k += 64) dst[k] = (acc && pr.type >= 5 && k == pr.idx) ? pr.x_new : ld_state(hx + k);
+        const int vz = opaque_zero();
+        for (int k = lane; k < nh; k += 64) dst[k] = ld_state(hx + k, vz);
         for (int k = lane; k < S; k += 64) {
-            const double t = ld_state(cs.tc.x + (size_t)c * S + k), a = ld_state(cs.ac.x + (size_t)c * S + k);
-            dst[nh + k] = (acc && pr.type == 2 && k == pr.idx) ? pr.x_new : t;
-            dst[nh + S + k] = (acc && pr.type == 4 && k == pr.idx) ? pr.x_new : a;
+            dst[nh + k] = ld_state(cs.tc.x + (size_t)c * S + k, vz);
+            dst[nh + S + k] = ld_state(cs.ac.x + (size_t)c * S + k, vz);
         }
         if (lane == 0) {
-            dst[nh + 2 * S] = (acc && pr.type == 1) ? pr.x_new : ld_state(cs.vs.x + c);
-            dst[nh + 2 * S + 1] = (acc && pr.type == 3) ? pr.x_new : ld_state(cs.qs.x + c);
+            dst[nh + 2 * S] = ld_state(cs.vs.x + c, vz);
+            dst[nh + 2 * S + 1] = ld_state(cs.qs.x + c, vz);
             cs.smp_iter[ss] = iter; cs.smp_chain[ss] = c;
         }
     }
@@ -319,7 +402,7 @@ __device__ __forceinline__ void commit_chain(const ChainsDev &cs, StepShared &sh
 #endif
 
 template <int NCH>
-__global__ __launch_bounds__(576) void k_step(FwdDev f, ChainsDev cs, int mode, int target_arg,
+__global__ __launch_bounds__(512) void k_step(FwdDev f, ChainsDev cs, int mode, int target_arg,
                                                const double *gathered, int ring_size, int wmax)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -333,6 +416,7 @@ __global__ __launch_bounds__(576) void k_step(FwdDev f, ChainsDev cs, int mode, 
     rg.pr = reinterpret_cast<double *>(carve);         carve += sizeof(double) * ring_size;
     rg.plogr = reinterpret_cast<double *>(carve);      carve += sizeof(double) * ring_size;
     rg.dec = reinterpret_cast<int4 *>(carve);          carve += sizeof(int4) * ring_size;
+    rg.sw = reinterpret_cast<int4 *>(carve);           carve += sizeof(int4) * ring_size;
     rg.hop = reinterpret_cast<int *>(carve);           carve += sizeof(int) * kHops * ring_size;
     double *s_sx = reinterpret_cast<double *>(carve);
     double *s_sy = s_sx + f.S;
@@ -340,12 +424,13 @@ __global__ __launch_bounds__(576) void k_step(FwdDev f, ChainsDev cs, int mode, 
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int NW = (blockDim.x >> 6) - 1;          // chain waves; wave NW is the prefetch wave
-    const bool prefetcher = wave == NW;
+    const int NW = blockDim.x >> 6;                // every wave is a chain wave
     const int nc = cs.n_chains;
     const bool lockstep = (mode != MODE_RUN);
     const int n_all = cs.n_procs * nc;
     const int RW = 4 + 2 * nc;                     // swap-record words
+    // helper roles between the barriers: validation+bookkeeping on wave 0, records and swap on other waves
+    const int wave_R = NW > 1 ? 1 : 0, wave_W = NW > 2 ? 2 : 0, wave_P = NW - 1;   // wave_P extends the window
 #ifdef HTM_STAMPS
     unsigned long long stamp_last_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -357,10 +442,11 @@ __global__ __launch_bounds__(576) void k_step(FwdDev f, ChainsDev cs, int mode, 
         sh.origin = sh.c.spos;
         const long long av = he - sh.c.spos;
         sh.avail = av > (1 << 30) ? (1 << 30) : (int)av;
-        sh.fill = 0; sh.base = 0; sh.redo = -1; sh.sw_do = 0;
+        sh.fill = 0; sh.base = 0; sh.redo = -1; sh.sw_do = 0; sh.catchup = 0;
     }
     for (int j = tid; j < f.S; j += blockDim.x) { s_sx[j] = f.sx[j]; s_sy[j] = f.sy[j]; s_sz[j] = f.sz[j]; }
     for (int c = tid; c < nc; c += blockDim.x) { sh.temp[c] = cs.temp[c]; sh.L[c] = cs.L[c]; }
+    for (int k = tid; k < 7 * nc; k += blockDim.x) { sh.np[k] = 0; sh.na[k] = 0; }
     __syncthreads();
 
     // ---------------- MODE_APPLY: cls_parallel.f90:118-213 from the all-gathered records -------------
@@ -404,10 +490,8 @@ __global__ __launch_bounds__(576) void k_step(FwdDev f, ChainsDev cs, int mode, 
     }
     STAMP(0);   // prologue
 
-    // ---------------- P0: first window of the stream || judge of the chains that came back from k_full --
-    if (prefetcher) {
-        prefetch_until(cs, sh, rg, 2 * wmax, lane);
-    } else if (resume) {
+    // ---------------- P0: judge + commit of the chains that came back from k_full; first stream window ----
+    if (resume) {
         for (int c = wave; c < nc; c += NW) {
             Proposal pr = cs.prop[c];
             if (pr.need_full) {
@@ -415,12 +499,18 @@ __global__ __launch_bounds__(576) void k_step(FwdDev f, ChainsDev cs, int mode, 
                 for (int k = lane; k < cs.n_wg; k += 64) acc += cs.partial[(size_t)c * cs.n_wg + k];
                 pr.L_new = -wave_sum1(acc) - f.const_sum;      // cls_forward.f90:277-300
                 pr.accepted = metropolis(pr.L_new, sh.L[c], sh.temp[c], pr.lpr, pr.r_judge, pr.logr_judge) ? 1 : 0;
+                if (lane == 0 && pr.accepted) {                // cls_mcmc.f90:207-219
+                    const ModelDev Mo = pick_model(cs, pr.type);
+                    Mo.x[(size_t)c * Mo.nx + pr.idx] = pr.x_new;
+                    sh.L[c] = pr.L_new;
+                    cs.L[c] = pr.L_new;
+                    if (pr.cool) sh.na[c * 7 + pr.type - 1] += 1;
+                }
             }
-            pr.cool = (sh.temp[c] < 1.0 + kEps) ? 1 : 0;
             if (lane == 0) sh.prop[c] = pr;
         }
     }
-    __syncthreads();
+    prefetch_all(cs, sh, rg, 2 * wmax);           // ends with a barrier
     STAMP(1);   // P0
 
     for (;;) {
@@ -440,114 +530,112 @@ __global__ __launch_bounds__(576) void k_step(FwdDev f, ChainsDev cs, int mode, 
                 __syncthreads();
                 break;
             }
-            // ---------------- passes: propose -> partial update -> decision, per chain wave ----------
+            if (sh.catchup) prefetch_all(cs, sh, rg, sh.base + 2 * wmax);   // rare; flag is uniform (set between barriers)
+            // ---------------- passes: propose -> partial update -> decide -> commit, per chain wave ----
             int redo = 0;
             bool first = true;
             for (;;) {
-                if (prefetcher) {
-                    // the NEXT iteration starts at most wmax further and needs wmax more
-                    if (first) prefetch_until(cs, sh, rg, sh.base + 3 * wmax, lane);
-                } else {
-                    int p = 0;
-                    bool have_p = false;
-                    for (int c = wave; c < nc; c += NW) {
-                        if (c < redo) continue;
-                        if (!first) p = sh.start_fix[c];                    // corrected by the validation
-                        else if (!have_p)                                   // optimistic start: c steps after base
-                            p = c == 0 ? sh.base : sh.base + rg.hop[(sh.base & rg.mask) * kHops + c - 1];
-                        p = chain_pass<NCH>(f, cs, sh, rg, s_sx, s_sy, s_sz, c, p, iter, lane);
-                        have_p = true;
-                        if (NW > 1 && c + NW < nc) p += rg.hop[(p & rg.mask) * kHops + NW - 2];   // skip NW-1 steps
+                // one wave keeps the LDS window ahead: loads issued before its pass, stored after it
+                PfRegs pf;
+                pf.p = -1;
+                const bool extend = first && wave == wave_P;
+                const int pf_limit = min(min(sh.base + 3 * wmax, sh.avail), sh.base + rg.mask + 1 - 8);
+                if (extend) pf_load(pf, cs, sh, sh.fill + lane, pf_limit);
+                int p = 0;
+                bool have_p = false;
+                for (int c = wave; c < nc; c += NW) {
+                    if (c < redo) continue;
+                    if (!first) {
+                        if (lane == 0) undo_chain(cs, sh, c);
+                        p = sh.start_fix[c];                                // corrected by the validation
+                    } else if (!have_p) {                                   // optimistic start: c steps after base
+                        p = c == 0 ? sh.base : sh.base + rg.hop[(sh.base & rg.mask) * kHops + c - 1];
                     }
+                    p = chain_pass<NCH>(f, cs, sh, rg, s_sx, s_sy, s_sz, c, p, iter, lane);
+                    have_p = true;
+                    if (NW > 1 && c + NW < nc) p += rg.hop[(p & rg.mask) * kHops + NW - 2];   // skip NW-1 steps
+                }
+                if (extend) {
+                    pf_store(pf, rg);
+                    if (lane == 0) sh.fill = max(sh.fill, min(sh.fill + 64, pf_limit));
                 }
                 __syncthreads();                                            // ---- barrier A
                 STAMP(2);   // passes
-                if (wave == 0) {
-                    // ---------------- validation: exact start = base + exclusive scan of the draw counts
-                    const bool in = lane < nc;
-                    const int my_cnt = in ? sh.cnt[lane] : 0, my_start = in ? sh.start[lane] : 0;
-                    const int incl = wave_incl_scan(my_cnt);
-                    const int exact = sh.base + incl - my_cnt;
-                    const unsigned long long bad = __ballot(in && exact != my_start);
-                    if (bad) {
-                        if (in) sh.start_fix[lane] = exact;
-                        if (lane == 0) sh.redo = __ffsll((long long)bad) - 1;
-                    } else {
-                        const int total = __builtin_amdgcn_readlane(incl, 63);
-                        const unsigned long long mf = __ballot(in && sh.prop[lane].need_full != 0);
-                        const unsigned long long mp = __ballot(in && sh.prop[lane].prior_ok != 0 && sh.prop[lane].need_full == 0);
-                        // ---------------- swap plan (cls_parallel.f90:226-230,:294), uniform over the wave ---
-                        int pos = sh.base + total, i1 = -1, i2 = -1, abort_ = 0;
-                        double sr = 0.0, slr = 0.0;
-                        const int limit = sh.fill - 2;            // positions the LDS window covers for sure
-                        if (n_all > 1) {
-                            if (cs.rank == 0) {
-                                i1 = (int)(rg.U[pos & rg.mask] * cs.n_procs * nc);
-                                pos++;
-                                for (;;) {
-                                    if (pos >= limit) { abort_ = 1; break; }
-                                    i2 = (int)(rg.U[pos & rg.mask] * cs.n_procs * nc);
-                                    pos++;
-                                    if (i1 != i2) break;
-                                }
-                            }
-                            if (pos >= limit) abort_ = 1;
-                            sr = rg.U[pos & rg.mask]; slr = rg.LOGU[pos & rg.mask];
-                            if (!lockstep) pos++;                // single rank: this rank is always rank1
-                        }
-                        if (abort_) {
-                            // a select_pair redraw run longer than the prefetched window (p < 1e-40): nothing
-                            // has been committed yet, so the iteration is simply retried by the next launch
+                if (wave == 0 || wave == wave_R || wave == wave_W) {
+                    const Valid v = validate(sh, nc, lane);
+                    int pos = 0, i1, i2;
+                    double sr, slr;
+                    const bool ok_plan = v.bad ? true : swap_plan(cs, sh, rg, lockstep, v.base + v.total, pos, i1, i2, sr, slr);
+                    const bool done = !v.bad && ok_plan && v.mf == 0;       // iteration complete in this launch
+                    if (wave == 0) {                                        // role V: validation + bookkeeping
+                        const bool in = lane < nc;
+                        if (v.bad) {
+                            const int my_cnt = in ? sh.cnt[lane] : 0;
+                            const int exact = v.base + wave_incl_scan(my_cnt) - my_cnt;
+                            if (in) sh.start_fix[lane] = exact;
+                            if (lane == 0) sh.redo = __ffsll((long long)v.bad) - 1;
+                        } else if (!ok_plan) {
+                            // nothing has been decided for good: undo and retry in the next launch
                             if (lane == 0) { sh.redo = -2; if (lockstep) sh.c.err = -7; else sh.c.stop = 2; }
                         } else {
-                            if (in && ((mf >> lane) & 1ull)) cs.full_list[__popcll(mf & ((1ull << lane) - 1ull))] = lane;
+                            const unsigned long long mp = __ballot(in && sh.prop[lane].prior_ok != 0 && sh.prop[lane].need_full == 0);
+                            if (in && ((v.mf >> lane) & 1ull)) cs.full_list[__popcll(v.mf & ((1ull << lane) - 1ull))] = lane;
                             if (lane == 0) {
                                 sh.c.swap_i1 = i1; sh.c.swap_i2 = i2; sh.c.swap_r = sr; sh.c.swap_logr = slr;
                                 sh.c.spos = sh.origin + pos;     // RNG commit: draws consumed so far
                                 sh.base = pos;
                                 sh.redo = -1;
-                                sh.c.n_full = __popcll(mf);
-                                sh.c.n_full_evals += __popcll(mf);
+                                sh.catchup = (sh.fill < pos + wmax) ? 1 : 0;
+                                sh.c.n_full = __popcll(v.mf);
+                                sh.c.n_full_evals += __popcll(v.mf);
                                 sh.c.n_partial_evals += __popcll(mp);
+                                if (v.mf == 0) {
+                                    if (lockstep) sh.c.stage = ST_WAIT_SWAP;
+                                    else { sh.c.iter_done = iter; sh.c.stage = ST_IDLE; }
+                                }
                             }
-                            if (mf == 0) finish_iteration(cs, sh, iter, lockstep, lane, NW == 1, true);
                         }
                     }
-                } else if (wave == 1 && NW > 1) {
-                    // helper wave: same validation (cheap), then the record half of the iteration end.
-                    // It reads only what wave 0 does not write between the barriers.
-                    const bool in = lane < nc;
-                    const int my_cnt = in ? sh.cnt[lane] : 0, my_start = in ? sh.start[lane] : 0;
-                    const int exact = sh.start[0] + wave_incl_scan(my_cnt) - my_cnt;   // chain 0 starts at base
-                    const unsigned long long bad = __ballot(in && exact != my_start);
-                    const unsigned long long mf = __ballot(in && sh.prop[lane].need_full != 0);
-                    if (!bad && mf == 0) finish_iteration(cs, sh, iter, lockstep, lane, true, false);
+                    if (wave == wave_R && done) role_records(cs, sh, iter, lockstep, lane);
+                    if (wave == wave_W && done) role_swap(cs, sh, iter, lockstep, lane, i1, i2, sr, slr);
                 }
                 __syncthreads();                                            // ---- barrier B
-                STAMP(3);   // validation + plan + finish
+                STAMP(3);   // validation + plan + records + swap
                 if (sh.redo < 0) break;
                 redo = sh.redo;
                 first = false;
             }
-            if (sh.redo == -2) break;            // aborted before any commit
-            if (sh.c.n_full > 0) {               // hand over to k_full; the next launch resumes after P0
+            if (sh.redo == -2) {                 // aborted: take everything back, retry in the next launch
+                for (int c = wave; c < nc; c += NW)
+                    if (lane == 0) undo_chain(cs, sh, c);
+                break;
+            }
+            if (sh.c.n_full > 0) {               // hand over to k_full; the next launch resumes at P0
                 for (int c = tid; c < nc; c += blockDim.x) cs.prop[c] = sh.prop[c];
                 if (tid == 0) sh.c.stage = ST_WAIT_FULL;
                 break;
             }
         } else {
-            if (wave == 0) finish_iteration(cs, sh, iter, lockstep, lane, NW == 1, true);
-            else if (wave == 1 && NW > 1) finish_iteration(cs, sh, iter, lockstep, lane, true, false);
+            // the iteration that waited for k_full: only its end is left (decisions were taken in P0)
+            if (wave == wave_R) role_records(cs, sh, iter, lockstep, lane);
+            if (wave == wave_W) role_swap(cs, sh, iter, lockstep, lane, sh.c.swap_i1, sh.c.swap_i2, sh.c.swap_r, sh.c.swap_logr);
+            if (tid == 0) {
+                if (lockstep) sh.c.stage = ST_WAIT_SWAP;
+                else { sh.c.iter_done = iter; sh.c.stage = ST_IDLE; }
+            }
             __syncthreads();
             resume = false;
         }
-        // ---------------- commit decisions + records (chain waves) ------------------------------------
-        if (!prefetcher)
-            for (int c = wave; c < nc; c += NW) commit_chain(cs, sh, c, iter, lane);
-        STAMP(4);   // commit
+        // ---------------- after the barrier: swap + records of the chains this wave owns ---------------
+        for (int c = wave; c < nc; c += NW) post_chain(cs, sh, c, iter, lane);
+        STAMP(4);   // post
         if (lockstep) break;
     }
     __syncthreads();
+    for (int k = tid; k < 7 * nc; k += blockDim.x) {          // flush this launch's counters
+        if (sh.np[k]) atomicAdd(&cs.n_propose[k], sh.np[k]);
+        if (sh.na[k]) atomicAdd(&cs.n_accept[k], sh.na[k]);
+    }
     if (tid == 0) *cs.ctrl = sh.c;
     STAMP(5);
 }

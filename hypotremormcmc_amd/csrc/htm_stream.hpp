@@ -17,7 +17,7 @@
 namespace htm {
 
 constexpr int kHops = 8;          // hop tables cover 1..8 chain steps (k_step has at most 8 chain waves)
-constexpr int kRecLag = 5;        // a record at p reads transforms up to p+5
+constexpr int kRecLag = 16;       // a record at p reads transforms up to p+5, a swap plan up to p+13
 constexpr int kHopLag = 6 * kHops;
 
 __global__ __launch_bounds__(64) void k_rawgen(StreamDev sd, long long start, int n)
@@ -50,7 +50,8 @@ __global__ __launch_bounds__(256) void k_stream_tr(StreamDev sd, long long start
 
 // cls_mcmc.f90:134-165: a_select, then (id,) (icmp,) then the two draws of rand_g, then the judge's rand_u
 __global__ __launch_bounds__(256) void k_stream_rec(StreamDev sd, long long start, long long end, double th1,
-                                                    double th2, double th3, double th4, int S, int E)
+                                                    double th2, double th3, double th4, int S, int E,
+                                                    int n_procs, int n_chains)
 {
     const long long p = start + (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= end) return;
@@ -71,6 +72,16 @@ __global__ __launch_bounds__(256) void k_stream_rec(StreamDev sd, long long star
     sd.pg[p & M] = sd.G[gpos & M];
     sd.pr[p & M] = sd.U[jpos & M];
     sd.plogr[p & M] = sd.LOGU[jpos & M];
+    // select_pair (cls_parallel.f90:226-230) if it started at p: i1, then i2 redrawn until it differs
+    int i1 = -1, i2 = -1, used = -1;
+    if (n_procs * n_chains > 1) {
+        i1 = (int)(a * n_procs * n_chains);
+        for (int k = 1; k <= 12; ++k) {
+            i2 = (int)(sd.U[(p + k) & M] * n_procs * n_chains);
+            if (i2 != i1) { used = k + 1; break; }
+        }
+    }
+    sd.sw[p & M] = make_int4(i1, i2, used, 0);
 }
 
 __global__ __launch_bounds__(256) void k_stream_hop(StreamDev sd, long long start, long long end)

@@ -26,13 +26,13 @@ base = list(a)
 n = 10000
 cs.run(n)
 lib.htm_chains_read_stamps(cs.handle, a)
-names = ["prologue", "P0 (window prefetch / resume judge)", "passes (propose+partial+decide)", "validate+plan+finish",
-         "commit", "epilogue"]
+names = ["prologue", "P0 (resume judge + window)", "passes (propose+partial+decide+commit)", "validate/records/swap roles",
+         "post (swap apply, records)", "epilogue"]
 tot = sum(a[k] - base[k] for k in range(len(names)))
 for k, nm in enumerate(names):
     d = a[k] - base[k]
     print("%-34s %9.0f ticks/iter  %5.1f %%" % (nm, d / n, 100.0 * d / tot))
-cn = ["decode+load issue", "proposal arith (load wait)", "event_misfit", "final sum+decision", "LDS write-back"]
+cn = ["decode+load issue", "proposal arith (load wait)", "event_misfit", "final sum+decision", "commit+LDS write-back"]
 for k, nm in enumerate(cn):
     print("  chain_pass[last chain] %-28s %8.0f ticks/iter" % (nm, (a[32 + k] - base[32 + k]) / n))
 st = cs.last_run_stats()
