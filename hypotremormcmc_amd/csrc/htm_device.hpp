@@ -291,6 +291,17 @@ struct Proposal {            // everything random about one chain step, resolved
     double L_new;
 };
 
+// Work order for k_full, written by k_step in one contiguous block when it hands over, so that every
+// workgroup of k_full learns what to do with a single memory round trip.
+struct FullEntry {
+    int chain, type, idx, pad;    // proposal being evaluated: cls_mcmc.f90 type 1..7, 0-based element
+    double x_new, beta, q;        // proposed value; vs and qs of the evaluated model (proposal applied)
+};
+struct FullDesc {
+    int n, pad0, pad1, pad2;      // number of entries; 0 = nothing pending
+    FullEntry e[kMaxChains];
+};
+
 struct Ctrl {
     int iter_done, iter_target, stage, n_full;
     int err, stop, n_lik, n_smp;
@@ -325,7 +336,7 @@ struct ChainsDev {
     double th1, th2, th3, th4;       // cumulative proposal thresholds, cls_mcmc.f90:139-153
     int n_burn, n_interval;
     Proposal *prop;                  // [n_chains]
-    int *full_list;                  // [n_chains]
+    FullDesc *desc;                  // k_full's work order (chains whose proposal needs a full evaluation)
     double *partial;                 // [n_chains][n_wg]
     int n_wg;
     Ctrl *ctrl;

@@ -116,6 +116,7 @@ struct htm_chains {
     long long cap = 0;                         // ring capacity (positions)
     long long n_raw = 0, n_tr = 0, n_rec = 0, n_hop = 0;   // positions produced per stage (host view)
     long long spos_lo = 0, spos_hi = 0;        // bounds on the consumed position since the last sync
+    const double *pending_gathered = nullptr;  // lock-step: records whose swap the next k_step applies
     uint32_t init_state[4] = {0, 0, 0, 0};     // mod_random state at stream position 0
     double th[4] = {0, 0, 0, 0};
 };
@@ -125,7 +126,7 @@ namespace {
 int launch_full(htm_forward *h, const FullJob &jb, int gy)
 {
     dim3 grid(h->n_wg, gy), block(256);
-    const size_t smem = (3 * (size_t)h->S + 4) * sizeof(double);
+    const size_t smem = 0;
     switch (h->nch) {
     case 1: hipLaunchKernelGGL(k_full<1>, grid, block, smem, h->stream, h->dev, jb); break;
     case 2: hipLaunchKernelGGL(k_full<2>, grid, block, smem, h->stream, h->dev, jb); break;
@@ -188,7 +189,7 @@ FullJob chain_full_job(htm_chains *hc)
     jb.tc = d.tc.x; jb.tc_stride = d.S;
     jb.ac = d.ac.x; jb.ac_stride = d.S;
     jb.vs = d.vs.x; jb.qs = d.qs.x;
-    jb.prop = d.prop; jb.list = d.full_list; jb.ctrl = d.ctrl;
+    jb.desc = d.desc;
     jb.n_models = d.n_chains;
     jb.partial = d.partial; jb.n_wg = hc->fwd->n_wg; jb.epw = hc->fwd->epw;
     return jb;
@@ -547,7 +548,8 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
     d.n_burn = init->n_burn; d.n_interval = init->n_interval;
     d.n_wg = h->n_wg;
     if ((rc = dev_alloc(hc->pool, &d.prop, nc))) return cleanup(rc);
-    if ((rc = dev_alloc(hc->pool, &d.full_list, nc))) return cleanup(rc);
+    if ((rc = dev_alloc(hc->pool, &d.desc, 1))) return cleanup(rc);
+    HIPCHK(hipMemset(d.desc, 0, sizeof(FullDesc)));
     if ((rc = dev_alloc(hc->pool, &d.partial, (size_t)nc * h->n_wg))) return cleanup(rc);
     if ((rc = dev_alloc(hc->pool, &d.swap_rec, 4 + 2 * (size_t)nc))) return cleanup(rc);
     HIPCHK(hipMemset(d.prop, 0, nc * sizeof(Proposal)));
@@ -645,8 +647,18 @@ int htm_chains_destroy(htm_chains *hc)
     return HTM_OK;
 }
 
+static int flush_pending(htm_chains *hc)
+{
+    if (!hc->pending_gathered) return HTM_OK;
+    const double *g = hc->pending_gathered;
+    hc->pending_gathered = nullptr;
+    return launch_step(hc, MODE_APPLY, hc->h_target, g);
+}
+
 static int read_ctrl(htm_chains *hc)
 {
+    int rc_ = flush_pending(hc);
+    if (rc_) return rc_;
     HIPCHK(hipMemcpyAsync(&hc->h_ctrl, hc->dev.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, hc->fwd->stream));
     HIPCHK(hipStreamSynchronize(hc->fwd->stream));
     hc->spos_lo = hc->spos_hi = hc->h_ctrl.spos;
@@ -707,7 +719,7 @@ static int build_graph(htm_chains *hc)
     const FullJob jb = chain_full_job(hc);
     for (int k = 0; k < hc->pairs && rc == HTM_OK; ++k) {
         rc = launch_step(hc, MODE_RUN, -1, nullptr);
-        if (rc == HTM_OK) rc = launch_full(h, jb, 1);
+        if (rc == HTM_OK) rc = launch_full(h, jb, hc->dev.n_chains);
     }
     hipGraph_t g = nullptr;
     e = hipStreamEndCapture(cap, &g);
@@ -798,7 +810,7 @@ int htm_chains_profile(htm_chains *hc, int n_iter, double *step_us, int *step_la
             HIPCHK(hipEventRecord(ev[3 * k], h->stream));
             if ((rc = launch_step(hc, MODE_RUN, -1, nullptr))) return rc;
             HIPCHK(hipEventRecord(ev[3 * k + 1], h->stream));
-            if ((rc = launch_full(h, jb, 1))) return rc;
+            if ((rc = launch_full(h, jb, hc->dev.n_chains))) return rc;
             HIPCHK(hipEventRecord(ev[3 * k + 2], h->stream));
         }
         if ((rc = read_ctrl(hc))) return rc;
@@ -839,9 +851,10 @@ int htm_chains_step_begin(htm_chains *hc)
         if ((rc = stream_produce(hc, 1 << 16))) return rc;
         HIPCHK(hipStreamWaitEvent(h->stream, hc->ev_side, 0));
     }
-    rc = launch_step(hc, MODE_ADVANCE, hc->h_target, nullptr);
+    rc = launch_step(hc, MODE_ADVANCE, hc->h_target, hc->pending_gathered);   // applies the previous swap first
+    hc->pending_gathered = nullptr;
     if (rc) return rc;
-    if ((rc = launch_full(h, chain_full_job(hc), 1))) return rc;
+    if ((rc = launch_full(h, chain_full_job(hc), hc->dev.n_chains))) return rc;
     return launch_step(hc, MODE_FINISH, hc->h_target, nullptr);
 }
 
@@ -858,7 +871,10 @@ int htm_chains_step_end(htm_chains *hc, const void *d_gathered_records)
     if (!hc) return fail(HTM_EINVAL, "NULL handle");
     if (!d_gathered_records) return fail(HTM_EINVAL, "gathered records pointer is NULL");
     HIPCHK(hipSetDevice(hc->fwd->device));
-    return launch_step(hc, MODE_APPLY, hc->h_target, static_cast<const double *>(d_gathered_records));
+    // deferred: the next step_begin's kernel applies the swap before it advances (one launch less per
+    // iteration); anything that looks at the state flushes it first (flush_pending)
+    hc->pending_gathered = static_cast<const double *>(d_gathered_records);
+    return HTM_OK;
 }
 
 int htm_chains_sync(htm_chains *hc)

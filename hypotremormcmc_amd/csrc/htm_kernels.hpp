@@ -19,50 +19,45 @@ struct FullJob {
     const double *hypo; long hypo_stride;
     const double *tc;   long tc_stride;
     const double *ac;   long ac_stride;
-    const double *vs, *qs;          // [n_models]
-    const Proposal *prop;           // chain mode: proposed override per model, else nullptr
-    const int *list;                // chain mode: models needing a full evaluation, else nullptr
-    const Ctrl *ctrl;               // chain mode: gate on ctrl->stage == ST_WAIT_FULL, n = ctrl->n_full
-    int n_models;
+    const double *vs, *qs;          // [n_models]   (batch mode)
+    const FullDesc *desc;           // chain mode: work order written by k_step; blockIdx.y = entry
+    int n_models;                   // batch mode: models m = blockIdx.y, blockIdx.y + gridDim.y, ...
     double *partial;                // [n_models][n_wg]
     int n_wg, epw;                  // event tiles; events per wave
 };
 
+// Full log-likelihood (reference forward_calc_log_likelihood, src/cls_forward.f90:268-303) of one or many
+// models.  Grid: x = event tile, y = model (chain mode: entry of the work order).  wave <-> event,
+// lane <-> station; each lane keeps its station's coordinates and corrections in registers; the four
+// observation streams are read with coalesced 512-B wave loads.  Output: one partial sum per workgroup,
+// reduced in a fixed order by the consumer (deterministic).
 template <int NCH>
 __global__ __launch_bounds__(256) void k_full(FwdDev f, FullJob jb)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    double *s_sx = reinterpret_cast<double *>(smem);
-    double *s_sy = s_sx + f.S;
-    double *s_sz = s_sy + f.S;
-    double *s_red = s_sz + f.S;   // 4 doubles
-
-    int nm = jb.n_models;
-    if (jb.ctrl) {
-        if (jb.ctrl->stage != ST_WAIT_FULL) return;
-        nm = jb.ctrl->n_full;
-    }
-    if (nm <= 0) return;
-
+    __shared__ double s_red[4];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (int j = threadIdx.x; j < f.S; j += blockDim.x) {
-        s_sx[j] = f.sx[j]; s_sy[j] = f.sy[j]; s_sz[j] = f.sz[j];
-    }
-    __syncthreads();
 
-    for (int k = blockIdx.y; k < nm; k += gridDim.y) {
-        const int m = jb.list ? jb.list[k] : k;
-        double beta = jb.vs[m], q = jb.qs[m];
+    int k0 = blockIdx.y, kstep = gridDim.y, nm = jb.n_models;
+    FullEntry en;
+    en.chain = 0; en.type = 0; en.idx = -1; en.pad = 0; en.x_new = 0.0; en.beta = 0.0; en.q = 0.0;
+    if (jb.desc) {                                  // one round trip: header + this block's entry
+        const int n = jb.desc->n;
+        en = jb.desc->e[blockIdx.y];
+        if ((int)blockIdx.y >= n) return;
+        kstep = 1 << 30; nm = blockIdx.y + 1;       // exactly one model per block
+    }
+    for (int k = k0; k < nm; k += kstep) {
+        const int m = jb.desc ? en.chain : k;
+        double beta, q;
         int ov_kind = 0, ov_idx = -1, ov_evt = -1, ov_cmp = 0;
-        double ov_val = 0.0;
-        if (jb.prop) {
-            const Proposal &pr = jb.prop[m];
-            ov_val = pr.x_new;
-            if (pr.type == 1) beta = pr.x_new;
-            else if (pr.type == 3) q = pr.x_new;
-            else if (pr.type == 2 || pr.type == 4) { ov_kind = pr.type; ov_idx = pr.idx; }
-            else { ov_evt = pr.idx / 3; ov_cmp = pr.idx - 3 * ov_evt; }
+        const double ov_val = en.x_new;
+        if (jb.desc) {
+            beta = en.beta; q = en.q;
+            if (en.type == 2 || en.type == 4) { ov_kind = en.type; ov_idx = en.idx; }
+            else if (en.type >= 5) { ov_evt = en.idx / 3; ov_cmp = en.idx - 3 * ov_evt; }
+        } else {
+            beta = jb.vs[m]; q = jb.qs[m];
         }
         const double *hyp = jb.hypo + (size_t)m * jb.hypo_stride;
         const double *tc = jb.tc + (size_t)m * jb.tc_stride;
@@ -71,7 +66,7 @@ __global__ __launch_bounds__(256) void k_full(FwdDev f, FullJob jb)
         double lane_acc = 0.0;
         if constexpr (NCH > 0) {
             StaRegs<NCH> st;
-            load_sta_regs<NCH>(st, f.S, lane, s_sx, s_sy, s_sz, tc, ac, ov_kind, ov_idx, ov_val);
+            load_sta_regs<NCH>(st, f.S, lane, f.sx, f.sy, f.sz, tc, ac, ov_kind, ov_idx, ov_val);
             for (int e = 0; e < jb.epw; ++e) {
                 const int ev = (blockIdx.x * jb.epw + e) * 4 + wave;
                 if (ev < f.E) {
@@ -92,14 +87,12 @@ __global__ __launch_bounds__(256) void k_full(FwdDev f, FullJob jb)
             for (int e = 0; e < jb.epw; ++e) {
                 const int ev = (blockIdx.x * jb.epw + e) * 4 + wave;
                 if (ev < f.E) {
-                    // plain selects: an if/else-if/else chain of stores into these arrays was miscompiled
-                    // by hipcc 7.2 at -O3 (the final else-store was dropped), see DESIGN.md §7
                     const bool ov = ev == ov_evt;
                     const double px[1] = {(ov && ov_cmp == 0) ? ov_val : hyp[3 * ev]};
                     const double py[1] = {(ov && ov_cmp == 1) ? ov_val : hyp[3 * ev + 1]};
                     const double pz[1] = {(ov && ov_cmp == 2) ? ov_val : hyp[3 * ev + 2]};
                     double out[1];
-                    event_misfit_generic<1>(f, ev, lane, s_sx, s_sy, s_sz, tc, ac, ov_kind, ov_idx, ov_val,
+                    event_misfit_generic<1>(f, ev, lane, f.sx, f.sy, f.sz, tc, ac, ov_kind, ov_idx, ov_val,
                                             px, py, pz, beta, q, out);
                     lane_acc += out[0];
                 }

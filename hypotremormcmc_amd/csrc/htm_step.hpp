@@ -388,6 +388,35 @@ __device__ __forceinline__ void post_chain(const ChainsDev &cs, StepShared &sh, 
     }
 }
 
+// thread 0: temperature swap between chains of any two ranks from the all-gathered records
+// (cls_parallel.f90:118-213, :285-302).  Every rank evaluates the same decision from the same records.
+__device__ __forceinline__ void apply_swap(const ChainsDev &cs, StepShared &sh, const double *gathered)
+{
+    const int nc = cs.n_chains, RW = 4 + 2 * nc;
+    const int iter = sh.c.iter_done + 1;
+    if (cs.n_procs * nc > 1) {
+        for (int r = 0; r < cs.n_procs; ++r)
+            if ((int)gathered[(size_t)r * RW + 3] != iter) sh.c.err = -6;
+        const int i1 = (int)gathered[0], i2 = (int)gathered[1];
+        const int rank1 = i1 / nc, chain1 = i1 % nc, rank2 = i2 / nc, chain2 = i2 % nc;
+        const double T1 = gathered[(size_t)rank1 * RW + 4 + 2 * chain1];
+        const double L1 = gathered[(size_t)rank1 * RW + 5 + 2 * chain1];
+        const double T2 = gathered[(size_t)rank2 * RW + 4 + 2 * chain2];
+        const double L2 = gathered[(size_t)rank2 * RW + 5 + 2 * chain2];
+        const double r = gathered[(size_t)rank1 * RW + 2];
+        const double del_s = (L2 - L1) * (1.0 / T1 - 1.0 / T2);
+        bool acc = false;
+        if (r >= kEps) { if (log(r) <= del_s) acc = true; }
+        if (acc) {
+            if (cs.rank == rank1) { cs.temp[chain1] = T2; sh.temp[chain1] = T2; }
+            if (cs.rank == rank2) { cs.temp[chain2] = T1; sh.temp[chain2] = T1; }
+        }
+        if (cs.rank == rank1) sh.c.spos += 1;       // judge_swap's rand_u() came from rank1's stream
+    }
+    sh.c.iter_done = iter;
+    sh.c.stage = ST_IDLE;
+}
+
 #ifdef HTM_STAMPS
 #define STAMP(k)                                                                                   \
     do {                                                                                           \
@@ -427,8 +456,6 @@ __global__ __launch_bounds__(512) void k_step(FwdDev f, ChainsDev cs, int mode, 
     const int NW = blockDim.x >> 6;                // every wave is a chain wave
     const int nc = cs.n_chains;
     const bool lockstep = (mode != MODE_RUN);
-    const int n_all = cs.n_procs * nc;
-    const int RW = 4 + 2 * nc;                     // swap-record words
     // helper roles between the barriers: validation+bookkeeping on wave 0, records and swap on other waves
     const int wave_R = NW > 1 ? 1 : 0, wave_W = NW > 2 ? 2 : 0, wave_P = NW - 1;   // wave_P extends the window
 #ifdef HTM_STAMPS
@@ -449,35 +476,19 @@ __global__ __launch_bounds__(512) void k_step(FwdDev f, ChainsDev cs, int mode, 
     for (int k = tid; k < 7 * nc; k += blockDim.x) { sh.np[k] = 0; sh.na[k] = 0; }
     __syncthreads();
 
-    // ---------------- MODE_APPLY: cls_parallel.f90:118-213 from the all-gathered records -------------
-    if (mode == MODE_APPLY) {
+    // ---------------- swap of the previous lock-step iteration (cls_parallel.f90:118-213) --------------
+    // MODE_APPLY does only this; MODE_ADVANCE does it first when the host passes the gathered records along
+    if ((mode == MODE_APPLY || mode == MODE_ADVANCE) && gathered != nullptr) {
         if (tid == 0 && sh.c.stage == ST_WAIT_SWAP && sh.c.err == 0) {
-            const int iter = sh.c.iter_done + 1;
-            if (n_all > 1) {
-                for (int r = 0; r < cs.n_procs; ++r)
-                    if ((int)gathered[(size_t)r * RW + 3] != iter) sh.c.err = -6;
-                const int i1 = (int)gathered[0], i2 = (int)gathered[1];
-                const int rank1 = i1 / nc, chain1 = i1 % nc, rank2 = i2 / nc, chain2 = i2 % nc;
-                const double T1 = gathered[(size_t)rank1 * RW + 4 + 2 * chain1];
-                const double L1 = gathered[(size_t)rank1 * RW + 5 + 2 * chain1];
-                const double T2 = gathered[(size_t)rank2 * RW + 4 + 2 * chain2];
-                const double L2 = gathered[(size_t)rank2 * RW + 5 + 2 * chain2];
-                const double r = gathered[(size_t)rank1 * RW + 2];
-                const double del_s = (L2 - L1) * (1.0 / T1 - 1.0 / T2);
-                bool acc = false;
-                if (r >= kEps) { if (log(r) <= del_s) acc = true; }
-                if (acc) {
-                    if (cs.rank == rank1) cs.temp[chain1] = T2;
-                    if (cs.rank == rank2) cs.temp[chain2] = T1;
-                }
-                if (cs.rank == rank1) sh.c.spos += 1;       // judge_swap's rand_u() came from rank1's stream
-            }
-            sh.c.iter_done = iter;
-            sh.c.stage = ST_IDLE;
+            apply_swap(cs, sh, gathered);
+            const long long av = *cs.stream.hop_end - sh.c.spos;
+            sh.origin = sh.c.spos;
+            sh.avail = av > (1 << 30) ? (1 << 30) : (int)av;
             *cs.ctrl = sh.c;
         }
-        return;
+        __syncthreads();
     }
+    if (mode == MODE_APPLY) return;
 
     bool resume = (sh.c.stage == ST_WAIT_FULL);
     if (mode == MODE_FINISH && !resume) return;
@@ -492,6 +503,7 @@ __global__ __launch_bounds__(512) void k_step(FwdDev f, ChainsDev cs, int mode, 
 
     // ---------------- P0: judge + commit of the chains that came back from k_full; first stream window ----
     if (resume) {
+        if (tid == 0) cs.desc->n = 0;                          // work order consumed
         for (int c = wave; c < nc; c += NW) {
             Proposal pr = cs.prop[c];
             if (pr.need_full) {
@@ -579,7 +591,15 @@ __global__ __launch_bounds__(512) void k_step(FwdDev f, ChainsDev cs, int mode, 
                             if (lane == 0) { sh.redo = -2; if (lockstep) sh.c.err = -7; else sh.c.stop = 2; }
                         } else {
                             const unsigned long long mp = __ballot(in && sh.prop[lane].prior_ok != 0 && sh.prop[lane].need_full == 0);
-                            if (in && ((v.mf >> lane) & 1ull)) cs.full_list[__popcll(v.mf & ((1ull << lane) - 1ull))] = lane;
+                            if (in && ((v.mf >> lane) & 1ull)) {            // k_full's work order, chain order
+                                const Proposal &pr = sh.prop[lane];
+                                const int vz = opaque_zero();
+                                FullEntry en;
+                                en.chain = lane; en.type = pr.type; en.idx = pr.idx; en.pad = 0; en.x_new = pr.x_new;
+                                en.beta = pr.type == 1 ? pr.x_new : ld_state(cs.vs.x + lane, vz);
+                                en.q = pr.type == 3 ? pr.x_new : ld_state(cs.qs.x + lane, vz);
+                                cs.desc->e[__popcll(v.mf & ((1ull << lane) - 1ull))] = en;
+                            }
                             if (lane == 0) {
                                 sh.c.swap_i1 = i1; sh.c.swap_i2 = i2; sh.c.swap_r = sr; sh.c.swap_logr = slr;
                                 sh.c.spos = sh.origin + pos;     // RNG commit: draws consumed so far
@@ -587,6 +607,7 @@ __global__ __launch_bounds__(512) void k_step(FwdDev f, ChainsDev cs, int mode, 
                                 sh.redo = -1;
                                 sh.catchup = (sh.fill < pos + wmax) ? 1 : 0;
                                 sh.c.n_full = __popcll(v.mf);
+                                if (v.mf) cs.desc->n = __popcll(v.mf);
                                 sh.c.n_full_evals += __popcll(v.mf);
                                 sh.c.n_partial_evals += __popcll(mp);
                                 if (v.mf == 0) {
