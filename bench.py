@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--chains", type=int, default=N_CHAINS)
     ap.add_argument("--events", type=int, default=N_EVENTS)
     ap.add_argument("--stations", type=int, default=N_STA)
+    ap.add_argument("--force-lockstep", action="store_true",
+                    help="N = 1 only: drive the multi-rank code path (RCCL all-gather per iteration) with one rank")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -83,10 +85,15 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_lockstep:
         import torch.distributed as dist
 
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     E, S, nc = args.events, args.stations, args.chains
     data = synth.make_synthetic(E, S, SEED)
@@ -101,7 +108,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if world == 1:
+    if world == 1 and not args.force_lockstep:
         run = cs.run
     else:
         from hypotremormcmc_amd.parallel import TorchWorld
@@ -137,7 +144,9 @@ def main():
                                   f"{8 * (4 + 2 * nc)} B per rank per iteration" if world > 1 else "single rank"},
     }
 
-    if rank == 0 and world == 1:
+    if args.force_lockstep:
+        out["config"]["parallelism"] = "lock-step path (one RCCL all-gather per iteration), 1 rank"
+    if rank == 0 and world == 1 and not args.force_lockstep:
         # ---- live per-kernel timings (HIP events on the kernels' stream), same chains, continuing the run
         n_prof = min(4000, max(500, args.steps // 5))
         prof = cs.profile(n_prof)

@@ -1,0 +1,214 @@
+!> ISO_C_BINDING view of libhtm_hip.so (C ABI: include/htm_hip.h).  One interface per C symbol the Fortran
+!> host code uses; argument names, order and meaning follow the header.
+module htm_c_api
+  use, intrinsic :: iso_c_binding
+  implicit none
+  private
+  public :: htm_model_init, htm_chains_init
+  public :: htm_last_error_c, htm_error_message
+  public :: htm_forward_create, htm_forward_destroy, htm_forward_loglik_full, htm_forward_loglik_partial
+  public :: htm_forward_travel_time, htm_forward_amp, htm_forward_travel_time_single, htm_forward_amp_single
+  public :: htm_chains_create, htm_chains_destroy, htm_chains_run, htm_chains_get_state, htm_chains_get_rng
+  public :: htm_chains_lik_count, htm_chains_lik_read, htm_chains_sample_count, htm_chains_sample_read
+  public :: htm_chains_iterations_done
+
+  !> one `type model` group stacked over the chains of the rank (include/htm_hip.h: htm_model_init)
+  type, bind(C) :: htm_model_init
+     type(c_ptr) :: x = c_null_ptr, mu = c_null_ptr, sigma = c_null_ptr, step_size = c_null_ptr
+     type(c_ptr) :: prior_type = c_null_ptr
+  end type htm_model_init
+
+  type, bind(C) :: htm_chains_init
+     integer(c_int) :: n_chains, n_procs, rank
+     type(htm_model_init) :: hypo, t_corr, vs, a_corr, qs
+     type(c_ptr) :: temp
+     integer(c_int) :: solve_vs, solve_t_corr, solve_qs, solve_a_corr
+     integer(c_int32_t) :: rng_state(4)
+     integer(c_int) :: n_burn, n_interval
+     integer(c_int) :: lik_capacity = 0, sample_capacity = 0
+  end type htm_chains_init
+
+  interface
+     function htm_last_error_c() bind(C, name="htm_last_error") result(p)
+       import :: c_ptr
+       type(c_ptr) :: p
+     end function htm_last_error_c
+
+     function htm_forward_create(n_sta, n_events, sta_x, sta_y, sta_z, t_obs, t_stdv, a_obs, a_stdv, &
+          & use_time, use_amp, device, handle) bind(C, name="htm_forward_create") result(rc)
+       import :: c_int, c_double, c_ptr
+       integer(c_int), value :: n_sta, n_events, use_time, use_amp, device
+       real(c_double), intent(in) :: sta_x(*), sta_y(*), sta_z(*)
+       real(c_double), intent(in) :: t_obs(*), t_stdv(*), a_obs(*), a_stdv(*)
+       type(c_ptr), intent(out) :: handle
+       integer(c_int) :: rc
+     end function htm_forward_create
+
+     function htm_forward_destroy(handle) bind(C, name="htm_forward_destroy") result(rc)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: handle
+       integer(c_int) :: rc
+     end function htm_forward_destroy
+
+     function htm_forward_loglik_full(handle, hypo, t_corr, vs, a_corr, qs, log_likelihood) &
+          & bind(C, name="htm_forward_loglik_full") result(rc)
+       import :: c_int, c_double, c_ptr
+       type(c_ptr), value :: handle
+       real(c_double), intent(in) :: hypo(*), t_corr(*), a_corr(*)
+       real(c_double), value :: vs, qs
+       real(c_double), intent(out) :: log_likelihood
+       integer(c_int) :: rc
+     end function htm_forward_loglik_full
+
+     function htm_forward_loglik_partial(handle, evt_id, hypo_old_xyz, log_likelihood_old, hypo_xyz, &
+          & t_corr, vs, a_corr, qs, log_likelihood) bind(C, name="htm_forward_loglik_partial") result(rc)
+       import :: c_int, c_double, c_ptr
+       type(c_ptr), value :: handle
+       integer(c_int), value :: evt_id
+       real(c_double), intent(in) :: hypo_old_xyz(3), hypo_xyz(3), t_corr(*), a_corr(*)
+       real(c_double), value :: log_likelihood_old, vs, qs
+       real(c_double), intent(out) :: log_likelihood
+       integer(c_int) :: rc
+     end function htm_forward_loglik_partial
+
+     function htm_forward_travel_time(handle, hypo, t_corr, vs, t_syn) &
+          & bind(C, name="htm_forward_travel_time") result(rc)
+       import :: c_int, c_double, c_ptr
+       type(c_ptr), value :: handle
+       real(c_double), intent(in) :: hypo(*), t_corr(*)
+       real(c_double), value :: vs
+       real(c_double), intent(out) :: t_syn(*)
+       integer(c_int) :: rc
+     end function htm_forward_travel_time
+
+     function htm_forward_amp(handle, hypo, a_corr, qs, vs, a_syn) bind(C, name="htm_forward_amp") result(rc)
+       import :: c_int, c_double, c_ptr
+       type(c_ptr), value :: handle
+       real(c_double), intent(in) :: hypo(*), a_corr(*)
+       real(c_double), value :: qs, vs
+       real(c_double), intent(out) :: a_syn(*)
+       integer(c_int) :: rc
+     end function htm_forward_amp
+
+     function htm_forward_travel_time_single(handle, evt_id, hypo, t_corr, vs, t_syn) &
+          & bind(C, name="htm_forward_travel_time_single") result(rc)
+       import :: c_int, c_double, c_ptr
+       type(c_ptr), value :: handle
+       integer(c_int), value :: evt_id
+       real(c_double), intent(in) :: hypo(*), t_corr(*)
+       real(c_double), value :: vs
+       real(c_double), intent(out) :: t_syn(*)
+       integer(c_int) :: rc
+     end function htm_forward_travel_time_single
+
+     function htm_forward_amp_single(handle, evt_id, hypo, a_corr, qs, vs, a_syn) &
+          & bind(C, name="htm_forward_amp_single") result(rc)
+       import :: c_int, c_double, c_ptr
+       type(c_ptr), value :: handle
+       integer(c_int), value :: evt_id
+       real(c_double), intent(in) :: hypo(*), a_corr(*)
+       real(c_double), value :: qs, vs
+       real(c_double), intent(out) :: a_syn(*)
+       integer(c_int) :: rc
+     end function htm_forward_amp_single
+
+     function htm_chains_create(forward_handle, init, handle) bind(C, name="htm_chains_create") result(rc)
+       import :: c_int, c_ptr, htm_chains_init
+       type(c_ptr), value :: forward_handle
+       type(htm_chains_init), intent(in) :: init
+       type(c_ptr), intent(out) :: handle
+       integer(c_int) :: rc
+     end function htm_chains_create
+
+     function htm_chains_destroy(handle) bind(C, name="htm_chains_destroy") result(rc)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: handle
+       integer(c_int) :: rc
+     end function htm_chains_destroy
+
+     function htm_chains_run(handle, n_iter) bind(C, name="htm_chains_run") result(rc)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: handle
+       integer(c_int), value :: n_iter
+       integer(c_int) :: rc
+     end function htm_chains_run
+
+     function htm_chains_iterations_done(handle, n) bind(C, name="htm_chains_iterations_done") result(rc)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: handle
+       integer(c_int), intent(out) :: n
+       integer(c_int) :: rc
+     end function htm_chains_iterations_done
+
+     function htm_chains_get_state(handle, chain, hypo, t_corr, vs, a_corr, qs, temp, log_likelihood, &
+          & n_propose, n_accept) bind(C, name="htm_chains_get_state") result(rc)
+       import :: c_int, c_int32_t, c_double, c_ptr
+       type(c_ptr), value :: handle
+       integer(c_int), value :: chain
+       real(c_double), intent(out) :: hypo(*), t_corr(*), a_corr(*), vs, qs, temp, log_likelihood
+       integer(c_int32_t), intent(out) :: n_propose(7), n_accept(7)
+       integer(c_int) :: rc
+     end function htm_chains_get_state
+
+     function htm_chains_get_rng(handle, state) bind(C, name="htm_chains_get_rng") result(rc)
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value :: handle
+       integer(c_int32_t), intent(out) :: state(4)
+       integer(c_int) :: rc
+     end function htm_chains_get_rng
+
+     function htm_chains_lik_count(handle, n) bind(C, name="htm_chains_lik_count") result(rc)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: handle
+       integer(c_int), intent(out) :: n
+       integer(c_int) :: rc
+     end function htm_chains_lik_count
+
+     function htm_chains_lik_read(handle, iter, chain, log_likelihood) bind(C, name="htm_chains_lik_read") result(rc)
+       import :: c_int, c_int32_t, c_double, c_ptr
+       type(c_ptr), value :: handle
+       integer(c_int32_t), intent(out) :: iter(*), chain(*)
+       real(c_double), intent(out) :: log_likelihood(*)
+       integer(c_int) :: rc
+     end function htm_chains_lik_read
+
+     function htm_chains_sample_count(handle, n) bind(C, name="htm_chains_sample_count") result(rc)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: handle
+       integer(c_int), intent(out) :: n
+       integer(c_int) :: rc
+     end function htm_chains_sample_count
+
+     function htm_chains_sample_read(handle, k, iter, chain, vs, qs, hypo, t_corr, a_corr) &
+          & bind(C, name="htm_chains_sample_read") result(rc)
+       import :: c_int, c_int32_t, c_double, c_ptr
+       type(c_ptr), value :: handle
+       integer(c_int), value :: k
+       integer(c_int32_t), intent(out) :: iter, chain
+       real(c_double), intent(out) :: vs, qs, hypo(*), t_corr(*), a_corr(*)
+       integer(c_int) :: rc
+     end function htm_chains_sample_read
+  end interface
+
+contains
+
+  !> htm_last_error() as a Fortran string
+  function htm_error_message() result(msg)
+    character(len=:), allocatable :: msg
+    type(c_ptr) :: p
+    character(kind=c_char), pointer :: s(:)
+    integer :: n
+    p = htm_last_error_c()
+    msg = ""
+    if (.not. c_associated(p)) return
+    call c_f_pointer(p, s, [512])
+    n = 0
+    do while (n < 512)
+       if (s(n + 1) == c_null_char) exit
+       n = n + 1
+    end do
+    allocate(character(len=n) :: msg)
+    msg = transfer(s(1:n), msg)
+  end function htm_error_message
+
+end module htm_c_api

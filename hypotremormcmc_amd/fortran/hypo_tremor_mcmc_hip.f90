@@ -1,0 +1,237 @@
+!> hypo_tremor_mcmc on the MI355X: same command line, parameter file, input files and output files as the
+!> reference's step-5 program (src/hypo_tremor_mcmc.f90), with the whole main loop -- propose, forward,
+!> judge, record, swap (:236-284) -- executed by the device-resident chains of libhtm_hip.so.
+!>
+!>   hypo_tremor_mcmc_hip <parameter file>
+!>
+!> One process drives one GPU (n_procs = 1 in this program; multi-GPU jobs run one rank per GPU through
+!> the Python launcher, see INTEGRATION.md).  Set-up follows the reference line by line so that the random
+!> stream is consumed in the same order: station corrections, amplitude corrections, hypocentres, then the
+!> temperature of each tempered chain.
+program hypo_tremor_mcmc_hip
+  use, intrinsic :: iso_c_binding
+  use, intrinsic :: iso_fortran_env, only: iostat_end
+  use htm_c_api
+  use htm_random
+  use htm_param, only: param, line_max
+  use cls_model, only: model
+  use cls_obs_data, only: obs_data
+  use cls_forward, only: forward
+  implicit none
+
+  type(param) :: para
+  type(obs_data) :: obs
+  type(forward) :: fwd
+  type(model) :: t_corr, a_corr, hypo, vs, qs
+  type(htm_chains_init) :: init
+  type(c_ptr) :: chains
+  character(line_max) :: param_file
+  integer, allocatable :: win_id(:)
+  double precision, allocatable :: x_mu(:), y_mu(:)
+  integer :: n_events, n_sta, n_chains, i, j, io, id, ierr, rank
+  double precision :: dummy
+  double precision, parameter :: eps = epsilon(1.d0)
+  ! chain-major stacks handed to htm_chains_create
+  real(c_double), allocatable, target :: hx(:,:), hmu(:,:), hsg(:,:), hst(:,:)
+  real(c_double), allocatable, target :: tx(:,:), tmu(:,:), tsg(:,:), tst(:,:)
+  real(c_double), allocatable, target :: ax(:,:), amu(:,:), asg(:,:), ast(:,:)
+  real(c_double), allocatable, target :: vx(:), vmu(:), vsg(:), vst(:), qx(:), qmu(:), qsg(:), qst(:), temps(:)
+  integer(c_int32_t), allocatable, target :: hpt(:,:), tpt(:,:), apt(:,:), vpt(:), qpt(:)
+
+  rank = 0
+  if (command_argument_count() /= 1) error stop "USAGE: hypo_tremor_mcmc [parameter file]"
+  call get_command_argument(1, param_file)
+  call para%load(trim(param_file), verb=.true.)
+  if (para%n_procs /= 1) then
+     write(*, *) "ERROR: n_procs in parameter file must be equal to that is given in the command line"
+     write(*, *) "       (this program drives one GPU; use the multi-rank launcher for n_procs > 1)"
+     stop 1
+  end if
+  call rng_seed([5551111, 453222, 4444431, 6765], rank)
+
+  ! events
+  allocate(win_id(0))
+  open(newunit=io, file="selected_win.dat", status="old", action="read", iostat=ierr)
+  if (ierr /= 0) error stop "cannot open selected_win.dat"
+  do
+     read(io, *, iostat=ierr) id, dummy
+     if (ierr == iostat_end) exit
+     win_id = [win_id, id]
+  end do
+  close(io)
+  n_events = size(win_id)
+  n_sta = para%n_stations
+  n_chains = para%n_chains
+
+  obs = obs_data(win_id=win_id, n_sta=n_sta, sta_x=para%sta_x, sta_y=para%sta_y, verb=.true.)
+  allocate(x_mu(n_events), y_mu(n_events))
+  call obs%make_initial_guess(x_mu, y_mu)
+  fwd = forward(n_sta=n_sta, n_events=n_events, sta_x=para%sta_x, sta_y=para%sta_y, sta_z=para%sta_z, &
+       & obs=obs, use_amp=para%use_amp, use_time=para%use_time)
+
+  allocate(hx(3*n_events, n_chains), hmu(3*n_events, n_chains), hsg(3*n_events, n_chains), hst(3*n_events, n_chains))
+  allocate(hpt(3*n_events, n_chains))
+  allocate(tx(n_sta, n_chains), tmu(n_sta, n_chains), tsg(n_sta, n_chains), tst(n_sta, n_chains), tpt(n_sta, n_chains))
+  allocate(ax(n_sta, n_chains), amu(n_sta, n_chains), asg(n_sta, n_chains), ast(n_sta, n_chains), apt(n_sta, n_chains))
+  allocate(vx(n_chains), vmu(n_chains), vsg(n_chains), vst(n_chains), vpt(n_chains))
+  allocate(qx(n_chains), qmu(n_chains), qsg(n_chains), qst(n_chains), qpt(n_chains), temps(n_chains))
+
+  do j = 1, n_chains
+     t_corr = model(nx=n_sta)
+     if (para%solve_t_corr) then
+        do i = 1, n_sta
+           call t_corr%set_prior(i=i, mu=para%prior_t_corr, sigma=para%prior_width_t_corr)
+           call t_corr%set_perturb(i=i, step_size=para%step_size_t_corr)
+        end do
+        call t_corr%generate_model()
+     else
+        t_corr%x = para%prior_t_corr
+     end if
+     a_corr = model(nx=n_sta)
+     if (para%solve_a_corr) then
+        do i = 1, n_sta
+           call a_corr%set_prior(i=i, mu=para%prior_a_corr, sigma=para%prior_width_a_corr)
+           call a_corr%set_perturb(i=i, step_size=para%step_size_a_corr)
+        end do
+        call a_corr%generate_model()
+     else
+        a_corr%x = para%prior_a_corr
+     end if
+     hypo = model(nx=3*n_events)
+     do i = 1, n_events
+        call hypo%set_prior(i=3*i-2, mu=x_mu(i), sigma=para%prior_width_xy)
+        call hypo%set_prior(i=3*i-1, mu=y_mu(i), sigma=para%prior_width_xy)
+        call hypo%set_prior(i=3*i, mu=para%prior_z, sigma=para%prior_width_z, prior_type=1)
+        call hypo%set_perturb(i=3*i-2, step_size=para%step_size_xy)
+        call hypo%set_perturb(i=3*i-1, step_size=para%step_size_xy)
+        call hypo%set_perturb(i=3*i, step_size=para%step_size_z)
+     end do
+     call hypo%generate_model()
+     vs = model(nx=1)
+     call vs%set_prior(i=1, mu=para%prior_vs, sigma=para%prior_width_vs)
+     call vs%set_perturb(i=1, step_size=para%step_size_vs)
+     call vs%set_x(1, para%prior_vs)
+     qs = model(nx=1)
+     call qs%set_prior(i=1, mu=para%prior_qs, sigma=para%prior_width_qs)
+     call qs%set_perturb(i=1, step_size=para%step_size_qs)
+     call qs%set_x(1, para%prior_qs)
+
+     hx(:, j) = hypo%x;  hmu(:, j) = hypo%mu;  hsg(:, j) = hypo%sigma;  hst(:, j) = hypo%step_size
+     hpt(:, j) = int(hypo%prior_type, c_int32_t)
+     tx(:, j) = t_corr%x; tmu(:, j) = t_corr%mu; tsg(:, j) = t_corr%sigma; tst(:, j) = t_corr%step_size
+     tpt(:, j) = int(t_corr%prior_type, c_int32_t)
+     ax(:, j) = a_corr%x; amu(:, j) = a_corr%mu; asg(:, j) = a_corr%sigma; ast(:, j) = a_corr%step_size
+     apt(:, j) = int(a_corr%prior_type, c_int32_t)
+     vx(j) = vs%x(1); vmu(j) = vs%mu(1); vsg(j) = vs%sigma(1); vst(j) = vs%step_size(1); vpt(j) = 0
+     qx(j) = qs%x(1); qmu(j) = qs%mu(1); qsg(j) = qs%sigma(1); qst(j) = qs%step_size(1); qpt(j) = 0
+     if (j <= para%n_cool) then
+        temps(j) = 1.d0
+     else
+        temps(j) = exp((rand_u() * (1.d0 - eps) + eps) * log(para%temp_high))
+     end if
+  end do
+
+  init%n_chains = n_chains; init%n_procs = 1; init%rank = rank
+  init%hypo = pack_model(hx, hmu, hsg, hst, hpt)
+  init%t_corr = pack_model(tx, tmu, tsg, tst, tpt)
+  init%a_corr = pack_model(ax, amu, asg, ast, apt)
+  init%vs%x = c_loc(vx); init%vs%mu = c_loc(vmu); init%vs%sigma = c_loc(vsg); init%vs%step_size = c_loc(vst)
+  init%vs%prior_type = c_loc(vpt)
+  init%qs%x = c_loc(qx); init%qs%mu = c_loc(qmu); init%qs%sigma = c_loc(qsg); init%qs%step_size = c_loc(qst)
+  init%qs%prior_type = c_loc(qpt)
+  init%temp = c_loc(temps)
+  init%solve_vs = merge(1, 0, para%solve_vs); init%solve_t_corr = merge(1, 0, para%solve_t_corr)
+  init%solve_qs = merge(1, 0, para%solve_qs); init%solve_a_corr = merge(1, 0, para%solve_a_corr)
+  init%rng_state = rng_state()
+  init%n_burn = para%n_burn; init%n_interval = para%n_interval
+  call check(htm_chains_create(fwd%c_handle(), init, chains), "htm_chains_create")
+
+  print *, "start MCMC"
+  do i = 0, para%n_iter - 1, 1000
+     call check(htm_chains_run(chains, int(min(1000, para%n_iter - i), c_int)), "htm_chains_run")
+     call summary(min(i + 1000, para%n_iter))
+  end do
+
+  call write_outputs()
+  call check(htm_chains_destroy(chains), "htm_chains_destroy")
+
+contains
+
+  subroutine check(rc, where)
+    integer(c_int), intent(in) :: rc
+    character(*), intent(in) :: where
+    if (rc /= 0) then
+       write(0, '(4A)') "ERROR: ", where, ": ", htm_error_message()
+       error stop "libhtm_hip call failed"
+    end if
+  end subroutine check
+
+  function pack_model(x, mu, sg, st, pt) result(m)
+    real(c_double), intent(in), target :: x(:,:), mu(:,:), sg(:,:), st(:,:)
+    integer(c_int32_t), intent(in), target :: pt(:,:)
+    type(htm_model_init) :: m
+    m%x = c_loc(x); m%mu = c_loc(mu); m%sigma = c_loc(sg); m%step_size = c_loc(st); m%prior_type = c_loc(pt)
+  end function pack_model
+
+  !> the reference prints chain 1 every 1000 iterations (src/cls_mcmc.f90:230-237)
+  subroutine summary(it)
+    integer, intent(in) :: it
+    real(c_double) :: h(3*n_events), tc(n_sta), ac(n_sta), v, q, t, l
+    integer(c_int32_t) :: np(7), na(7)
+    call check(htm_chains_get_state(chains, 0_c_int, h, tc, v, ac, q, t, l, np, na), "htm_chains_get_state")
+    write(*, *) "Iteration    : ", it, "/", para%n_iter
+    write(*, *) "Likelihood   : ", l
+    write(*, *)
+  end subroutine summary
+
+  !> hypo.RR.out, t_corr.RR.out, vs.RR.out, a_corr.RR.out, qs.RR.out, likelihoodRR.out (stream access,
+  !> unformatted, src/hypo_tremor_mcmc.f90:216-233,:270-280) and proposal_count.txt (src/cls_parallel.f90:270-278)
+  subroutine write_outputs()
+    integer(c_int) :: n, k
+    integer(c_int32_t), allocatable :: it(:), ch(:)
+    real(c_double), allocatable :: lk(:)
+    integer(c_int32_t) :: it1, ch1, np(7), na(7), np_sum(7), na_sum(7)
+    real(c_double) :: h(3*n_events), tc(n_sta), ac(n_sta), v, q, t, l
+    integer :: io_h, io_t, io_v, io_a, io_q, io_l, c
+    character(5), parameter :: label(7) = [character(5) :: "vs", "t_corr", "qs", "a_corr", "x", "y", "z"]
+    character(32) :: f
+
+    write(f, '(A,I2.2,A)') "likelihood", rank, ".out"
+    open(newunit=io_l, file=trim(f), status="replace", access="stream", form="unformatted")
+    call check(htm_chains_lik_count(chains, n), "htm_chains_lik_count")
+    allocate(it(n), ch(n), lk(n))
+    if (n > 0) call check(htm_chains_lik_read(chains, it, ch, lk), "htm_chains_lik_read")
+    do k = 1, n
+       write(io_l) int(it(k)), lk(k)
+    end do
+    close(io_l)
+
+    write(f, '(A,I2.2,A)') "hypo.", rank, ".out";   open(newunit=io_h, file=trim(f), status="replace", access="stream", form="unformatted")
+    write(f, '(A,I2.2,A)') "t_corr.", rank, ".out"; open(newunit=io_t, file=trim(f), status="replace", access="stream", form="unformatted")
+    write(f, '(A,I2.2,A)') "vs.", rank, ".out";     open(newunit=io_v, file=trim(f), status="replace", access="stream", form="unformatted")
+    write(f, '(A,I2.2,A)') "a_corr.", rank, ".out"; open(newunit=io_a, file=trim(f), status="replace", access="stream", form="unformatted")
+    write(f, '(A,I2.2,A)') "qs.", rank, ".out";     open(newunit=io_q, file=trim(f), status="replace", access="stream", form="unformatted")
+    call check(htm_chains_sample_count(chains, n), "htm_chains_sample_count")
+    do k = 0, n - 1
+       call check(htm_chains_sample_read(chains, k, it1, ch1, v, q, h, tc, ac), "htm_chains_sample_read")
+       write(io_v) int(it1), v
+       write(io_h) int(it1), h
+       write(io_t) int(it1), tc
+       write(io_q) int(it1), q
+       write(io_a) int(it1), ac
+    end do
+    close(io_h); close(io_t); close(io_v); close(io_a); close(io_q)
+
+    np_sum = 0; na_sum = 0
+    do c = 0, n_chains - 1
+       call check(htm_chains_get_state(chains, int(c, c_int), h, tc, v, ac, q, t, l, np, na), "htm_chains_get_state")
+       np_sum = np_sum + np; na_sum = na_sum + na
+    end do
+    open(newunit=io_l, file="proposal_count.txt", status="unknown")
+    do c = 1, 7
+       write(io_l, '(A,2I10)') '"' // label(c) // '"', np_sum(c), na_sum(c)
+    end do
+    close(io_l)
+  end subroutine write_outputs
+
+end program hypo_tremor_mcmc_hip

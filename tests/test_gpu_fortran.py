@@ -1,0 +1,81 @@
+"""GPU parity of the Fortran host layer (hypotremormcmc_amd/fortran): the drop-in `module cls_forward`
+shim and the Fortran step-5 driver, both through ISO_C_BINDING onto the same C ABI.  Expected values are
+the reference's own outputs (golden fixtures)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from hypotremormcmc_amd import synth
+from tests.helpers import load_case, tf
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+BUILD = os.path.join(ROOT, "hypotremormcmc_amd", "fortran", "build")
+
+
+def _need(binary):
+    path = os.path.join(BUILD, binary)
+    if not os.path.exists(path):
+        pytest.fail(f"{path} missing: run `make -C hypotremormcmc_amd/fortran` (build() does)")
+    return path
+
+
+@pytest.mark.parametrize("name", ["c1", "missing", "timeonly"])
+def test_fortran_forward_shim_known_answers(name, tmp_path):
+    fx, data, params = load_case(name)
+    synth.write_dataset(str(tmp_path), data)
+    E, S = data.n_events, data.n_sta
+    n_cases = len(fx["probe_L"])
+    fl = lambda v: "T" if tf(v) else "F"
+    with open(tmp_path / "probe_in.txt", "w") as f:
+        f.write(f"{S} {E} {fl(params.get('use_time', 'T'))} {fl(params.get('use_amp', 'T'))} {n_cases}\n")
+        for arr in (data.sta_x, data.sta_y, data.sta_z):
+            f.write(" ".join("%.17g" % v for v in arr) + "\n")
+        for k in range(n_cases):
+            f.write(" ".join("%.17g" % v for v in fx["probe_in_hypo"][k]) + "\n")
+            f.write(" ".join("%.17g" % v for v in fx["probe_in_t_corr"][k]) + "\n")
+            f.write("%.17g\n" % fx["probe_in_vs"][k])
+            f.write(" ".join("%.17g" % v for v in fx["probe_in_a_corr"][k]) + "\n")
+            f.write("%.17g\n" % fx["probe_in_qs"][k])
+            f.write("%d\n" % int(fx["probe_in_evt_id"][k]))
+            f.write(" ".join("%.17g" % v for v in fx["probe_in_xyz"][k]) + "\n")
+    subprocess.run([_need("forward_probe")], cwd=tmp_path, check=True, timeout=300)
+    tok = [float(t) for t in open(tmp_path / "probe_out_hip.txt").read().split()]
+    L0 = np.array(tok[:3]); single = np.array(tok[3:3 + 2 * S]).reshape(S, 2); rest = np.array(tok[3 + 2 * S:]).reshape(-1, 3)
+    got = np.vstack([L0, rest])
+    np.testing.assert_allclose(got, fx["probe_L"], rtol=1e-12)
+    np.testing.assert_allclose(single[:, 0], fx["probe_t_syn_single"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(single[:, 1], fx["probe_a_syn_single"], rtol=0, atol=1e-12)
+
+
+def _records(path, n_val):
+    dt = np.dtype([("iter", "<i4"), ("val", "<f8", (n_val,))])
+    if os.path.getsize(path) == 0:
+        return np.zeros(0, np.int32), np.zeros((0, n_val))
+    a = np.fromfile(path, dtype=dt)
+    return a["iter"].copy(), a["val"].reshape(-1, n_val).copy()
+
+
+@pytest.mark.parametrize("name", ["c2", "missing"])
+def test_fortran_driver_reproduces_reference_outputs(name, tmp_path):
+    """same CLI, parameter file, inputs and output files as the reference's hypo_tremor_mcmc"""
+    fx, data, params = load_case(name)
+    synth.write_dataset(str(tmp_path), data)
+    synth.write_param_file(str(tmp_path / "run.in"), **{k: v for k, v in params.items()})
+    subprocess.run([_need("hypo_tremor_mcmc_hip"), "run.in"], cwd=tmp_path, check=True, timeout=600,
+                   stdout=subprocess.DEVNULL)
+    E, S = data.n_events, data.n_sta
+    it, v = _records(tmp_path / "likelihood00.out", 1)
+    assert np.array_equal(it, fx["lik_iter_0"])
+    np.testing.assert_allclose(v[:, 0], fx["lik_0"], rtol=1e-9, atol=0)
+    for nm, nv in (("vs", 1), ("qs", 1), ("t_corr", S), ("a_corr", S), ("hypo", 3 * E)):
+        it, v = _records(tmp_path / f"{nm}.00.out", nv)
+        assert np.array_equal(it, fx[f"{nm}_iter_0"])
+        np.testing.assert_allclose(v, fx[f"{nm}_0"], rtol=1e-11, atol=1e-12)
+    rows = [ln.split('"') for ln in open(tmp_path / "proposal_count.txt")]
+    assert [r[1] for r in rows] == fx["count_labels"].tolist()
+    assert [int(r[2].split()[0]) for r in rows] == fx["n_propose"].tolist()
+    assert [int(r[2].split()[1]) for r in rows] == fx["n_accept"].tolist()

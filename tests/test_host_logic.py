@@ -96,3 +96,25 @@ def test_proposal_count_format(tmp_path):
     lines = p.read_text().splitlines()
     assert lines[0] == '"vs   "       984        50' and lines[1] == '"t_cor"       985       736'
     assert lines[4] == '"x    "     12041      9326'
+
+
+def test_fortran_host_layer_builds_and_fails_loudly_without_gpu(tmp_path):
+    """the Fortran shim + driver link against the C ABI; without a device they stop with the library's message"""
+    import ctypes as C
+    import subprocess
+
+    from hypotremormcmc_amd import _lib
+
+    fdir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hypotremormcmc_amd", "fortran")
+    subprocess.run(["make", "-C", fdir], check=True, stdout=subprocess.DEVNULL)
+    exe = os.path.join(fdir, "build", "hypo_tremor_mcmc_hip")
+    assert os.path.exists(exe) and os.path.exists(os.path.join(fdir, "build", "forward_probe"))
+    n = C.c_int(0)
+    if _lib.load().htm_device_count(C.byref(n)) == 0 and n.value > 0:
+        pytest.skip("a GPU is present")
+    d = synth.make_synthetic(3, 4, 0)
+    synth.write_dataset(str(tmp_path), d)
+    synth.write_param_file(str(tmp_path / "p.in"), n_procs=1, n_chains=2, n_iter=10)
+    r = subprocess.run([exe, "p.in"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0
+    assert "no HIP device" in (r.stderr + r.stdout) or "libhtm_hip" in (r.stderr + r.stdout)
