@@ -127,11 +127,20 @@ int launch_full(htm_forward *h, const FullJob &jb, int gy)
 {
     dim3 grid(h->n_wg, gy), block(256);
     const size_t smem = 0;
-    switch (h->nch) {
-    case 1: hipLaunchKernelGGL(k_full<1>, grid, block, smem, h->stream, h->dev, jb); break;
-    case 2: hipLaunchKernelGGL(k_full<2>, grid, block, smem, h->stream, h->dev, jb); break;
-    case 4: hipLaunchKernelGGL(k_full<4>, grid, block, smem, h->stream, h->dev, jb); break;
-    default: hipLaunchKernelGGL(k_full<0>, grid, block, smem, h->stream, h->dev, jb); break;
+    if (jb.desc) {
+        switch (h->nch) {
+        case 1: hipLaunchKernelGGL((k_full<1, false>), grid, block, smem, h->stream, h->dev, jb); break;
+        case 2: hipLaunchKernelGGL((k_full<2, false>), grid, block, smem, h->stream, h->dev, jb); break;
+        case 4: hipLaunchKernelGGL((k_full<4, false>), grid, block, smem, h->stream, h->dev, jb); break;
+        default: hipLaunchKernelGGL((k_full<0, false>), grid, block, smem, h->stream, h->dev, jb); break;
+        }
+    } else {
+        switch (h->nch) {
+        case 1: hipLaunchKernelGGL((k_full<1, true>), grid, block, smem, h->stream, h->dev, jb); break;
+        case 2: hipLaunchKernelGGL((k_full<2, true>), grid, block, smem, h->stream, h->dev, jb); break;
+        case 4: hipLaunchKernelGGL((k_full<4, true>), grid, block, smem, h->stream, h->dev, jb); break;
+        default: hipLaunchKernelGGL((k_full<0, true>), grid, block, smem, h->stream, h->dev, jb); break;
+        }
     }
     HIPCHK(hipGetLastError());
     return HTM_OK;

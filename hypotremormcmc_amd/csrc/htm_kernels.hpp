@@ -31,7 +31,9 @@ struct FullJob {
 // lane <-> station; each lane keeps its station's coordinates and corrections in registers; the four
 // observation streams are read with coalesced 512-B wave loads.  Output: one partial sum per workgroup,
 // reduced in a fixed order by the consumer (deterministic).
-template <int NCH>
+// BATCH only gives the two launch shapes distinct kernel names (profilers list them separately):
+// false = work order from k_step inside the MCMC loop, true = n_models stacked models.
+template <int NCH, bool BATCH>
 __global__ __launch_bounds__(256) void k_full(FwdDev f, FullJob jb)
 {
     __shared__ double s_red[4];
