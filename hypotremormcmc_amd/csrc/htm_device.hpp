@@ -302,6 +302,15 @@ struct FullDesc {
     FullEntry e[kMaxChains];
 };
 
+// Hand-shake words between the chain master (block 0) and the full-evaluation workers (blocks 1..W) of one
+// k_mcmc launch.  Every word is polled / updated with agent-scope accesses only and sits on its own 128-B line.
+struct PSync {
+    unsigned long long arrive; char p0[120];   // ticket counter: launch index = ticket / (1 + W)
+    unsigned long long job;    char p1[120];   // (launch << 32) | number of jobs published in that launch
+    unsigned long long done;   char p2[120];   // worker blocks that finished a job, ever
+    unsigned long long quit;   char p3[120];   // launches whose master has finished
+};
+
 struct Ctrl {
     int iter_done, iter_target, stage, n_full;
     int err, stop, n_lik, n_smp;
@@ -346,6 +355,8 @@ struct ChainsDev {
     int32_t *smp_iter, *smp_chain; double *smp_data;   // [cap_smp][3E + 2S + 2]
     int32_t *slog_i; double *slog_d;
     double *swap_rec;                // [4 + 2*n_chains] this rank's record (8-byte words)
+    PSync *ps;                       // persistent-worker hand-shake (k_mcmc)
+    int n_workers;                   // worker blocks of a k_mcmc launch
     StreamDev stream;
     unsigned long long *stamps;      // diagnostic builds (-DHTM_STAMPS) only, else nullptr
 };

@@ -117,6 +117,8 @@ struct htm_chains {
     long long n_raw = 0, n_tr = 0, n_rec = 0, n_hop = 0;   // positions produced per stage (host view)
     long long spos_lo = 0, spos_hi = 0;        // bounds on the consumed position since the last sync
     const double *pending_gathered = nullptr;  // lock-step: records whose swap the next k_step applies
+    bool persist = true;                       // k_mcmc (master + resident full-evaluation workers) vs k_step + k_full
+    ChainsDev dev_np{};                        // view for the non-persistent kernels (partial sums per k_full tile)
     uint32_t init_state[4] = {0, 0, 0, 0};     // mod_random state at stream position 0
     double th[4] = {0, 0, 0, 0};
 };
@@ -146,14 +148,27 @@ int launch_full(htm_forward *h, const FullJob &jb, int gy)
     return HTM_OK;
 }
 
+int launch_mcmc(htm_chains *hc, int mode, int target, const double *gathered)
+{
+    htm_forward *h = hc->fwd;
+    dim3 grid(1 + hc->dev.n_workers), block(512);
+    switch (h->nch) {
+    case 1: hipLaunchKernelGGL(k_mcmc<1>, grid, block, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax); break;
+    case 2: hipLaunchKernelGGL(k_mcmc<2>, grid, block, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax); break;
+    default: hipLaunchKernelGGL(k_mcmc<0>, grid, block, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax); break;
+    }
+    HIPCHK(hipGetLastError());
+    return HTM_OK;
+}
+
 int launch_step(htm_chains *hc, int mode, int target, const double *gathered)
 {
     htm_forward *h = hc->fwd;
     dim3 grid(1), block(64 * hc->nw);
     switch (h->nch) {
-    case 1: hipLaunchKernelGGL(k_step<1>, grid, block, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax); break;
-    case 2: hipLaunchKernelGGL(k_step<2>, grid, block, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax); break;
-    default: hipLaunchKernelGGL(k_step<0>, grid, block, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax); break;
+    case 1: hipLaunchKernelGGL(k_step<1>, grid, block, hc->step_smem, h->stream, h->dev, hc->dev_np, mode, target, gathered, hc->ring_size, hc->wmax); break;
+    case 2: hipLaunchKernelGGL(k_step<2>, grid, block, hc->step_smem, h->stream, h->dev, hc->dev_np, mode, target, gathered, hc->ring_size, hc->wmax); break;
+    default: hipLaunchKernelGGL(k_step<0>, grid, block, hc->step_smem, h->stream, h->dev, hc->dev_np, mode, target, gathered, hc->ring_size, hc->wmax); break;
     }
     HIPCHK(hipGetLastError());
     return HTM_OK;
@@ -193,7 +208,7 @@ int stream_produce(htm_chains *hc, long long n)
 FullJob chain_full_job(htm_chains *hc)
 {
     FullJob jb{};
-    const ChainsDev &d = hc->dev;
+    const ChainsDev &d = hc->dev_np;
     jb.hypo = d.hypo.x; jb.hypo_stride = d.hypo.nx;
     jb.tc = d.tc.x; jb.tc_stride = d.S;
     jb.ac = d.ac.x; jb.ac_stride = d.S;
@@ -559,7 +574,14 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
     if ((rc = dev_alloc(hc->pool, &d.prop, nc))) return cleanup(rc);
     if ((rc = dev_alloc(hc->pool, &d.desc, 1))) return cleanup(rc);
     HIPCHK(hipMemset(d.desc, 0, sizeof(FullDesc)));
-    if ((rc = dev_alloc(hc->pool, &d.partial, (size_t)nc * h->n_wg))) return cleanup(rc);
+    d.n_workers = std::max(1, std::min(240, (h->E + 7) / 8));
+    if ((rc = dev_alloc(hc->pool, &d.partial, (size_t)nc * std::max(h->n_wg, d.n_workers)))) return cleanup(rc);
+    if ((rc = dev_alloc(hc->pool, &d.ps, 1))) return cleanup(rc);
+    HIPCHK(hipMemset(d.ps, 0, sizeof(PSync)));
+    {
+        const char *env = getenv("HTM_PERSIST");
+        hc->persist = !(env && env[0] == '0');
+    }
     if ((rc = dev_alloc(hc->pool, &d.swap_rec, 4 + 2 * (size_t)nc))) return cleanup(rc);
     HIPCHK(hipMemset(d.prop, 0, nc * sizeof(Proposal)));
     HIPCHK(hipMemset(d.swap_rec, 0, (4 + 2 * (size_t)nc) * sizeof(double)));
@@ -632,6 +654,13 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
     }
     if (hipEventCreate(&hc->ev0) != hipSuccess || hipEventCreate(&hc->ev1) != hipSuccess)
         return cleanup(fail(HTM_EHIP, "hipEventCreate failed"));
+    hc->dev_np = hc->dev;                       // same state; partial sums laid out per k_full tile
+    hc->dev.n_wg = hc->dev.n_workers;           // persistent kernel: one partial per worker block
+    if (hc->step_smem < 1024) hc->step_smem = 1024;
+    if (hc->step_smem > 48 * 1024) {
+        const void *fn = h->nch == 1 ? (const void *)k_mcmc<1> : h->nch == 2 ? (const void *)k_mcmc<2> : (const void *)k_mcmc<0>;
+        HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hc->step_smem));
+    }
     // first stretch of the random stream (synchronous)
     if ((rc = stream_produce(hc, 1 << 16))) return cleanup(rc);
     HIPCHK(hipStreamSynchronize(hc->side));
@@ -681,6 +710,7 @@ static int ctrl_error(const htm_chains *hc)
     case -4: return fail(HTM_ESTATE, "device RNG window exhausted (iteration %d)", hc->h_ctrl.iter_done + 1);
     case -5: return fail(HTM_EOVERFLOW, "record buffer overflow in lock-step mode: call htm_chains_drain more often");
     case -6: return fail(HTM_EDESYNC, "swap records of the ranks carry different iteration numbers");
+    case -8: return fail(HTM_ESTATE, "persistent workers did not answer within 5 s (iteration %d)", hc->h_ctrl.iter_done + 1);
     case -7: return fail(HTM_ESTATE, "random stream underrun in lock-step mode (iteration %d)", hc->h_ctrl.iter_done + 1);
     default: return fail(HTM_ESTATE, "device error flag %d", hc->h_ctrl.err);
     }
@@ -743,6 +773,42 @@ static int build_graph(htm_chains *hc)
     return rc;
 }
 
+// Single-rank main loop on the persistent kernel: one k_mcmc launch runs until the target, a full record
+// buffer or the end of the produced random stream; no graph, no per-hand-over launches.
+static int run_persistent(htm_chains *hc, int n_iter)
+{
+    htm_forward *h = hc->fwd;
+    int rc;
+    hc->h_target = hc->h_ctrl.iter_done + n_iter;
+    hc->run_full0 = hc->h_ctrl.n_full_evals; hc->run_part0 = hc->h_ctrl.n_partial_evals;
+    hc->last_graph_launches = 0;
+    HIPCHK(hipEventRecord(hc->ev0, h->stream));
+    while (hc->h_ctrl.iter_done < hc->h_target) {
+        // a launch may run as far as the produced stream reaches
+        const long long fed = (hc->n_hop - hc->h_ctrl.spos) / (6 * hc->dev.n_chains + 4) - 2;
+        const int target = (int)std::min<long long>(hc->h_target, hc->h_ctrl.iter_done + std::max<long long>(1, fed));
+        if ((rc = launch_mcmc(hc, MODE_RUN, target, nullptr))) return rc;
+        hc->last_graph_launches += 1;
+        // keep the random stream about half a ring ahead (asynchronous, side stream), while the launch runs
+        {
+            const long long ahead = hc->n_hop - hc->h_ctrl.spos;
+            if (ahead < hc->cap / 2 && (rc = stream_produce(hc, std::min<long long>(hc->cap / 2 - ahead + 4096, 1 << 18)))) return rc;
+        }
+        if ((rc = read_ctrl(hc))) return rc;
+        if ((rc = ctrl_error(hc))) return rc;
+        if (hc->h_ctrl.stop == 2) HIPCHK(hipStreamSynchronize(hc->side));
+        if (hc->h_ctrl.stop) { if ((rc = drain_records(hc))) return rc; }
+    }
+    HIPCHK(hipEventRecord(hc->ev1, h->stream));
+    HIPCHK(hipEventSynchronize(hc->ev1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, hc->ev0, hc->ev1));
+    hc->last_device_us = 1000.0 * ms;
+    hc->last_full = hc->h_ctrl.n_full_evals - hc->run_full0;
+    hc->last_part = hc->h_ctrl.n_partial_evals - hc->run_part0;
+    return drain_records(hc);
+}
+
 int htm_chains_run(htm_chains *hc, int n_iter)
 {
     if (!hc) return fail(HTM_EINVAL, "NULL handle");
@@ -754,6 +820,7 @@ int htm_chains_run(htm_chains *hc, int n_iter)
     int rc = read_ctrl(hc);
     if (rc) return rc;
     if (hc->h_ctrl.stage == ST_WAIT_SWAP) return fail(HTM_ESTATE, "a lock-step iteration is in flight");
+    if (hc->persist && hc->h_ctrl.stage == ST_IDLE) return run_persistent(hc, n_iter);
     if ((rc = build_graph(hc))) return rc;
     hc->h_target = hc->h_ctrl.iter_done + n_iter;
     HIPCHK(hipMemcpyAsync(&hc->dev.ctrl->iter_target, &hc->h_target, sizeof(int), hipMemcpyHostToDevice, h->stream));
@@ -859,6 +926,11 @@ int htm_chains_step_begin(htm_chains *hc)
         hc->spos_hi += hc->wmax;
         if ((rc = stream_produce(hc, 1 << 16))) return rc;
         HIPCHK(hipStreamWaitEvent(h->stream, hc->ev_side, 0));
+    }
+    if (hc->persist) {       // whole iteration (full evaluations included) in one launch
+        rc = launch_mcmc(hc, MODE_ADVANCE, hc->h_target, hc->pending_gathered);
+        hc->pending_gathered = nullptr;
+        return rc;
     }
     rc = launch_step(hc, MODE_ADVANCE, hc->h_target, hc->pending_gathered);   // applies the previous swap first
     hc->pending_gathered = nullptr;
@@ -1009,6 +1081,7 @@ int htm_chains_enable_steplog(htm_chains *hc, int capacity)
     // the graph bakes ChainsDev by value: rebuild it with the new pointers
     if (hc->gexec) { (void)hipGraphExecDestroy(hc->gexec); hc->gexec = nullptr; }
     if (hc->graph) { (void)hipGraphDestroy(hc->graph); hc->graph = nullptr; }
+    hc->dev_np.slog_i = hc->dev.slog_i; hc->dev_np.slog_d = hc->dev.slog_d;
     hc->h_ctrl.slog_n = 0; hc->h_ctrl.slog_cap = capacity;
     HIPCHK(hipMemcpy(&hc->dev.ctrl->slog_n, &hc->h_ctrl.slog_n, 2 * sizeof(int), hipMemcpyHostToDevice));
     return HTM_OK;

@@ -32,6 +32,8 @@ struct StepShared {
     int np[kMaxChains * 7], na[kMaxChains * 7];   // proposal / acceptance counters of this launch
     int sw_do, sw_c1, sw_c2;      // swap decided between the barriers; applied by the waves owning the chains
     double sw_T1, sw_T2;          // new temperatures of chains sw_c1 / sw_c2
+    unsigned long long done_base; // PSync::done when this launch started
+    int jobs;                     // full-evaluation jobs published in this launch
     long long origin;             // absolute stream position of relative position 0 (= spos at launch)
     int avail;                    // the produced stream covers relative positions < avail
     int fill;                     // the LDS ring holds relative positions < fill
@@ -136,6 +138,16 @@ __device__ __forceinline__ int opaque_zero()
 }
 __device__ __forceinline__ double ld_state(const double *p, int vz) { return p[vz]; }
 
+// agent-scope relaxed accesses: sc1 write-through stores / L1-bypassing loads (MI355X_MICROARCH.md,
+// inter-workgroup visibility).  Used for everything another workgroup of the same launch reads or writes.
+__device__ __forceinline__ void st_agent(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_agent(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int ld_agent(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 __device__ __forceinline__ bool metropolis(double L_new, double L_cur, double T, double lpr, double r,
                                            double logr)
 {
@@ -234,7 +246,7 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
         sh.start[c] = p; sh.cnt[c] = cnt;
         if (cool) sh.np[c * 7 + type - 1] += 1;                 // cls_mcmc.f90:186-189
         if (acc) {                                              // :207-219
-            Mo.x[o] = x_new;
+            st_agent(Mo.x + o, x_new);
             sh.L[c] = L_new;
             cs.L[c] = L_new;
             if (cool) sh.na[c * 7 + type - 1] += 1;
@@ -251,7 +263,7 @@ __device__ __forceinline__ void undo_chain(const ChainsDev &cs, StepShared &sh, 
     if (pr.cool) sh.np[c * 7 + pr.type - 1] -= 1;
     if (pr.accepted) {
         const ModelDev Mo = pick_model(cs, pr.type);
-        Mo.x[(size_t)c * Mo.nx + pr.idx] = pr.x_old;
+        st_agent(Mo.x + (size_t)c * Mo.nx + pr.idx, pr.x_old);
         sh.L[c] = pr.L_old;
         cs.L[c] = pr.L_old;
         if (pr.cool) sh.na[c * 7 + pr.type - 1] -= 1;
@@ -430,9 +442,13 @@ __device__ __forceinline__ void apply_swap(const ChainsDev &cs, StepShared &sh, 
 #define STAMP(k) do { } while (0)
 #endif
 
-template <int NCH>
-__global__ __launch_bounds__(512) void k_step(FwdDev f, ChainsDev cs, int mode, int target_arg,
-                                               const double *gathered, int ring_size, int wmax)
+// PERSIST = true: this is block 0 of a k_mcmc launch; full evaluations are handed to the worker blocks of the
+// same launch through PSync (no kernel exit).  PERSIST = false: the kernel exits at a hand-over and k_full runs
+// as its own launch (fallback path, also used for profiling the two stages separately).
+template <int NCH, bool PERSIST>
+__device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, int mode, int target_arg,
+                                          const double *gathered, int ring_size, int wmax,
+                                          unsigned long long launch)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     StepShared &sh = *reinterpret_cast<StepShared *>(smem);
@@ -470,6 +486,8 @@ __global__ __launch_bounds__(512) void k_step(FwdDev f, ChainsDev cs, int mode, 
         const long long av = he - sh.c.spos;
         sh.avail = av > (1 << 30) ? (1 << 30) : (int)av;
         sh.fill = 0; sh.base = 0; sh.redo = -1; sh.sw_do = 0; sh.catchup = 0;
+        sh.jobs = 0;
+        if constexpr (PERSIST) sh.done_base = ld_agent(&cs.ps->done);
     }
     for (int j = tid; j < f.S; j += blockDim.x) { s_sx[j] = f.sx[j]; s_sy[j] = f.sy[j]; s_sz[j] = f.sz[j]; }
     for (int c = tid; c < nc; c += blockDim.x) { sh.temp[c] = cs.temp[c]; sh.L[c] = cs.L[c]; }
@@ -513,7 +531,7 @@ __global__ __launch_bounds__(512) void k_step(FwdDev f, ChainsDev cs, int mode, 
                 pr.accepted = metropolis(pr.L_new, sh.L[c], sh.temp[c], pr.lpr, pr.r_judge, pr.logr_judge) ? 1 : 0;
                 if (lane == 0 && pr.accepted) {                // cls_mcmc.f90:207-219
                     const ModelDev Mo = pick_model(cs, pr.type);
-                    Mo.x[(size_t)c * Mo.nx + pr.idx] = pr.x_new;
+                    st_agent(Mo.x + (size_t)c * Mo.nx + pr.idx, pr.x_new);
                     sh.L[c] = pr.L_new;
                     cs.L[c] = pr.L_new;
                     if (pr.cool) sh.na[c * 7 + pr.type - 1] += 1;
@@ -594,12 +612,13 @@ __global__ __launch_bounds__(512) void k_step(FwdDev f, ChainsDev cs, int mode, 
                             if (in && ((v.mf >> lane) & 1ull)) {            // k_full's work order, chain order
                                 const Proposal &pr = sh.prop[lane];
                                 const int vz = opaque_zero();
-                                FullEntry en;
-                                en.chain = lane; en.type = pr.type; en.idx = pr.idx; en.pad = 0; en.x_new = pr.x_new;
-                                en.beta = pr.type == 1 ? pr.x_new : ld_state(cs.vs.x + lane, vz);
-                                en.q = pr.type == 3 ? pr.x_new : ld_state(cs.qs.x + lane, vz);
-                                cs.desc->e[__popcll(v.mf & ((1ull << lane) - 1ull))] = en;
+                                FullEntry *en = &cs.desc->e[__popcll(v.mf & ((1ull << lane) - 1ull))];
+                                st_agent(&en->chain, lane); st_agent(&en->type, pr.type); st_agent(&en->idx, pr.idx);
+                                st_agent(&en->x_new, pr.x_new);
+                                st_agent(&en->beta, pr.type == 1 ? pr.x_new : ld_state(cs.vs.x + lane, vz));
+                                st_agent(&en->q, pr.type == 3 ? pr.x_new : ld_state(cs.qs.x + lane, vz));
                             }
+                            if (PERSIST && v.mf && lane == 0) st_agent(&cs.desc->n, (int)__popcll(v.mf));
                             if (lane == 0) {
                                 sh.c.swap_i1 = i1; sh.c.swap_i2 = i2; sh.c.swap_r = sr; sh.c.swap_logr = slr;
                                 sh.c.spos = sh.origin + pos;     // RNG commit: draws consumed so far
@@ -607,7 +626,7 @@ __global__ __launch_bounds__(512) void k_step(FwdDev f, ChainsDev cs, int mode, 
                                 sh.redo = -1;
                                 sh.catchup = (sh.fill < pos + wmax) ? 1 : 0;
                                 sh.c.n_full = __popcll(v.mf);
-                                if (v.mf) cs.desc->n = __popcll(v.mf);
+                                if (!PERSIST && v.mf) cs.desc->n = __popcll(v.mf);
                                 sh.c.n_full_evals += __popcll(v.mf);
                                 sh.c.n_partial_evals += __popcll(mp);
                                 if (v.mf == 0) {
@@ -631,10 +650,53 @@ __global__ __launch_bounds__(512) void k_step(FwdDev f, ChainsDev cs, int mode, 
                     if (lane == 0) undo_chain(cs, sh, c);
                 break;
             }
-            if (sh.c.n_full > 0) {               // hand over to k_full; the next launch resumes at P0
-                for (int c = tid; c < nc; c += blockDim.x) cs.prop[c] = sh.prop[c];
-                if (tid == 0) sh.c.stage = ST_WAIT_FULL;
-                break;
+            if (sh.c.n_full > 0) {
+                if constexpr (PERSIST) {
+                    // Publish the work order to the worker blocks of this launch.  Every wave of this workgroup
+                    // that stored chain state or order entries drains its stores first (a workgroup barrier
+                    // alone does not: same-CU waves share the L1), then ONE lane moves the job word.
+                    drain_vmem();
+                    __syncthreads();
+                    if (tid == 0) {
+                        sh.jobs += 1;
+                        st_agent(&cs.ps->job, (launch << 32) | (unsigned long long)sh.jobs);
+                        // ... and wait until every worker has delivered its partial sums (bounded: 5 s)
+                        const unsigned long long want = sh.done_base + (unsigned long long)cs.n_workers * sh.jobs;
+                        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz
+                        while (ld_agent(&cs.ps->done) < want) {
+                            __builtin_amdgcn_s_sleep(1);
+                            if (__builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) { sh.c.err = -8; break; }
+                        }
+                    }
+                    __syncthreads();
+                    if (sh.c.err) break;
+                    for (int c = wave; c < nc; c += NW) {            // judge + commit (cls_mcmc.f90:193-219)
+                        Proposal pr = sh.prop[c];
+                        if (pr.need_full) {
+                            double acc = 0.0;
+                            for (int k = lane; k < cs.n_wg; k += 64) acc += ld_agent(cs.partial + (size_t)c * cs.n_wg + k);
+                            pr.L_new = -wave_sum1(acc) - f.const_sum;      // cls_forward.f90:277-300
+                            pr.accepted = metropolis(pr.L_new, sh.L[c], sh.temp[c], pr.lpr, pr.r_judge, pr.logr_judge) ? 1 : 0;
+                            if (lane == 0) {
+                                if (pr.accepted) {
+                                    const ModelDev Mo = pick_model(cs, pr.type);
+                                    st_agent(Mo.x + (size_t)c * Mo.nx + pr.idx, pr.x_new);
+                                    sh.L[c] = pr.L_new;
+                                    cs.L[c] = pr.L_new;
+                                    if (pr.cool) sh.na[c * 7 + pr.type - 1] += 1;
+                                }
+                                sh.prop[c] = pr;
+                            }
+                        }
+                    }
+                    __syncthreads();
+                    resume = true;               // the iteration's end (records, swap, counters) follows
+                    continue;
+                } else {                         // hand over to k_full; the next launch resumes at P0
+                    for (int c = tid; c < nc; c += blockDim.x) cs.prop[c] = sh.prop[c];
+                    if (tid == 0) sh.c.stage = ST_WAIT_FULL;
+                    break;
+                }
             }
         } else {
             // the iteration that waited for k_full: only its end is left (decisions were taken in P0)
@@ -659,6 +721,129 @@ __global__ __launch_bounds__(512) void k_step(FwdDev f, ChainsDev cs, int mode, 
     }
     if (tid == 0) *cs.ctrl = sh.c;
     STAMP(5);
+}
+
+template <int NCH>
+__global__ __launch_bounds__(512) void k_step(FwdDev f, ChainsDev cs, int mode, int target_arg,
+                                               const double *gathered, int ring_size, int wmax)
+{
+    step_body<NCH, false>(f, cs, mode, target_arg, gathered, ring_size, wmax, 0ull);
+}
+
+// Worker block of a k_mcmc launch: waits for work orders of its own launch and evaluates its event tile of
+// every model in the order (same arithmetic as k_full: wave <-> event, lane <-> station).  Block w, wave v
+// take events (w*8 + v) + k * 8 * W.  One partial sum per (model, worker), written through (sc1), then one
+// agent-scope add on PSync::done.  Leaves when the master has finished (PSync::quit) or a bounded spin ends.
+template <int NCH>
+__device__ __forceinline__ void worker_body(const FwdDev &f, const ChainsDev &cs, unsigned long long launch)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *s_red = reinterpret_cast<double *>(smem);          // [8]
+    int *s_flag = reinterpret_cast<int *>(smem + 128);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = blockIdx.x - 1, W = cs.n_workers;
+    unsigned mine = 0;
+    for (;;) {
+        if (tid == 0) {
+            int flag = 0;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();          // 100 MHz
+            for (;;) {
+                const unsigned long long j = ld_agent(&cs.ps->job);
+                if ((j >> 32) == launch && (unsigned)(j & 0xffffffffull) > mine) { flag = 1; break; }
+                if (ld_agent(&cs.ps->quit) > launch) break;
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 3000000000ull) break;    // never spin forever (30 s)
+                __builtin_amdgcn_s_sleep(2);
+            }
+            *s_flag = flag;
+        }
+        __syncthreads();
+        if (*s_flag == 0) return;
+        mine += 1;
+        const int n = ld_agent(&cs.desc->n);
+        for (int k = 0; k < n; ++k) {
+            const FullEntry *en = &cs.desc->e[k];
+            const int m = ld_agent(&en->chain), type = ld_agent(&en->type), idx = ld_agent(&en->idx);
+            const double ov_val = ld_agent(&en->x_new), beta = ld_agent(&en->beta), q = ld_agent(&en->q);
+            int ov_kind = 0, ov_idx = -1, ov_evt = -1, ov_cmp = 0;
+            if (type == 2 || type == 4) { ov_kind = type; ov_idx = idx; }
+            else if (type >= 5) { ov_evt = idx / 3; ov_cmp = idx - 3 * ov_evt; }
+            const double *hyp = cs.hypo.x + (size_t)m * cs.hypo.nx;
+            const double *tc = cs.tc.x + (size_t)m * cs.S, *ac = cs.ac.x + (size_t)m * cs.S;
+            double lane_acc = 0.0;
+            if constexpr (NCH > 0) {
+                StaRegs<NCH> st;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {                 // chain state: agent-scope loads
+                    const int j = lane + 64 * c;
+                    const bool valid = j < f.S;
+                    st.sx[c] = valid ? f.sx[j] : 0.0; st.sy[c] = valid ? f.sy[j] : 0.0; st.sz[c] = valid ? f.sz[j] : 0.0;
+                    st.tc[c] = valid ? ld_agent(tc + j) : 0.0;
+                    st.ac[c] = valid ? ld_agent(ac + j) : 0.0;
+                    if (valid && ov_idx == j) { if (ov_kind == 2) st.tc[c] = ov_val; if (ov_kind == 4) st.ac[c] = ov_val; }
+                }
+                for (int ev = w * 8 + wave; ev < f.E; ev += 8 * W) {
+                    const bool ov = ev == ov_evt;
+                    const double hx = ld_agent(hyp + 3 * ev), hy = ld_agent(hyp + 3 * ev + 1), hz = ld_agent(hyp + 3 * ev + 2);
+                    const double px[1] = {(ov && ov_cmp == 0) ? ov_val : hx};
+                    const double py[1] = {(ov && ov_cmp == 1) ? ov_val : hy};
+                    const double pz[1] = {(ov && ov_cmp == 2) ? ov_val : hz};
+                    double out[1];
+                    ObsRegs<NCH> ob;
+                    load_obs_regs<NCH>(ob, f, ev, lane);
+                    event_misfit<NCH, 1>(f, ob, lane, st, px, py, pz, beta, q, out);
+                    lane_acc += out[0];
+                }
+            } else {
+                // generic station count: corrections are read through plain loads after an agent acquire
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                for (int ev = w * 8 + wave; ev < f.E; ev += 8 * W) {
+                    const bool ov = ev == ov_evt;
+                    const double hx = ld_agent(hyp + 3 * ev), hy = ld_agent(hyp + 3 * ev + 1), hz = ld_agent(hyp + 3 * ev + 2);
+                    const double px[1] = {(ov && ov_cmp == 0) ? ov_val : hx};
+                    const double py[1] = {(ov && ov_cmp == 1) ? ov_val : hy};
+                    const double pz[1] = {(ov && ov_cmp == 2) ? ov_val : hz};
+                    double out[1];
+                    event_misfit_generic<1>(f, ev, lane, f.sx, f.sy, f.sz, tc, ac, ov_kind, ov_idx, ov_val, px, py, pz,
+                                            beta, q, out);
+                    lane_acc += out[0];
+                }
+            }
+            const double tot = wave_sum1(lane_acc);
+            if (lane == 0) s_red[wave] = tot;
+            __syncthreads();
+            if (tid == 0)
+                st_agent(cs.partial + (size_t)m * cs.n_wg + w,
+                         ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) + ((s_red[4] + s_red[5]) + (s_red[6] + s_red[7])));
+            __syncthreads();
+        }
+        if (tid == 0) {
+            drain_vmem();                                       // partial sums have left before the count moves
+            __hip_atomic_fetch_add(&cs.ps->done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+    }
+}
+
+// One launch = the chain master (block 0) + W full-evaluation workers (blocks 1..W), all resident.
+template <int NCH>
+__global__ __launch_bounds__(512) void k_mcmc(FwdDev f, ChainsDev cs, int mode, int target_arg,
+                                               const double *gathered, int ring_size, int wmax)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long *s_ticket = reinterpret_cast<unsigned long long *>(smem);
+    if (threadIdx.x == 0)
+        *s_ticket = __hip_atomic_fetch_add(&cs.ps->arrive, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const unsigned long long launch = *s_ticket / (unsigned long long)(1 + cs.n_workers);
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        step_body<NCH, true>(f, cs, mode, target_arg, gathered, ring_size, wmax, launch);
+        __syncthreads();
+        if (threadIdx.x == 0) st_agent(&cs.ps->quit, launch + 1ull);    // releases the workers
+    } else {
+        worker_body<NCH>(f, cs, launch);
+    }
 }
 
 }  // namespace htm
