@@ -14,10 +14,9 @@ forward -> judge for every chain, then swap_temperature).  `value` = proposal st
 ranks; inputs are resident in HBM before the timed region starts.
 
 Besides the driver contract the JSON line carries
-  roofline      k_full, the batched full-evaluation kernel (moves >99 % of the path's algorithmic bytes),
-                timed live with HIP events on its stream; peak = 8 TB/s HBM3E
-  kernels       live HIP-event averages for both kernels of the loop (k_step dominates TIME at 8 chains/GPU:
-                the configuration is latency-bound)
+  roofline          the dominant kernel of the timed region (k_mcmc), HIP events on its stream; peak = 8 TB/s
+  roofline_batch64  the full-evaluation kernel on its own (64 stacked models per launch)
+  stages            the two stages of an iteration timed separately on the two-kernel path
   cpu_baseline  the CPU restatement (oracle/) timed on one host core on a bounded sample of the same workload
 """
 from __future__ import annotations
@@ -107,6 +106,11 @@ def cpu_baseline(params, data, seconds_target=10.0):
 
 
 def main():
+    # Native libraries (RCCL prints a version banner) write to fd 1; the contract is ONE JSON line on stdout.
+    # Everything else goes to stderr; the JSON is written to the saved stdout at the end.
+    real_stdout = os.dup(1)
+    sys.stdout.flush()
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20000)
@@ -139,7 +143,11 @@ def main():
 
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29533")
+            import socket
+
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
             dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
@@ -196,37 +204,43 @@ def main():
     if args.force_lockstep:
         out["config"]["parallelism"] = "lock-step path (one RCCL all-gather per iteration), 1 rank"
     if rank == 0 and world == 1 and not args.force_lockstep:
-        # ---- live per-kernel timings (HIP events on the kernels' stream), same chains, continuing the run
+        # ---- dominant kernel of the timed region: k_mcmc (chain master + resident full-evaluation workers).
+        # Its launches ARE the timed region; duration from the HIP events htm_chains_run records on the
+        # kernels' stream around them, algorithmic bytes from the evaluations they performed.
+        st = cs.last_run_stats()
+        persistent = os.environ.get("HTM_PERSIST", "1") != "0"
+        n_launch = max(1, st["graph_launches"])
+        bytes_region = st["full_evals"] * b_full + st["partial_evals"] * b_part
+        achieved = bytes_region / (st["device_us"] * 1e-6) / 1e9
+        out["roofline"] = {
+            "bound": "hbm",
+            "kernel": "k_mcmc<1> (propose + partial/full log-likelihood + judge + swap, persistent)" if persistent
+                      else "k_step<1> + k_full<1,false> (graph of the two-kernel path)",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "bytes_per_launch": bytes_region / n_launch, "avg_launch_us": st["device_us"] / n_launch,
+            "launches": n_launch, "full_evals": st["full_evals"], "partial_evals": st["partial_evals"],
+            "note": "algorithmic bytes = 2 074 568 B per full evaluation + 4 672 B per single-event partial update "
+                    "(SURVEY 8d); at 8 chains/GPU an iteration is a dependent chain of ~12 us that moves ~1.7 MB, "
+                    "so the workload is latency-bound, not HBM-bound (DESIGN.md 5); see roofline_batch64 for the "
+                    "full-evaluation kernel on its own",
+        }
+        # ---- the two stages timed separately (fallback two-kernel path, same arithmetic), HIP events per launch
         n_prof = min(4000, max(500, args.steps // 5))
         prof = cs.profile(n_prof)
         full_avg_us = prof["full_us"] / max(1, prof["full_launches"])
         step_avg_us = prof["step_us"] / max(1, prof["step_launches"])
-        evals_per_launch = prof["full_evals"] / max(1, prof["full_launches"])
-        bytes_per_launch = evals_per_launch * b_full
-        achieved = bytes_per_launch / (full_avg_us * 1e-6) / 1e9
-        out["roofline"] = {
-            "bound": "hbm", "kernel": "k_full<1,false> (full log-likelihood, launched from the MCMC loop)",
-            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
-            "bytes_per_launch": bytes_per_launch, "evals_per_launch": evals_per_launch,
-            "avg_launch_us": full_avg_us, "launches": prof["full_launches"],
-            "note": "algorithmic bytes = 2 074 568 B per full evaluation (SURVEY 8d) x evaluations per launch; a "
-                    "launch in the MCMC loop carries only the chains whose proposal needs a full evaluation "
-                    "(1.3 on average at 8 chains/GPU), so this launch shape is latency-bound; avg_launch_us is "
-                    "event-to-event and includes the dependent-launch boundary after k_step",
-        }
-        out["kernels"] = {
+        out["stages"] = {
             "k_step": {"avg_launch_us": step_avg_us, "launches": prof["step_launches"],
-                       "partial_evals": prof["partial_evals"],
-                       "algorithmic_bytes": prof["partial_evals"] * b_part},
+                       "partial_evals": prof["partial_evals"], "algorithmic_bytes": prof["partial_evals"] * b_part},
             "k_full": {"avg_launch_us": full_avg_us, "launches": prof["full_launches"],
-                       "full_evals": prof["full_evals"], "algorithmic_bytes": prof["full_evals"] * b_full},
+                       "full_evals": prof["full_evals"], "algorithmic_bytes": prof["full_evals"] * b_full,
+                       "achieved_GBps": prof["full_evals"] * b_full / max(1e-9, prof["full_us"] * 1e-6) / 1e9},
             "time_share_k_step": prof["step_us"] / max(1e-9, prof["step_us"] + prof["full_us"]),
             "iterations_profiled": n_prof,
+            "note": "two-kernel path (k_step exits at every hand-over, k_full is its own launch); event-to-event "
+                    "times include the dependent-launch boundary",
         }
-        # whole-loop algorithmic traffic of the timed region (steps/s x expected bytes per step)
-        st = cs.last_run_stats()
-        out["loop_algorithmic_GBps"] = None
         # ---- standalone batched full evaluation: 64 models resident in HBM, the kernel's own ceiling
         nb = 64
         g = torch.Generator(device="cpu").manual_seed(3)
@@ -241,13 +255,12 @@ def main():
         us = fwd.time_full_batch_dev(nb, hyp.data_ptr(), tc.data_ptr(), vs.data_ptr(), ac.data_ptr(),
                                      qs.data_ptr(), L.data_ptr(), reps=200)
         gbs = nb * b_full / (us * 1e-6) / 1e9
-        out["roofline_batch64"] = {"bound": "hbm", "kernel": "k_full<1,true> (same kernel, 64 stacked models per launch)",
+        out["roofline_batch64"] = {"bound": "hbm", "kernel": "k_full<1,true> (64 stacked models per launch)",
                                    "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                    "traffic": None, "bytes_per_launch": nb * b_full, "evals_per_launch": nb,
                                    "avg_launch_us": us, "evals_per_s": nb / (us * 1e-6),
                                    "note": "200 back-to-back launches of k_full<1,true> + k_sum_partials bracketed by "
                                            "HIP events; inputs resident in HBM"}
-        out["loop_algorithmic_GBps"] = (st["full_evals"] * b_full + st["partial_evals"] * b_part) / dt / 1e9
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dict(params, n_procs=1), data)
     elif rank == 0:
@@ -258,7 +271,7 @@ def main():
                            "note": "N > 1: steps/s x 211 662 B expected algorithmic bytes per step / n_gpus; "
                                    "per-kernel figures are reported by the N = 1 run"}
     if rank == 0:
-        print(json.dumps(out))
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

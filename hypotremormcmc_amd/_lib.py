@@ -62,6 +62,7 @@ SIGNATURES = {
     "htm_chains_step_begin": (C.c_int, [vp]),
     "htm_chains_swap_record": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]),
     "htm_chains_step_end": (C.c_int, [vp, vp]),
+    "htm_chains_run_lockstep": (C.c_int, [vp, C.c_int, vp, vp, vp]),
     "htm_chains_sync": (C.c_int, [vp]),
     "htm_chains_drain": (C.c_int, [vp]),
     "htm_chains_iterations_done": (C.c_int, [vp, C.POINTER(C.c_int)]),

@@ -99,6 +99,12 @@ class ChainSet:
     def step_end(self, d_gathered: int):
         check(self._lib.htm_chains_step_end(self.handle, C.c_void_p(d_gathered)))
 
+    def run_lockstep(self, n_iter: int, allgather_fn: int, comm: int, d_gathered: int):
+        """n_iter lock-step iterations driven from C (see htm_chains_run_lockstep): allgather_fn is the
+        address of an ncclAllGather-compatible function, comm the rank's communicator handle."""
+        check(self._lib.htm_chains_run_lockstep(self.handle, int(n_iter), C.c_void_p(allgather_fn),
+                                                C.c_void_p(comm), C.c_void_p(d_gathered)))
+
     def sync(self):
         check(self._lib.htm_chains_sync(self.handle))
 

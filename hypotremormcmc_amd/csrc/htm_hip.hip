@@ -939,6 +939,25 @@ int htm_chains_step_begin(htm_chains *hc)
     return launch_step(hc, MODE_FINISH, hc->h_target, nullptr);
 }
 
+int htm_chains_run_lockstep(htm_chains *hc, int n_iter, htm_allgather_fn allgather, void *comm, void *d_gathered)
+{
+    if (!hc || !allgather || !d_gathered || n_iter < 0) return fail(HTM_EINVAL, "bad argument");
+    htm_forward *h = hc->fwd;
+    HIPCHK(hipSetDevice(h->device));
+    const size_t words = 4 + 2 * (size_t)hc->dev.n_chains;
+    // records a rank may hold on the device between drains: n_chains per iteration at most
+    const int drain_every = std::max(1, std::min(hc->dev.cap_lik, hc->dev.cap_smp) / (2 * hc->dev.n_chains) - 2);
+    for (int k = 0; k < n_iter; ++k) {
+        int rc = htm_chains_step_begin(hc);
+        if (rc) return rc;
+        const int st = allgather(hc->dev.swap_rec, d_gathered, words, 8 /* ncclFloat64 */, comm, h->stream);
+        if (st != 0) return fail(HTM_EHIP, "all-gather of the swap records failed with status %d", st);
+        if ((rc = htm_chains_step_end(hc, d_gathered))) return rc;
+        if ((k + 1) % drain_every == 0 && (rc = htm_chains_drain(hc))) return rc;
+    }
+    return HTM_OK;
+}
+
 int htm_chains_swap_record(htm_chains *hc, void **d_record, size_t *record_bytes)
 {
     if (!hc || !d_record || !record_bytes) return fail(HTM_EINVAL, "NULL argument");

@@ -77,6 +77,33 @@ class TorchWorld:
         self.gathered = torch.zeros(self.world * self.rec.numel(), dtype=torch.float64, device=self.rec.device)
         # records a rank may hold between drains: n_chains per iteration at most
         self.drain_every = 4096
+        self.fast = self._try_direct_rccl()
+
+    def _try_direct_rccl(self):
+        """(function pointer, communicator) of RCCL's ncclAllGather on torch's own communicator, so that the
+        iteration loop can run in C (one kernel launch + one all-gather enqueue per iteration, no Python in
+        between).  None -> the torch.distributed call per iteration is used (also the gloo / CPU-test path)."""
+        import ctypes
+        import os
+
+        if os.environ.get("HTM_DIRECT_RCCL", "1") == "0" or not isinstance(self.r, DeviceRank):
+            return None
+        try:
+            if self.dist.get_backend(self.group) != "nccl":
+                return None
+            # make sure the communicator exists, then fetch it
+            self.dist.all_gather_into_tensor(self.gathered, self.rec, group=self.group)
+            self.torch.cuda.synchronize()
+            pg = self.group if self.group is not None else self.dist.distributed_c10d._get_default_group()
+            backend = pg._get_backend(self.torch.device("cuda", self.r.cs.fwd.device))
+            comm = int(backend._comm_ptr())
+            lib = ctypes.CDLL(os.path.join(os.path.dirname(self.torch.__file__), "lib", "librccl.so"))
+            fn = ctypes.cast(lib.ncclAllGather, ctypes.c_void_p).value
+            if not comm or not fn:
+                return None
+            return fn, comm
+        except Exception:
+            return None
 
     def step(self):
         self.r.step_begin()
@@ -84,6 +111,10 @@ class TorchWorld:
         self.r.step_end(self.gathered)
 
     def run(self, n_iter: int):
+        if self.fast is not None:
+            self.r.cs.run_lockstep(n_iter, self.fast[0], self.fast[1], self.gathered.data_ptr())
+            self.r.drain()
+            return
         for k in range(n_iter):
             self.step()
             if (k + 1) % self.drain_every == 0:

@@ -159,6 +159,15 @@ int htm_chains_run(htm_chains *hc, int n_iter);
 int htm_chains_step_begin(htm_chains *hc);
 int htm_chains_swap_record(htm_chains *hc, void **d_record, size_t *record_bytes);
 int htm_chains_step_end(htm_chains *hc, const void *d_gathered_records);
+/* The same loop driven from C: n_iter lock-step iterations, each = step_begin + all-gather of the swap
+ * records + step_end, all enqueued on the handle's stream without host synchronisation.  `allgather` has
+ * ncclAllGather's signature (RCCL: pass &ncclAllGather and the rank's ncclComm_t; count is in elements of
+ * dtype 8 = ncclFloat64); d_gathered must hold n_procs * record_bytes.  Returns the function's first
+ * non-zero status as HTM_EHIP. */
+typedef int (*htm_allgather_fn)(const void *sendbuff, void *recvbuff, size_t count, int dtype, void *comm,
+                                void *stream);
+int htm_chains_run_lockstep(htm_chains *hc, int n_iter, htm_allgather_fn allgather, void *comm,
+                            void *d_gathered);
 int htm_chains_sync(htm_chains *hc);        /* wait + raise device-side error flags */
 int htm_chains_drain(htm_chains *hc);       /* sync + move device record buffers to host memory */
 
