@@ -311,6 +311,16 @@ struct PSync {
     unsigned long long quit;   char p3[120];   // launches whose master has finished
 };
 
+// Work order of the persistent kernel as tagged 8-byte granules {tag : 32, payload : 32} (agent-scope
+// stores/loads; the data is the flag: a granule is valid for job `tag` iff its upper half equals `tag`).
+constexpr int kGranPerEntry = 9;       // chain, type, idx, x_new (2), beta (2), q (2)
+struct GDesc {
+    // line 0 (128 B, polled with ONE wide request): [0] job word (launch << 32 | tag), written last, after the
+    // master has drained its chain-state stores; [1] header {tag, number of entries}; [2..10] entry 0
+    unsigned long long line0[16];
+    unsigned long long e[kMaxChains][16];      // entries 1.. (entry k at e[k]; e[0] unused), 9 granules each
+};
+
 struct Ctrl {
     int iter_done, iter_target, stage, n_full;
     int err, stop, n_lik, n_smp;
@@ -319,6 +329,7 @@ struct Ctrl {
     double swap_r, swap_logr;
     int slog_n, slog_cap;
     long long n_full_evals, n_partial_evals;
+    unsigned long long jobs_total;   // full-evaluation jobs ever published (persistent kernel): the granule tag
 };
 
 // The rank's random stream, produced AHEAD of consumption by k_rawgen / k_stream_* on a side stream.
@@ -356,6 +367,8 @@ struct ChainsDev {
     int32_t *slog_i; double *slog_d;
     double *swap_rec;                // [4 + 2*n_chains] this rank's record (8-byte words)
     PSync *ps;                       // persistent-worker hand-shake (k_mcmc)
+    GDesc *gdesc;                    // work order, tagged granules
+    unsigned long long *pgran;       // [n_chains][n_workers][2] partial sums, tagged granules (hi, lo)
     int n_workers;                   // worker blocks of a k_mcmc launch
     StreamDev stream;
     unsigned long long *stamps;      // diagnostic builds (-DHTM_STAMPS) only, else nullptr

@@ -578,6 +578,10 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
     if ((rc = dev_alloc(hc->pool, &d.partial, (size_t)nc * std::max(h->n_wg, d.n_workers)))) return cleanup(rc);
     if ((rc = dev_alloc(hc->pool, &d.ps, 1))) return cleanup(rc);
     HIPCHK(hipMemset(d.ps, 0, sizeof(PSync)));
+    if ((rc = dev_alloc(hc->pool, &d.gdesc, 1))) return cleanup(rc);
+    HIPCHK(hipMemset(d.gdesc, 0, sizeof(GDesc)));
+    if ((rc = dev_alloc(hc->pool, &d.pgran, (size_t)nc * d.n_workers * 2))) return cleanup(rc);
+    HIPCHK(hipMemset(d.pgran, 0, (size_t)nc * d.n_workers * 2 * sizeof(unsigned long long)));
     {
         const char *env = getenv("HTM_PERSIST");
         hc->persist = !(env && env[0] == '0');

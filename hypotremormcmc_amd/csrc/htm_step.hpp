@@ -146,6 +146,20 @@ __device__ __forceinline__ void st_agent(unsigned long long *p, unsigned long lo
 __device__ __forceinline__ double ld_agent(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int ld_agent(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned long long ld_agent(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_gran(unsigned long long *g, unsigned tag, unsigned payload)
+{
+    st_agent(g, ((unsigned long long)tag << 32) | payload);
+}
+__device__ __forceinline__ void st_gran_f64(unsigned long long *g, unsigned tag, double v)   // two granules
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    st_gran(g, tag, (unsigned)(b >> 32));
+    st_gran(g + 1, tag, (unsigned)b);
+}
+__device__ __forceinline__ double gran_f64(unsigned long long hi, unsigned long long lo)
+{
+    return __longlong_as_double((long long)(((hi & 0xffffffffull) << 32) | (lo & 0xffffffffull)));
+}
 __device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 __device__ __forceinline__ bool metropolis(double L_new, double L_cur, double T, double lpr, double r,
@@ -487,7 +501,6 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
         sh.avail = av > (1 << 30) ? (1 << 30) : (int)av;
         sh.fill = 0; sh.base = 0; sh.redo = -1; sh.sw_do = 0; sh.catchup = 0;
         sh.jobs = 0;
-        if constexpr (PERSIST) sh.done_base = ld_agent(&cs.ps->done);
     }
     for (int j = tid; j < f.S; j += blockDim.x) { s_sx[j] = f.sx[j]; s_sy[j] = f.sy[j]; s_sz[j] = f.sz[j]; }
     for (int c = tid; c < nc; c += blockDim.x) { sh.temp[c] = cs.temp[c]; sh.L[c] = cs.L[c]; }
@@ -612,13 +625,23 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
                             if (in && ((v.mf >> lane) & 1ull)) {            // k_full's work order, chain order
                                 const Proposal &pr = sh.prop[lane];
                                 const int vz = opaque_zero();
-                                FullEntry *en = &cs.desc->e[__popcll(v.mf & ((1ull << lane) - 1ull))];
-                                st_agent(&en->chain, lane); st_agent(&en->type, pr.type); st_agent(&en->idx, pr.idx);
-                                st_agent(&en->x_new, pr.x_new);
-                                st_agent(&en->beta, pr.type == 1 ? pr.x_new : ld_state(cs.vs.x + lane, vz));
-                                st_agent(&en->q, pr.type == 3 ? pr.x_new : ld_state(cs.qs.x + lane, vz));
+                                const int slot = __popcll(v.mf & ((1ull << lane) - 1ull));
+                                const double beta_e = pr.type == 1 ? pr.x_new : ld_state(cs.vs.x + lane, vz);
+                                const double q_e = pr.type == 3 ? pr.x_new : ld_state(cs.qs.x + lane, vz);
+                                if constexpr (PERSIST) {
+                                    const unsigned tag = (unsigned)(sh.c.jobs_total + 1ull);
+                                    unsigned long long *g = slot == 0 ? cs.gdesc->line0 + 2 : cs.gdesc->e[slot];
+                                    st_gran(g + 0, tag, (unsigned)lane); st_gran(g + 1, tag, (unsigned)pr.type);
+                                    st_gran(g + 2, tag, (unsigned)pr.idx);
+                                    st_gran_f64(g + 3, tag, pr.x_new); st_gran_f64(g + 5, tag, beta_e); st_gran_f64(g + 7, tag, q_e);
+                                } else {
+                                    FullEntry *en = &cs.desc->e[slot];
+                                    en->chain = lane; en->type = pr.type; en->idx = pr.idx; en->pad = 0;
+                                    en->x_new = pr.x_new; en->beta = beta_e; en->q = q_e;
+                                }
                             }
-                            if (PERSIST && v.mf && lane == 0) st_agent(&cs.desc->n, (int)__popcll(v.mf));
+                            if (PERSIST && v.mf && lane == 0)
+                                st_gran(&cs.gdesc->line0[1], (unsigned)(sh.c.jobs_total + 1ull), (unsigned)__popcll(v.mf));
                             if (lane == 0) {
                                 sh.c.swap_i1 = i1; sh.c.swap_i2 = i2; sh.c.swap_r = sr; sh.c.swap_logr = slr;
                                 sh.c.spos = sh.origin + pos;     // RNG commit: draws consumed so far
@@ -657,24 +680,33 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
                     // alone does not: same-CU waves share the L1), then ONE lane moves the job word.
                     drain_vmem();
                     __syncthreads();
-                    if (tid == 0) {
-                        sh.jobs += 1;
-                        st_agent(&cs.ps->job, (launch << 32) | (unsigned long long)sh.jobs);
-                        // ... and wait until every worker has delivered its partial sums (bounded: 5 s)
-                        const unsigned long long want = sh.done_base + (unsigned long long)cs.n_workers * sh.jobs;
-                        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz
-                        while (ld_agent(&cs.ps->done) < want) {
-                            __builtin_amdgcn_s_sleep(1);
-                            if (__builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) { sh.c.err = -8; break; }
-                        }
-                    }
-                    __syncthreads();
-                    if (sh.c.err) break;
+                    const unsigned tag = (unsigned)(sh.c.jobs_total + 1ull);
+                    if (tid == 0) st_agent(&cs.gdesc->line0[0], (launch << 32) | (unsigned long long)tag);
+#ifdef HTM_STAMPS
+                    if (tid == 0 && cs.stamps) { cs.stamps[20] += __builtin_amdgcn_s_memrealtime(); cs.stamps[26] += 1; }
+#endif
+                    // every chain wave collects the partial sums of its own chains: tagged granules, no counter
                     for (int c = wave; c < nc; c += NW) {            // judge + commit (cls_mcmc.f90:193-219)
                         Proposal pr = sh.prop[c];
                         if (pr.need_full) {
+                            const unsigned long long *pg = cs.pgran + (size_t)c * cs.n_wg * 2;
                             double acc = 0.0;
-                            for (int k = lane; k < cs.n_wg; k += 64) acc += ld_agent(cs.partial + (size_t)c * cs.n_wg + k);
+                            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz
+                            for (int k0 = 0; k0 < cs.n_wg; k0 += 64) {
+                                const int k = k0 + lane;
+                                unsigned long long hi = 0, lo = 0;
+                                for (;;) {
+                                    bool ok = true;
+                                    if (k < cs.n_wg) {
+                                        hi = ld_agent(pg + 2 * k); lo = ld_agent(pg + 2 * k + 1);
+                                        ok = (unsigned)(hi >> 32) == tag && (unsigned)(lo >> 32) == tag;
+                                    }
+                                    if (__all(ok)) break;
+                                    if (__builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) { if (lane == 0) sh.c.err = -8; break; }
+                                    __builtin_amdgcn_s_sleep(1);
+                                }
+                                acc += k < cs.n_wg ? gran_f64(hi, lo) : 0.0;
+                            }
                             pr.L_new = -wave_sum1(acc) - f.const_sum;      // cls_forward.f90:277-300
                             pr.accepted = metropolis(pr.L_new, sh.L[c], sh.temp[c], pr.lpr, pr.r_judge, pr.logr_judge) ? 1 : 0;
                             if (lane == 0) {
@@ -690,6 +722,13 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
                         }
                     }
                     __syncthreads();
+#ifdef HTM_STAMPS
+                    if (tid == 0 && cs.stamps) cs.stamps[25] += __builtin_amdgcn_s_memrealtime();
+#endif
+                    if (tid == 0) sh.c.jobs_total += 1ull;
+                    if (sh.c.err) break;
+                    __syncthreads();
+                    STAMP(6);   // hand-over: publish, workers, partial sums, judge
                     resume = true;               // the iteration's end (records, swap, counters) follows
                     continue;
                 } else {                         // hand over to k_full; the next launch resumes at P0
@@ -732,39 +771,107 @@ __global__ __launch_bounds__(512) void k_step(FwdDev f, ChainsDev cs, int mode, 
 
 // Worker block of a k_mcmc launch: waits for work orders of its own launch and evaluates its event tile of
 // every model in the order (same arithmetic as k_full: wave <-> event, lane <-> station).  Block w, wave v
-// take events (w*8 + v) + k * 8 * W.  One partial sum per (model, worker), written through (sc1), then one
-// agent-scope add on PSync::done.  Leaves when the master has finished (PSync::quit) or a bounded spin ends.
+// take events (w*8 + v) + k * 8 * W.  The immutable inputs of its first event (observation rows, station
+// coordinates) are loaded once per launch and stay in registers.  Hand-off in both directions by tagged
+// granules (data is the flag); chain state is read with agent-scope loads after the job word has been seen
+// (the master drained its stores before publishing it).  Leaves when the master has finished (PSync::quit)
+// or after a bounded wait.
 template <int NCH>
 __device__ __forceinline__ void worker_body(const FwdDev &f, const ChainsDev &cs, unsigned long long launch)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *s_red = reinterpret_cast<double *>(smem);          // [8]
-    int *s_flag = reinterpret_cast<int *>(smem + 128);
+    unsigned *s_tag = reinterpret_cast<unsigned *>(smem + 128);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int w = blockIdx.x - 1, W = cs.n_workers;
-    unsigned mine = 0;
+    const int nc = cs.n_chains;
+    const int ev0 = w * 8 + wave;
+
+    constexpr int N = NCH > 0 ? NCH : 1;
+    StaRegs<N> st;
+    ObsRegs<N> ob0;
+    if constexpr (NCH > 0) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int j = lane + 64 * c;
+            const bool valid = j < f.S;
+            st.sx[c] = valid ? f.sx[j] : 0.0; st.sy[c] = valid ? f.sy[j] : 0.0; st.sz[c] = valid ? f.sz[j] : 0.0;
+            st.tc[c] = 0.0; st.ac[c] = 0.0;
+        }
+        if (ev0 < f.E) load_obs_regs<NCH>(ob0, f, ev0, lane);
+    }
+
+    unsigned long long *s_line0 = reinterpret_cast<unsigned long long *>(smem + 256);   // [16]
+    unsigned last_tag = 0;
     for (;;) {
-        if (tid == 0) {
-            int flag = 0;
+        if (wave == 0) {
+            // lanes 0..10 read {job word, header, entry 0} -- one 128-B line, one request per poll
+            unsigned tag = 0;
+            unsigned long long x = 0;
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();          // 100 MHz
             for (;;) {
-                const unsigned long long j = ld_agent(&cs.ps->job);
-                if ((j >> 32) == launch && (unsigned)(j & 0xffffffffull) > mine) { flag = 1; break; }
-                if (ld_agent(&cs.ps->quit) > launch) break;
-                if (__builtin_amdgcn_s_memrealtime() - t0 > 3000000000ull) break;    // never spin forever (30 s)
-                __builtin_amdgcn_s_sleep(2);
+                x = lane < 11 ? ld_agent(&cs.gdesc->line0[lane]) : 0ull;
+                const unsigned long long j = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)x, 0) |
+                                             ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(x >> 32), 0) << 32);
+                if ((j >> 32) == launch && (unsigned)j != last_tag) {
+                    const unsigned t = (unsigned)j;
+                    const bool ok = lane == 0 || lane >= 11 || (unsigned)(x >> 32) == t;   // header + entry 0 carry the tag
+                    if (__all(ok)) { tag = t; break; }
+                } else {
+                    unsigned long long qv = 0;
+                    if (lane == 0) qv = ld_agent(&cs.ps->quit);
+                    const unsigned qlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)qv, 0);
+                    const unsigned qhi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(qv >> 32), 0);
+                    if ((((unsigned long long)qhi << 32) | qlo) > launch) break;
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > 3000000000ull) break;    // never spin forever (30 s)
+                }
+                __builtin_amdgcn_s_sleep(1);
             }
-            *s_flag = flag;
+            if (lane < 11) s_line0[lane] = x;
+            if (lane == 0) *s_tag = tag;
         }
         __syncthreads();
-        if (*s_flag == 0) return;
-        mine += 1;
-        const int n = ld_agent(&cs.desc->n);
+        const unsigned tag = *s_tag;
+        if (tag == 0) return;
+        last_tag = tag;
+#ifdef HTM_STAMPS
+        const bool wstamp = cs.stamps && w == 0 && tid == 0;
+        if (wstamp) cs.stamps[21] += __builtin_amdgcn_s_memrealtime();
+#endif
+        const unsigned long long hdr = s_line0[1];
+        // entry 0 arrived with the poll; entries 1.. (lane k holds entry k) are re-read until their tags match
+        unsigned long long g[kGranPerEntry];
+#pragma unroll
+        for (int q = 0; q < kGranPerEntry; ++q) g[q] = s_line0[2 + q];
+        if ((int)(hdr & 0xffffffffull) > 1) {
+            const int n_ = (int)(hdr & 0xffffffffull);
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            for (;;) {
+                bool ok = true;
+                if (lane >= 1 && lane < n_) {
+#pragma unroll
+                    for (int q = 0; q < kGranPerEntry; ++q) {
+                        g[q] = ld_agent(&cs.gdesc->e[lane][q]);
+                        ok = ok && (unsigned)(g[q] >> 32) == tag;
+                    }
+                }
+                if (__all(ok)) break;
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) return;
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        const int n = (int)(hdr & 0xffffffffull);
         for (int k = 0; k < n; ++k) {
-            const FullEntry *en = &cs.desc->e[k];
-            const int m = ld_agent(&en->chain), type = ld_agent(&en->type), idx = ld_agent(&en->idx);
-            const double ov_val = ld_agent(&en->x_new), beta = ld_agent(&en->beta), q = ld_agent(&en->q);
+            // entry k lives in lane k: broadcast its fields
+            unsigned long long e[kGranPerEntry];
+#pragma unroll
+            for (int q = 0; q < kGranPerEntry; ++q) {
+                const int lo = __builtin_amdgcn_readlane((int)(unsigned)g[q], k);   // lane 0 holds entry 0 too
+                e[q] = (unsigned long long)(unsigned)lo;
+            }
+            const int m = (int)e[0], type = (int)e[1], idx = (int)e[2];
+            const double ov_val = gran_f64(e[3], e[4]), beta = gran_f64(e[5], e[6]), q = gran_f64(e[7], e[8]);
             int ov_kind = 0, ov_idx = -1, ov_evt = -1, ov_cmp = 0;
             if (type == 2 || type == 4) { ov_kind = type; ov_idx = idx; }
             else if (type >= 5) { ov_evt = idx / 3; ov_cmp = idx - 3 * ov_evt; }
@@ -772,32 +879,34 @@ __device__ __forceinline__ void worker_body(const FwdDev &f, const ChainsDev &cs
             const double *tc = cs.tc.x + (size_t)m * cs.S, *ac = cs.ac.x + (size_t)m * cs.S;
             double lane_acc = 0.0;
             if constexpr (NCH > 0) {
-                StaRegs<NCH> st;
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {                 // chain state: agent-scope loads
                     const int j = lane + 64 * c;
                     const bool valid = j < f.S;
-                    st.sx[c] = valid ? f.sx[j] : 0.0; st.sy[c] = valid ? f.sy[j] : 0.0; st.sz[c] = valid ? f.sz[j] : 0.0;
                     st.tc[c] = valid ? ld_agent(tc + j) : 0.0;
                     st.ac[c] = valid ? ld_agent(ac + j) : 0.0;
                     if (valid && ov_idx == j) { if (ov_kind == 2) st.tc[c] = ov_val; if (ov_kind == 4) st.ac[c] = ov_val; }
                 }
-                for (int ev = w * 8 + wave; ev < f.E; ev += 8 * W) {
+                for (int ev = ev0; ev < f.E; ev += 8 * W) {
                     const bool ov = ev == ov_evt;
                     const double hx = ld_agent(hyp + 3 * ev), hy = ld_agent(hyp + 3 * ev + 1), hz = ld_agent(hyp + 3 * ev + 2);
                     const double px[1] = {(ov && ov_cmp == 0) ? ov_val : hx};
                     const double py[1] = {(ov && ov_cmp == 1) ? ov_val : hy};
                     const double pz[1] = {(ov && ov_cmp == 2) ? ov_val : hz};
                     double out[1];
-                    ObsRegs<NCH> ob;
-                    load_obs_regs<NCH>(ob, f, ev, lane);
-                    event_misfit<NCH, 1>(f, ob, lane, st, px, py, pz, beta, q, out);
+                    if (ev == ev0) {
+                        event_misfit<NCH, 1>(f, ob0, lane, st, px, py, pz, beta, q, out);
+                    } else {
+                        ObsRegs<NCH> ob;
+                        load_obs_regs<NCH>(ob, f, ev, lane);
+                        event_misfit<NCH, 1>(f, ob, lane, st, px, py, pz, beta, q, out);
+                    }
                     lane_acc += out[0];
                 }
             } else {
                 // generic station count: corrections are read through plain loads after an agent acquire
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                for (int ev = w * 8 + wave; ev < f.E; ev += 8 * W) {
+                for (int ev = ev0; ev < f.E; ev += 8 * W) {
                     const bool ov = ev == ov_evt;
                     const double hx = ld_agent(hyp + 3 * ev), hy = ld_agent(hyp + 3 * ev + 1), hz = ld_agent(hyp + 3 * ev + 2);
                     const double px[1] = {(ov && ov_cmp == 0) ? ov_val : hx};
@@ -810,18 +919,19 @@ __device__ __forceinline__ void worker_body(const FwdDev &f, const ChainsDev &cs
                 }
             }
             const double tot = wave_sum1(lane_acc);
+#ifdef HTM_STAMPS
+            if (wstamp && k == 0) cs.stamps[22] += __builtin_amdgcn_s_memrealtime();
+#endif
             if (lane == 0) s_red[wave] = tot;
             __syncthreads();
+#ifdef HTM_STAMPS
+            if (wstamp && k == n - 1) cs.stamps[23] += __builtin_amdgcn_s_memrealtime();
+#endif
             if (tid == 0)
-                st_agent(cs.partial + (size_t)m * cs.n_wg + w,
-                         ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) + ((s_red[4] + s_red[5]) + (s_red[6] + s_red[7])));
+                st_gran_f64(cs.pgran + ((size_t)m * cs.n_wg + w) * 2, tag,
+                            ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) + ((s_red[4] + s_red[5]) + (s_red[6] + s_red[7])));
             __syncthreads();
         }
-        if (tid == 0) {
-            drain_vmem();                                       // partial sums have left before the count moves
-            __hip_atomic_fetch_add(&cs.ps->done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
     }
 }
 

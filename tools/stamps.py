@@ -27,7 +27,7 @@ n = 10000
 cs.run(n)
 lib.htm_chains_read_stamps(cs.handle, a)
 names = ["prologue", "P0 (resume judge + window)", "passes (propose+partial+decide+commit)", "validate/records/swap roles",
-         "post (swap apply, records)", "epilogue"]
+         "post (swap apply, records)", "epilogue", "hand-over to workers (wait+judge)"]
 tot = sum(a[k] - base[k] for k in range(len(names)))
 for k, nm in enumerate(names):
     d = a[k] - base[k]
@@ -35,5 +35,14 @@ for k, nm in enumerate(names):
 cn = ["decode+load issue", "proposal arith (load wait)", "event_misfit", "final sum+decision", "commit+LDS write-back"]
 for k, nm in enumerate(cn):
     print("  chain_pass[last chain] %-28s %8.0f ticks/iter" % (nm, (a[32 + k] - base[32 + k]) / n))
+jobs = a[26] - base[26]
+if jobs:
+    d = lambda k: (a[k] - base[k]) / jobs
+    print("  hand-over timeline (100 MHz ticks = 10 ns, per job, %d jobs):" % jobs)
+    print("    publish -> worker 0 has seen job+order   %7.1f ns" % (10 * (d(21) - d(20))))
+    print("    ... -> worker 0 first model reduced      %7.1f ns" % (10 * (d(22) - d(21))))
+    print("    ... -> worker 0 last model combined      %7.1f ns" % (10 * (d(23) - d(22))))
+    print("    ... -> master has all partials + judged  %7.1f ns" % (10 * (d(25) - d(23))))
+    print("    publish -> master done                   %7.1f ns" % (10 * (d(25) - d(20))))
 st = cs.last_run_stats()
 print("total ticks/iter", tot / n, " device_us/iter", st["device_us"] / n, st)
