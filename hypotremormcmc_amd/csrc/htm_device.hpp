@@ -311,14 +311,15 @@ struct PSync {
     unsigned long long quit;   char p3[120];   // launches whose master has finished
 };
 
-// Work order of the persistent kernel as tagged 8-byte granules {tag : 32, payload : 32} (agent-scope
+// Work orders of the persistent kernel as tagged 8-byte granules {tag : 32, payload : 32} (agent-scope
 // stores/loads; the data is the flag: a granule is valid for job `tag` iff its upper half equals `tag`).
-constexpr int kGranPerEntry = 9;       // chain, type, idx, x_new (2), beta (2), q (2)
+// Every chain has its own order slot and publishes it by itself, as soon as its proposal is known.
+constexpr int kGranPerEntry = 8;       // type, idx, x_new (2), beta (2), q (2), spare
 struct GDesc {
-    // line 0 (128 B, polled with ONE wide request): [0] job word (launch << 32 | tag), written last, after the
-    // master has drained its chain-state stores; [1] header {tag, number of entries}; [2..10] entry 0
-    unsigned long long line0[16];
-    unsigned long long e[kMaxChains][16];      // entries 1.. (entry k at e[k]; e[0] unused), 9 granules each
+    // board[c] = (launch << 32) | tag of chain c's latest order; written last, after the owning chain wave has
+    // drained its entry granules and its chain-state stores.  One or two 128-B lines: the workers poll only this.
+    unsigned long long board[kMaxChains];
+    unsigned long long e[kMaxChains][16];      // chain c's order: kGranPerEntry granules
 };
 
 struct Ctrl {

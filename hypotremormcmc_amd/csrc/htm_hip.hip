@@ -604,8 +604,8 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
     d.slog_i = nullptr; d.slog_d = nullptr;
     d.stamps = nullptr;
 #ifdef HTM_STAMPS
-    if ((rc = dev_alloc(hc->pool, &d.stamps, 64))) return cleanup(rc);
-    HIPCHK(hipMemset(d.stamps, 0, 64 * sizeof(unsigned long long)));
+    if ((rc = dev_alloc(hc->pool, &d.stamps, 128))) return cleanup(rc);
+    HIPCHK(hipMemset(d.stamps, 0, 128 * sizeof(unsigned long long)));
 #endif
 
     // random-stream service
@@ -1134,10 +1134,10 @@ int htm_chains_last_run_stats(htm_chains *hc, double *device_us, int *graph_laun
 }
 
 #ifdef HTM_STAMPS
-int htm_chains_read_stamps(htm_chains *hc, unsigned long long out[64])
+int htm_chains_read_stamps(htm_chains *hc, unsigned long long out[128])
 {
     HIPCHK(hipStreamSynchronize(hc->fwd->stream));
-    HIPCHK(hipMemcpy(out, hc->dev.stamps, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out, hc->dev.stamps, 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return HTM_OK;
 }
 #endif

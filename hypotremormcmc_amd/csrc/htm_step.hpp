@@ -181,10 +181,16 @@ __device__ __forceinline__ bool metropolis(double L_new, double L_cur, double T,
 // chain's Rayleigh prior rejected (then the step is undone and repeated one draw earlier, see undo_chain).
 // All 64 lanes execute with identical (uniform) values; lane <-> station only inside event_misfit.
 // Returns the stream position after this step.
-template <int NCH>
+//
+// PERSIST (k_mcmc): a proposal that needs the full evaluation (cls_forward.f90:268-303) is handed to the
+// worker blocks from HERE, by the chain's own wave, as soon as the proposed value is known: the order goes out
+// while the other chain waves are still in their partial updates, so the workers' round trip is hidden behind
+// them.  The wave then collects the workers' partial sums, judges and commits like any other step.
+template <int NCH, bool PERSIST>
 __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, StepShared &sh, const Ring &rg,
                                           const double *s_sx, const double *s_sy, const double *s_sz, int c,
-                                          int p, int iter, int lane)
+                                          int p, int iter, int lane, unsigned long long launch,
+                                          PfRegs &pf, bool do_pf, int pf_p, int pf_limit)
 {
     const int M = rg.mask;
 #ifdef HTM_STAMPS
@@ -214,6 +220,8 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
             load_sta_regs<NCH>(st, f.S, lane, s_sx, s_sy, s_sz, tc, ac, 0, -1, 0.0);
             load_obs_regs<NCH>(ob, f, ev, lane);      // in flight while the proposal is worked out
         }
+    } else if constexpr (PERSIST) {
+        beta = ld_state(cs.vs.x + c, vz); q = ld_state(cs.qs.x + c, vz);   // go out with the work order
     }
     const double T = sh.temp[c], L_cur = sh.L[c];
     CSTAMP(0);   // decode + load issue
@@ -228,6 +236,9 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
     const double r = ok ? r_ring : 0.0, logr = ok ? logr_ring : 0.0;
     const int cnt = dec.w - 1 + ok;                             // the judge draw happens only if prior_ok
     CSTAMP(1);   // proposal arithmetic (waits for the model loads)
+    // The wave that keeps the LDS window of the stream ahead issues those loads HERE: vector-memory results
+    // return in issue order, so issued any earlier their HBM latency would sit in front of this step's loads.
+    if (do_pf) pf_load(pf, cs, sh, pf_p, pf_limit);
 
     double L_new = 0.0;
     int need_full = 0, acc = 0;
@@ -248,6 +259,55 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
             CSTAMP(3);   // final sum + decision
         } else {
             need_full = 1;
+            if constexpr (PERSIST) {
+                // ---- work order: tag = ticket (unique over the life of the chain set), entry granules, then --
+                // ---- after this wave's stores (entry + every earlier commit of this chain) have drained -------
+                // ---- the board word that the workers poll ------------------------------------------------------
+                unsigned long long tk = 0;
+                if (lane == 0) tk = atomicAdd(&sh.c.jobs_total, 1ull) + 1ull;
+                const unsigned tag = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)tk);
+                if (lane == 0) {
+                    unsigned long long *ge = cs.gdesc->e[c];
+                    st_gran(ge + 0, tag, (unsigned)type); st_gran(ge + 1, tag, (unsigned)idx);
+                    st_gran_f64(ge + 2, tag, x_new);
+                    st_gran_f64(ge + 4, tag, type == 1 ? x_new : beta);
+                    st_gran_f64(ge + 6, tag, type == 3 ? x_new : q);
+                }
+                drain_vmem();
+                if (lane == 0) st_agent(&cs.gdesc->board[c], (launch << 32) | (unsigned long long)tag);
+#ifdef HTM_STAMPS
+                if (lane == 0 && cs.stamps) { atomicAdd(&cs.stamps[20], __builtin_amdgcn_s_memrealtime()); atomicAdd(&cs.stamps[26], 1ull); }
+#endif
+                // ---- the workers' partial sums: tagged granules, fixed summation order ------------------------
+                const unsigned long long *pg = cs.pgran + (size_t)c * cs.n_wg * 2;
+                double part = 0.0;
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz
+                constexpr int kSweep = 4;                 // <= 256 workers (host-checked); all sweeps in ONE round
+                unsigned long long hi[kSweep], lo[kSweep];
+                for (;;) {
+                    bool got = true;
+#pragma unroll
+                    for (int j = 0; j < kSweep; ++j) {
+                        const int k = j * 64 + lane;
+                        hi[j] = 0; lo[j] = 0;
+                        if (k < cs.n_wg) { hi[j] = ld_agent(pg + 2 * k); lo[j] = ld_agent(pg + 2 * k + 1); }
+                    }
+#pragma unroll
+                    for (int j = 0; j < kSweep; ++j)
+                        if (j * 64 + lane < cs.n_wg) got = got && (unsigned)(hi[j] >> 32) == tag && (unsigned)(lo[j] >> 32) == tag;
+                    if (__all(got)) break;
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) { if (lane == 0) sh.c.err = -8; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+#pragma unroll
+                for (int j = 0; j < kSweep; ++j)            // fixed order: worker lane, lane + 64, ...
+                    if (j * 64 < cs.n_wg) part += (j * 64 + lane < cs.n_wg) ? gran_f64(hi[j], lo[j]) : 0.0;
+                L_new = -wave_sum1(part) - f.const_sum;                  // cls_forward.f90:277-300
+                acc = metropolis(L_new, L_cur, T, lpr, r, logr) ? 1 : 0;
+#ifdef HTM_STAMPS
+                if (lane == 0 && cs.stamps) atomicAdd(&cs.stamps[25], __builtin_amdgcn_s_memrealtime());
+#endif
+            }
         }
     }
     if (lane == 0) {
@@ -291,6 +351,7 @@ struct Valid {
     unsigned long long bad, mf;
     int total, base;
 };
+template <bool PERSIST>
 __device__ __forceinline__ Valid validate(const StepShared &sh, int nc, int lane)
 {
     Valid v;
@@ -299,7 +360,7 @@ __device__ __forceinline__ Valid validate(const StepShared &sh, int nc, int lane
     const int incl = wave_incl_scan(my_cnt);
     v.base = sh.start[0];                       // chain 0 always starts at the iteration's base
     v.bad = __ballot(in && v.base + incl - my_cnt != my_start);
-    v.mf = __ballot(in && sh.prop[lane].need_full != 0);
+    v.mf = PERSIST ? 0ull : __ballot(in && sh.prop[lane].need_full != 0);   // PERSIST: already evaluated
     v.total = __builtin_amdgcn_readlane(incl, 63);
     return v;
 }
@@ -577,13 +638,17 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
             // ---------------- passes: propose -> partial update -> decide -> commit, per chain wave ----
             int redo = 0;
             bool first = true;
+#ifdef HTM_STAMPS
+            const unsigned long long t_top = __builtin_amdgcn_s_memtime();
+#endif
             for (;;) {
                 // one wave keeps the LDS window ahead: loads issued before its pass, stored after it
                 PfRegs pf;
                 pf.p = -1;
                 const bool extend = first && wave == wave_P;
                 const int pf_limit = min(min(sh.base + 3 * wmax, sh.avail), sh.base + rg.mask + 1 - 8);
-                if (extend) pf_load(pf, cs, sh, sh.fill + lane, pf_limit);
+                const int pf_p = sh.fill + lane;
+                bool pf_due = extend;
                 int p = 0;
                 bool have_p = false;
                 for (int c = wave; c < nc; c += NW) {
@@ -594,18 +659,29 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
                     } else if (!have_p) {                                   // optimistic start: c steps after base
                         p = c == 0 ? sh.base : sh.base + rg.hop[(sh.base & rg.mask) * kHops + c - 1];
                     }
-                    p = chain_pass<NCH>(f, cs, sh, rg, s_sx, s_sy, s_sz, c, p, iter, lane);
+                    p = chain_pass<NCH, PERSIST>(f, cs, sh, rg, s_sx, s_sy, s_sz, c, p, iter, lane, launch,
+                                                 pf, pf_due, pf_p, pf_limit);
+                    pf_due = false;
                     have_p = true;
                     if (NW > 1 && c + NW < nc) p += rg.hop[(p & rg.mask) * kHops + NW - 2];   // skip NW-1 steps
                 }
                 if (extend) {
+                    if (pf_due) pf_load(pf, cs, sh, pf_p, pf_limit);        // this wave owns no chain
                     pf_store(pf, rg);
                     if (lane == 0) sh.fill = max(sh.fill, min(sh.fill + 64, pf_limit));
                 }
+#ifdef HTM_STAMPS
+                if (lane == 0 && cs.stamps && first) {
+                    const unsigned long long ta = __builtin_amdgcn_s_memtime();
+                    const bool job = nc > wave && sh.prop[wave].need_full != 0;
+                    atomicAdd(&cs.stamps[48 + wave + (job ? 8 : 0)], ta - t_top);
+                    atomicAdd(&cs.stamps[64 + wave + (job ? 8 : 0)], 1ull);
+                }
+#endif
                 __syncthreads();                                            // ---- barrier A
                 STAMP(2);   // passes
                 if (wave == 0 || wave == wave_R || wave == wave_W) {
-                    const Valid v = validate(sh, nc, lane);
+                    const Valid v = validate<PERSIST>(sh, nc, lane);
                     int pos = 0, i1, i2;
                     double sr, slr;
                     const bool ok_plan = v.bad ? true : swap_plan(cs, sh, rg, lockstep, v.base + v.total, pos, i1, i2, sr, slr);
@@ -622,26 +698,17 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
                             if (lane == 0) { sh.redo = -2; if (lockstep) sh.c.err = -7; else sh.c.stop = 2; }
                         } else {
                             const unsigned long long mp = __ballot(in && sh.prop[lane].prior_ok != 0 && sh.prop[lane].need_full == 0);
-                            if (in && ((v.mf >> lane) & 1ull)) {            // k_full's work order, chain order
+                            const unsigned long long mfull = __ballot(in && sh.prop[lane].need_full != 0);
+                            if (!PERSIST && in && ((v.mf >> lane) & 1ull)) {   // k_full's work order, chain order
                                 const Proposal &pr = sh.prop[lane];
                                 const int vz = opaque_zero();
                                 const int slot = __popcll(v.mf & ((1ull << lane) - 1ull));
-                                const double beta_e = pr.type == 1 ? pr.x_new : ld_state(cs.vs.x + lane, vz);
-                                const double q_e = pr.type == 3 ? pr.x_new : ld_state(cs.qs.x + lane, vz);
-                                if constexpr (PERSIST) {
-                                    const unsigned tag = (unsigned)(sh.c.jobs_total + 1ull);
-                                    unsigned long long *g = slot == 0 ? cs.gdesc->line0 + 2 : cs.gdesc->e[slot];
-                                    st_gran(g + 0, tag, (unsigned)lane); st_gran(g + 1, tag, (unsigned)pr.type);
-                                    st_gran(g + 2, tag, (unsigned)pr.idx);
-                                    st_gran_f64(g + 3, tag, pr.x_new); st_gran_f64(g + 5, tag, beta_e); st_gran_f64(g + 7, tag, q_e);
-                                } else {
-                                    FullEntry *en = &cs.desc->e[slot];
-                                    en->chain = lane; en->type = pr.type; en->idx = pr.idx; en->pad = 0;
-                                    en->x_new = pr.x_new; en->beta = beta_e; en->q = q_e;
-                                }
+                                FullEntry *en = &cs.desc->e[slot];
+                                en->chain = lane; en->type = pr.type; en->idx = pr.idx; en->pad = 0;
+                                en->x_new = pr.x_new;
+                                en->beta = pr.type == 1 ? pr.x_new : ld_state(cs.vs.x + lane, vz);
+                                en->q = pr.type == 3 ? pr.x_new : ld_state(cs.qs.x + lane, vz);
                             }
-                            if (PERSIST && v.mf && lane == 0)
-                                st_gran(&cs.gdesc->line0[1], (unsigned)(sh.c.jobs_total + 1ull), (unsigned)__popcll(v.mf));
                             if (lane == 0) {
                                 sh.c.swap_i1 = i1; sh.c.swap_i2 = i2; sh.c.swap_r = sr; sh.c.swap_logr = slr;
                                 sh.c.spos = sh.origin + pos;     // RNG commit: draws consumed so far
@@ -650,7 +717,7 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
                                 sh.catchup = (sh.fill < pos + wmax) ? 1 : 0;
                                 sh.c.n_full = __popcll(v.mf);
                                 if (!PERSIST && v.mf) cs.desc->n = __popcll(v.mf);
-                                sh.c.n_full_evals += __popcll(v.mf);
+                                sh.c.n_full_evals += __popcll(mfull);
                                 sh.c.n_partial_evals += __popcll(mp);
                                 if (v.mf == 0) {
                                     if (lockstep) sh.c.stage = ST_WAIT_SWAP;
@@ -675,62 +742,9 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
             }
             if (sh.c.n_full > 0) {
                 if constexpr (PERSIST) {
-                    // Publish the work order to the worker blocks of this launch.  Every wave of this workgroup
-                    // that stored chain state or order entries drains its stores first (a workgroup barrier
-                    // alone does not: same-CU waves share the L1), then ONE lane moves the job word.
-                    drain_vmem();
+                    if (tid == 0) sh.c.err = -9;     // cannot happen: a chain wave evaluates its own order
                     __syncthreads();
-                    const unsigned tag = (unsigned)(sh.c.jobs_total + 1ull);
-                    if (tid == 0) st_agent(&cs.gdesc->line0[0], (launch << 32) | (unsigned long long)tag);
-#ifdef HTM_STAMPS
-                    if (tid == 0 && cs.stamps) { cs.stamps[20] += __builtin_amdgcn_s_memrealtime(); cs.stamps[26] += 1; }
-#endif
-                    // every chain wave collects the partial sums of its own chains: tagged granules, no counter
-                    for (int c = wave; c < nc; c += NW) {            // judge + commit (cls_mcmc.f90:193-219)
-                        Proposal pr = sh.prop[c];
-                        if (pr.need_full) {
-                            const unsigned long long *pg = cs.pgran + (size_t)c * cs.n_wg * 2;
-                            double acc = 0.0;
-                            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz
-                            for (int k0 = 0; k0 < cs.n_wg; k0 += 64) {
-                                const int k = k0 + lane;
-                                unsigned long long hi = 0, lo = 0;
-                                for (;;) {
-                                    bool ok = true;
-                                    if (k < cs.n_wg) {
-                                        hi = ld_agent(pg + 2 * k); lo = ld_agent(pg + 2 * k + 1);
-                                        ok = (unsigned)(hi >> 32) == tag && (unsigned)(lo >> 32) == tag;
-                                    }
-                                    if (__all(ok)) break;
-                                    if (__builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) { if (lane == 0) sh.c.err = -8; break; }
-                                    __builtin_amdgcn_s_sleep(1);
-                                }
-                                acc += k < cs.n_wg ? gran_f64(hi, lo) : 0.0;
-                            }
-                            pr.L_new = -wave_sum1(acc) - f.const_sum;      // cls_forward.f90:277-300
-                            pr.accepted = metropolis(pr.L_new, sh.L[c], sh.temp[c], pr.lpr, pr.r_judge, pr.logr_judge) ? 1 : 0;
-                            if (lane == 0) {
-                                if (pr.accepted) {
-                                    const ModelDev Mo = pick_model(cs, pr.type);
-                                    st_agent(Mo.x + (size_t)c * Mo.nx + pr.idx, pr.x_new);
-                                    sh.L[c] = pr.L_new;
-                                    cs.L[c] = pr.L_new;
-                                    if (pr.cool) sh.na[c * 7 + pr.type - 1] += 1;
-                                }
-                                sh.prop[c] = pr;
-                            }
-                        }
-                    }
-                    __syncthreads();
-#ifdef HTM_STAMPS
-                    if (tid == 0 && cs.stamps) cs.stamps[25] += __builtin_amdgcn_s_memrealtime();
-#endif
-                    if (tid == 0) sh.c.jobs_total += 1ull;
-                    if (sh.c.err) break;
-                    __syncthreads();
-                    STAMP(6);   // hand-over: publish, workers, partial sums, judge
-                    resume = true;               // the iteration's end (records, swap, counters) follows
-                    continue;
+                    break;
                 } else {                         // hand over to k_full; the next launch resumes at P0
                     for (int c = tid; c < nc; c += blockDim.x) cs.prop[c] = sh.prop[c];
                     if (tid == 0) sh.c.stage = ST_WAIT_FULL;
@@ -802,76 +816,59 @@ __device__ __forceinline__ void worker_body(const FwdDev &f, const ChainsDev &cs
         if (ev0 < f.E) load_obs_regs<NCH>(ob0, f, ev0, lane);
     }
 
-    unsigned long long *s_line0 = reinterpret_cast<unsigned long long *>(smem + 256);   // [16]
-    unsigned last_tag = 0;
+    int *s_chain = reinterpret_cast<int *>(smem + 136);
+    unsigned last_tag = 0;                 // wave 0, lane <-> chain: the last order of that chain served here
     for (;;) {
         if (wave == 0) {
-            // lanes 0..10 read {job word, header, entry 0} -- one 128-B line, one request per poll
+            // lanes <-> chains: the board is one or two 128-B lines, one request per poll
             unsigned tag = 0;
-            unsigned long long x = 0;
+            int chain = -1;
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();          // 100 MHz
             for (;;) {
-                x = lane < 11 ? ld_agent(&cs.gdesc->line0[lane]) : 0ull;
-                const unsigned long long j = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)x, 0) |
-                                             ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(x >> 32), 0) << 32);
-                if ((j >> 32) == launch && (unsigned)j != last_tag) {
-                    const unsigned t = (unsigned)j;
-                    const bool ok = lane == 0 || lane >= 11 || (unsigned)(x >> 32) == t;   // header + entry 0 carry the tag
-                    if (__all(ok)) { tag = t; break; }
-                } else {
-                    unsigned long long qv = 0;
-                    if (lane == 0) qv = ld_agent(&cs.ps->quit);
-                    const unsigned qlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)qv, 0);
-                    const unsigned qhi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(qv >> 32), 0);
-                    if ((((unsigned long long)qhi << 32) | qlo) > launch) break;
-                    if (__builtin_amdgcn_s_memrealtime() - t0 > 3000000000ull) break;    // never spin forever (30 s)
+                // lanes < nc: the board; lane 63: the quit word -- one load instruction per poll
+                const unsigned long long *pa = lane < nc ? &cs.gdesc->board[lane] : &cs.ps->quit;
+                const unsigned long long x = (lane < nc || lane == 63) ? ld_agent(pa) : 0ull;
+                const bool fresh = lane < nc && (x >> 32) == launch && (unsigned)x != last_tag;
+                const unsigned long long mask = __ballot(fresh);
+                if (mask) {
+                    chain = __ffsll((long long)mask) - 1;
+                    tag = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)x, chain);
+                    if (lane == chain) last_tag = tag;
+                    break;
                 }
+                const unsigned qlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)x, 63);
+                const unsigned qhi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(x >> 32), 63);
+                if ((((unsigned long long)qhi << 32) | qlo) > launch) break;
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 3000000000ull) break;    // never spin forever (30 s)
                 __builtin_amdgcn_s_sleep(1);
             }
-            if (lane < 11) s_line0[lane] = x;
-            if (lane == 0) *s_tag = tag;
+            if (lane == 0) { *s_tag = tag; *s_chain = chain; }
         }
         __syncthreads();
         const unsigned tag = *s_tag;
+        const int m = *s_chain;
         if (tag == 0) return;
-        last_tag = tag;
 #ifdef HTM_STAMPS
         const bool wstamp = cs.stamps && w == 0 && tid == 0;
         if (wstamp) cs.stamps[21] += __builtin_amdgcn_s_memrealtime();
 #endif
-        const unsigned long long hdr = s_line0[1];
-        // entry 0 arrived with the poll; entries 1.. (lane k holds entry k) are re-read until their tags match
-        unsigned long long g[kGranPerEntry];
-#pragma unroll
-        for (int q = 0; q < kGranPerEntry; ++q) g[q] = s_line0[2 + q];
-        if ((int)(hdr & 0xffffffffull) > 1) {
-            const int n_ = (int)(hdr & 0xffffffffull);
+        {
+            // The order's granules were drained before the board word moved, so they are there; every wave reads
+            // them itself (lanes <-> granules) together with the chain state below -- one round trip in all.
+            unsigned long long gq = 0;
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
             for (;;) {
-                bool ok = true;
-                if (lane >= 1 && lane < n_) {
-#pragma unroll
-                    for (int q = 0; q < kGranPerEntry; ++q) {
-                        g[q] = ld_agent(&cs.gdesc->e[lane][q]);
-                        ok = ok && (unsigned)(g[q] >> 32) == tag;
-                    }
-                }
-                if (__all(ok)) break;
+                if (lane < kGranPerEntry) gq = ld_agent(&cs.gdesc->e[m][lane]);
+                if (__all(lane >= kGranPerEntry || (unsigned)(gq >> 32) == tag)) break;
                 if (__builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) return;
                 __builtin_amdgcn_s_sleep(1);
             }
-        }
-        const int n = (int)(hdr & 0xffffffffull);
-        for (int k = 0; k < n; ++k) {
-            // entry k lives in lane k: broadcast its fields
             unsigned long long e[kGranPerEntry];
 #pragma unroll
-            for (int q = 0; q < kGranPerEntry; ++q) {
-                const int lo = __builtin_amdgcn_readlane((int)(unsigned)g[q], k);   // lane 0 holds entry 0 too
-                e[q] = (unsigned long long)(unsigned)lo;
-            }
-            const int m = (int)e[0], type = (int)e[1], idx = (int)e[2];
-            const double ov_val = gran_f64(e[3], e[4]), beta = gran_f64(e[5], e[6]), q = gran_f64(e[7], e[8]);
+            for (int qn = 0; qn < kGranPerEntry; ++qn)
+                e[qn] = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)gq, qn);
+            const int type = (int)e[0], idx = (int)e[1];
+            const double ov_val = gran_f64(e[2], e[3]), beta = gran_f64(e[4], e[5]), q = gran_f64(e[6], e[7]);
             int ov_kind = 0, ov_idx = -1, ov_evt = -1, ov_cmp = 0;
             if (type == 2 || type == 4) { ov_kind = type; ov_idx = idx; }
             else if (type >= 5) { ov_evt = idx / 3; ov_cmp = idx - 3 * ov_evt; }
@@ -920,12 +917,12 @@ __device__ __forceinline__ void worker_body(const FwdDev &f, const ChainsDev &cs
             }
             const double tot = wave_sum1(lane_acc);
 #ifdef HTM_STAMPS
-            if (wstamp && k == 0) cs.stamps[22] += __builtin_amdgcn_s_memrealtime();
+            if (wstamp) cs.stamps[22] += __builtin_amdgcn_s_memrealtime();
 #endif
             if (lane == 0) s_red[wave] = tot;
             __syncthreads();
 #ifdef HTM_STAMPS
-            if (wstamp && k == n - 1) cs.stamps[23] += __builtin_amdgcn_s_memrealtime();
+            if (wstamp) cs.stamps[23] += __builtin_amdgcn_s_memrealtime();
 #endif
             if (tid == 0)
                 st_gran_f64(cs.pgran + ((size_t)m * cs.n_wg + w) * 2, tag,

@@ -20,7 +20,7 @@ fwd, cs = driver.build_rank(params, data.sta_x, data.sta_y, data.sta_z, obs, 0, 
 cs.run(2000)
 lib = _lib.load()
 lib.htm_chains_read_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
-a = (C.c_uint64 * 64)()
+a = (C.c_uint64 * 128)()
 lib.htm_chains_read_stamps(cs.handle, a)
 base = list(a)
 n = 10000
@@ -35,6 +35,12 @@ for k, nm in enumerate(names):
 cn = ["decode+load issue", "proposal arith (load wait)", "event_misfit", "final sum+decision", "commit+LDS write-back"]
 for k, nm in enumerate(cn):
     print("  chain_pass[last chain] %-28s %8.0f ticks/iter" % (nm, (a[32 + k] - base[32 + k]) / n))
+for wv in range(8):
+    for job in (0, 1):
+        cnt = a[64 + wv + 8 * job] - base[64 + wv + 8 * job]
+        if cnt:
+            print("  wave %d %s: loop top -> barrier A  %7.0f ticks  (%d iterations)" %
+                  (wv, "with job" if job else "partial ", (a[48 + wv + 8 * job] - base[48 + wv + 8 * job]) / cnt, cnt))
 jobs = a[26] - base[26]
 if jobs:
     d = lambda k: (a[k] - base[k]) / jobs
