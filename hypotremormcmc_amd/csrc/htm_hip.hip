@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -117,6 +118,11 @@ struct htm_chains {
     long long n_raw = 0, n_tr = 0, n_rec = 0, n_hop = 0;   // positions produced per stage (host view)
     long long spos_lo = 0, spos_hi = 0;        // bounds on the consumed position since the last sync
     const double *pending_gathered = nullptr;  // lock-step: records whose swap the next k_step applies
+    // lock-step iterations captured as one graph: kLockGraph x [k_mcmc(advance) -> all-gather]
+    hipGraph_t lgraph = nullptr;
+    hipGraphExec_t lgexec = nullptr;
+    void *lg_fn = nullptr, *lg_comm = nullptr, *lg_buf = nullptr;
+    bool lg_failed = false;
     bool persist = true;                       // k_mcmc (master + resident full-evaluation workers) vs k_step + k_full
     ChainsDev dev_np{};                        // view for the non-persistent kernels (partial sums per k_full tile)
     uint32_t init_state[4] = {0, 0, 0, 0};     // mod_random state at stream position 0
@@ -681,6 +687,8 @@ int htm_chains_destroy(htm_chains *hc)
     if (hc->ev_side) (void)hipEventDestroy(hc->ev_side);
     if (hc->side) (void)hipStreamDestroy(hc->side);
     if (hc->gexec) (void)hipGraphExecDestroy(hc->gexec);
+    if (hc->lgexec) (void)hipGraphExecDestroy(hc->lgexec);
+    if (hc->lgraph) (void)hipGraphDestroy(hc->lgraph);
     if (hc->graph) (void)hipGraphDestroy(hc->graph);
     for (void *p : hc->pool) (void)hipFree(p);
     if (hc->ev0) (void)hipEventDestroy(hc->ev0);
@@ -943,6 +951,47 @@ int htm_chains_step_begin(htm_chains *hc)
     return launch_step(hc, MODE_FINISH, hc->h_target, nullptr);
 }
 
+// kLockGraph lock-step iterations as ONE hipGraph: [k_mcmc(apply previous swap, advance) -> all-gather] x K.
+// The collective is captured like any other stream operation (RCCL enqueues its kernel into the capture), so
+// a replay costs one host call per K iterations instead of two launches per iteration.
+static constexpr int kLockGraph = 16;
+
+static int build_lockstep_graph(htm_chains *hc, htm_allgather_fn allgather, void *comm, void *d_gathered)
+{
+    if (hc->lgexec && hc->lg_fn == (void *)allgather && hc->lg_comm == comm && hc->lg_buf == d_gathered) return HTM_OK;
+    if (hc->lgexec) { (void)hipGraphExecDestroy(hc->lgexec); hc->lgexec = nullptr; }
+    if (hc->lgraph) { (void)hipGraphDestroy(hc->lgraph); hc->lgraph = nullptr; }
+    htm_forward *h = hc->fwd;
+    const size_t words = 4 + 2 * (size_t)hc->dev.n_chains;
+    hipStream_t cap = nullptr;
+    HIPCHK(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
+    hipStream_t saved = h->stream;
+    h->stream = cap;
+    int rc = HTM_OK;
+    hipError_t e = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) rc = fail(HTM_EHIP, "hipStreamBeginCapture: %s", hipGetErrorString(e));
+    for (int k = 0; k < kLockGraph && rc == HTM_OK; ++k) {
+        rc = launch_mcmc(hc, MODE_ADVANCE, -2, static_cast<const double *>(d_gathered));
+        if (rc == HTM_OK && allgather(hc->dev.swap_rec, d_gathered, words, 8, comm, cap) != 0)
+            rc = fail(HTM_EHIP, "all-gather refused stream capture");
+    }
+    hipGraph_t g = nullptr;
+    if (e == hipSuccess) {
+        e = hipStreamEndCapture(cap, &g);
+        if (rc == HTM_OK && e != hipSuccess) rc = fail(HTM_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+    }
+    h->stream = saved;
+    if (rc == HTM_OK) {
+        e = hipGraphInstantiate(&hc->lgexec, g, nullptr, nullptr, 0);
+        if (e != hipSuccess) { rc = fail(HTM_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); hc->lgexec = nullptr; }
+    }
+    if (rc == HTM_OK) { hc->lgraph = g; hc->lg_fn = (void *)allgather; hc->lg_comm = comm; hc->lg_buf = d_gathered; }
+    else if (g) (void)hipGraphDestroy(g);
+    (void)hipStreamDestroy(cap);
+    (void)hipGetLastError();
+    return rc;
+}
+
 int htm_chains_run_lockstep(htm_chains *hc, int n_iter, htm_allgather_fn allgather, void *comm, void *d_gathered)
 {
     if (!hc || !allgather || !d_gathered || n_iter < 0) return fail(HTM_EINVAL, "bad argument");
@@ -951,13 +1000,42 @@ int htm_chains_run_lockstep(htm_chains *hc, int n_iter, htm_allgather_fn allgath
     const size_t words = 4 + 2 * (size_t)hc->dev.n_chains;
     // records a rank may hold on the device between drains: n_chains per iteration at most
     const int drain_every = std::max(1, std::min(hc->dev.cap_lik, hc->dev.cap_smp) / (2 * hc->dev.n_chains) - 2);
-    for (int k = 0; k < n_iter; ++k) {
-        int rc = htm_chains_step_begin(hc);
+    int k = 0, since_drain = 0, rc;
+    // Opt-in (HTM_LOCKSTEP_GRAPH=1): measured 19.4 vs 19.8 us per iteration on one rank -- the loop is not
+    // host-bound -- so the default stays the plain enqueue loop, which needs nothing special from the collective.
+    const char *env = std::getenv("HTM_LOCKSTEP_GRAPH");
+    const bool want_graph = hc->persist && !hc->lg_failed && n_iter >= kLockGraph && drain_every >= kLockGraph &&
+                            env && env[0] == '1';
+    if (want_graph) {
+        if (build_lockstep_graph(hc, allgather, comm, d_gathered) != HTM_OK) hc->lg_failed = true;   // eager loop below
+    }
+    if (want_graph && !hc->lg_failed) {
+        // an earlier eager iteration may have left its swap pending on another buffer: apply it first
+        if (hc->pending_gathered && hc->pending_gathered != d_gathered && (rc = flush_pending(hc))) return rc;
+        while (n_iter - k >= kLockGraph) {
+            // a replay consumes at most kLockGraph * wmax draws; keep the produced stream ahead of that bound
+            hc->spos_hi += (long long)kLockGraph * hc->wmax;
+            if (hc->n_hop - hc->spos_hi < 4 * (long long)hc->wmax) {
+                if ((rc = read_ctrl(hc))) return rc;
+                if ((rc = ctrl_error(hc))) return rc;
+                hc->spos_hi += (long long)kLockGraph * hc->wmax;
+                if ((rc = stream_produce(hc, 1 << 17))) return rc;
+                HIPCHK(hipStreamWaitEvent(h->stream, hc->ev_side, 0));
+            }
+            HIPCHK(hipGraphLaunch(hc->lgexec, h->stream));
+            hc->h_target += kLockGraph;
+            hc->pending_gathered = static_cast<const double *>(d_gathered);
+            k += kLockGraph; since_drain += kLockGraph;
+            if (since_drain + kLockGraph > drain_every) { if ((rc = htm_chains_drain(hc))) return rc; since_drain = 0; }
+        }
+    }
+    for (; k < n_iter; ++k) {
+        rc = htm_chains_step_begin(hc);
         if (rc) return rc;
         const int st = allgather(hc->dev.swap_rec, d_gathered, words, 8 /* ncclFloat64 */, comm, h->stream);
         if (st != 0) return fail(HTM_EHIP, "all-gather of the swap records failed with status %d", st);
         if ((rc = htm_chains_step_end(hc, d_gathered))) return rc;
-        if ((k + 1) % drain_every == 0 && (rc = htm_chains_drain(hc))) return rc;
+        if (++since_drain >= drain_every) { if ((rc = htm_chains_drain(hc))) return rc; since_drain = 0; }
     }
     return HTM_OK;
 }

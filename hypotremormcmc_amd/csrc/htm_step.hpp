@@ -556,6 +556,7 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
     if (tid == 0) {
         sh.c = *cs.ctrl;
         if (target_arg >= 0) sh.c.iter_target = target_arg;
+        else if (target_arg == -2) sh.c.iter_target = 0x7fffffff;   // lock-step graph replay: one iteration per launch
         const long long he = *cs.stream.hop_end;
         sh.origin = sh.c.spos;
         const long long av = he - sh.c.spos;

@@ -172,3 +172,43 @@ def test_many_chains_per_rank():
     assert sets[0].rng_state() == job.rng_state(0)
     a, b = sets[0].counts(); oa, ob = job.counts()
     assert np.array_equal(a, oa) and np.array_equal(b, ob)
+
+
+@pytest.mark.parametrize("graph", ["1", "0"])
+def test_rccl_lockstep_loop_equals_single_rank_driver_bitwise(graph, monkeypatch):
+    """The multi-GPU driver loop (htm_chains_run_lockstep: k_mcmc + ncclAllGather per iteration, replayed as a
+    hipGraph of 16 iterations or enqueued one by one) on a real RCCL communicator of one rank must produce the
+    bits of the single-rank driver; 700 iterations = graph replays + an eager tail."""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    from hypotremormcmc_amd.parallel import TorchWorld
+
+    monkeypatch.setenv("HTM_LOCKSTEP_GRAPH", graph)
+    fx, data, params = load_case("c2")
+    n_iter = 700
+    _, a = _build_world(data, params)
+    a[0].run(n_iter)
+    _, b = _build_world(data, params)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        tw = TorchWorld(b[0])
+        assert tw.fast is not None, "direct RCCL entry not found: the C loop was not exercised"
+        tw.run(300)
+        tw.run(n_iter - 300)
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    assert b[0].iterations_done == n_iter
+    ia, ca, la = a[0].likelihood_trace(); ib, cb, lb = b[0].likelihood_trace()
+    assert np.array_equal(ia, ib) and np.array_equal(la, lb)
+    assert a[0].rng_state() == b[0].rng_state()
+    for c in range(2):
+        assert np.array_equal(a[0].state(c).hypo, b[0].state(c).hypo)
+        assert a[0].state(c).temp == b[0].state(c).temp

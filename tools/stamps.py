@@ -17,14 +17,24 @@ data = synth.make_synthetic(1000, 64, 1)
 params = dict(synth.DEFAULT_PARAMS, n_procs=1, n_chains=nc, n_cool=1, n_iter=10**7, n_burn=10**9, n_interval=1000)
 obs = ObsData.from_arrays(data.sta_x, data.sta_y, data.t_obs, data.t_stdv, data.a_obs, data.a_stdv)
 fwd, cs = driver.build_rank(params, data.sta_x, data.sta_y, data.sta_z, obs, 0, n_procs=1)
-cs.run(2000)
+LOCK = len(sys.argv) > 2 and sys.argv[2] == "lockstep"
+if LOCK:
+    from hypotremormcmc_amd.parallel import LocalWorld
+    world = LocalWorld([cs])
+    run = world.run
+else:
+    run = cs.run
+run(2000)
 lib = _lib.load()
 lib.htm_chains_read_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
 a = (C.c_uint64 * 128)()
 lib.htm_chains_read_stamps(cs.handle, a)
 base = list(a)
 n = 10000
-cs.run(n)
+import time
+t0 = time.perf_counter()
+run(n)
+print("wall us/iter", 1e6 * (time.perf_counter() - t0) / n)
 lib.htm_chains_read_stamps(cs.handle, a)
 names = ["prologue", "P0 (resume judge + window)", "passes (propose+partial+decide+commit)", "validate/records/swap roles",
          "post (swap apply, records)", "epilogue", "hand-over to workers (wait+judge)"]
