@@ -656,7 +656,7 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
     // per LDS ring position: U, LOGU, pg, pr, plogr (5 doubles), dec, sw (int4), hop (kHops ints)
     hc->step_smem = ((sizeof(StepShared) + 15) & ~size_t(15)) +
                     (size_t)hc->ring_size * (5 * sizeof(double) + 2 * sizeof(int4) + kHops * sizeof(int)) +
-                    3 * (size_t)h->S * sizeof(double);
+                    3 * (size_t)h->S * sizeof(double) + kGathStage * sizeof(double);
     if (hc->step_smem > 150 * 1024) return cleanup(fail(HTM_EINVAL, "n_chains / n_sta too large for k_step's LDS budget"));
     if (hc->step_smem > 48 * 1024) {
         const void *fn = h->nch == 1 ? (const void *)k_step<1> : h->nch == 2 ? (const void *)k_step<2> : (const void *)k_step<0>;

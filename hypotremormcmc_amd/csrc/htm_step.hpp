@@ -22,6 +22,8 @@
 
 namespace htm {
 
+constexpr int kGathStage = 512;   // doubles of LDS for the gathered swap records (else they are read in place)
+
 struct StepShared {
     Proposal prop[kMaxChains];
     double temp[kMaxChains], L[kMaxChains];
@@ -35,6 +37,8 @@ struct StepShared {
     unsigned long long done_base; // PSync::done when this launch started
     int jobs;                     // full-evaluation jobs published in this launch
     long long origin;             // absolute stream position of relative position 0 (= spos at launch)
+    long long hop_end;            // StreamDev::hop_end when this launch started
+    unsigned long long ticket;    // k_mcmc: this block's arrival ticket (launch index = ticket / blocks per launch)
     int avail;                    // the produced stream covers relative positions < avail
     int fill;                     // the LDS ring holds relative positions < fill
     int base;                     // relative position at which the current iteration starts
@@ -522,8 +526,7 @@ __device__ __forceinline__ void apply_swap(const ChainsDev &cs, StepShared &sh, 
 // as its own launch (fallback path, also used for profiling the two stages separately).
 template <int NCH, bool PERSIST>
 __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, int mode, int target_arg,
-                                          const double *gathered, int ring_size, int wmax,
-                                          unsigned long long launch)
+                                          const double *gathered, int ring_size, int wmax)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     StepShared &sh = *reinterpret_cast<StepShared *>(smem);
@@ -541,6 +544,7 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
     double *s_sx = reinterpret_cast<double *>(carve);
     double *s_sy = s_sx + f.S;
     double *s_sz = s_sy + f.S;
+    double *s_gath = s_sz + f.S;                   // [kGathStage] the all-gathered swap records, staged
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -553,31 +557,47 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
     unsigned long long stamp_last_ = __builtin_amdgcn_s_memtime();
 #endif
 
-    if (tid == 0) {
-        sh.c = *cs.ctrl;
-        if (target_arg >= 0) sh.c.iter_target = target_arg;
-        else if (target_arg == -2) sh.c.iter_target = 0x7fffffff;   // lock-step graph replay: one iteration per launch
-        const long long he = *cs.stream.hop_end;
-        sh.origin = sh.c.spos;
-        const long long av = he - sh.c.spos;
-        sh.avail = av > (1 << 30) ? (1 << 30) : (int)av;
-        sh.fill = 0; sh.base = 0; sh.redo = -1; sh.sw_do = 0; sh.catchup = 0;
-        sh.jobs = 0;
+    // Everything the launch needs from memory is requested in ONE round of vector loads (a scalar load of the
+    // control block alone costs a cold K$ + L2 miss of its own): control block, stream coverage, station table,
+    // temperatures, gathered records.
+    {
+        const int vz0 = opaque_zero();
+        constexpr int kCtrlWords = (int)(sizeof(Ctrl) / sizeof(int));
+        if (tid < kCtrlWords) reinterpret_cast<int *>(&sh.c)[tid] = reinterpret_cast<const int *>(cs.ctrl)[tid + vz0];
+        if (tid == kCtrlWords) sh.hop_end = cs.stream.hop_end[vz0];
+        if (PERSIST && tid == kCtrlWords + 1)      // launch index: one ticket per block of the launch
+            sh.ticket = __hip_atomic_fetch_add(&cs.ps->arrive, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     for (int j = tid; j < f.S; j += blockDim.x) { s_sx[j] = f.sx[j]; s_sy[j] = f.sy[j]; s_sz[j] = f.sz[j]; }
     for (int c = tid; c < nc; c += blockDim.x) { sh.temp[c] = cs.temp[c]; sh.L[c] = cs.L[c]; }
     for (int k = tid; k < 7 * nc; k += blockDim.x) { sh.np[k] = 0; sh.na[k] = 0; }
+    // the gathered records of the previous lock-step iteration come in with the same round of loads
+    const bool do_apply = (mode == MODE_APPLY || mode == MODE_ADVANCE) && gathered != nullptr;
+    const int n_gath = cs.n_procs * (4 + 2 * nc);
+    const bool staged = do_apply && n_gath <= kGathStage;
+    if (staged)
+        for (int k = tid; k < n_gath; k += blockDim.x) s_gath[k] = gathered[k];
     __syncthreads();
+    const unsigned long long launch = PERSIST ? sh.ticket / (unsigned long long)(1 + cs.n_workers) : 0ull;
 
     // ---------------- swap of the previous lock-step iteration (cls_parallel.f90:118-213) --------------
     // MODE_APPLY does only this; MODE_ADVANCE does it first when the host passes the gathered records along
-    if ((mode == MODE_APPLY || mode == MODE_ADVANCE) && gathered != nullptr) {
-        if (tid == 0 && sh.c.stage == ST_WAIT_SWAP && sh.c.err == 0) {
-            apply_swap(cs, sh, gathered);
-            const long long av = *cs.stream.hop_end - sh.c.spos;
+    if (tid == 0) {
+        if (target_arg >= 0) sh.c.iter_target = target_arg;
+        else if (target_arg == -2) sh.c.iter_target = 0x7fffffff;   // lock-step graph replay: one iteration per launch
+        sh.origin = sh.c.spos;
+        const long long av = sh.hop_end - sh.c.spos;
+        sh.avail = av > (1 << 30) ? (1 << 30) : (int)av;
+        sh.fill = 0; sh.base = 0; sh.redo = -1; sh.sw_do = 0; sh.catchup = 0;
+        sh.jobs = 0;
+    }
+    {
+        if (do_apply && tid == 0 && sh.c.stage == ST_WAIT_SWAP && sh.c.err == 0) {
+            apply_swap(cs, sh, staged ? s_gath : gathered);
+            const int delta = (int)(sh.c.spos - sh.origin);     // rank1 consumed its judge_swap draw
             sh.origin = sh.c.spos;
-            sh.avail = av > (1 << 30) ? (1 << 30) : (int)av;
-            *cs.ctrl = sh.c;
+            sh.avail -= delta;
+            if (mode == MODE_APPLY) *cs.ctrl = sh.c;
         }
         __syncthreads();
     }
@@ -781,7 +801,7 @@ template <int NCH>
 __global__ __launch_bounds__(512) void k_step(FwdDev f, ChainsDev cs, int mode, int target_arg,
                                                const double *gathered, int ring_size, int wmax)
 {
-    step_body<NCH, false>(f, cs, mode, target_arg, gathered, ring_size, wmax, 0ull);
+    step_body<NCH, false>(f, cs, mode, target_arg, gathered, ring_size, wmax);
 }
 
 // Worker block of a k_mcmc launch: waits for work orders of its own launch and evaluates its event tile of
@@ -792,7 +812,7 @@ __global__ __launch_bounds__(512) void k_step(FwdDev f, ChainsDev cs, int mode, 
 // (the master drained its stores before publishing it).  Leaves when the master has finished (PSync::quit)
 // or after a bounded wait.
 template <int NCH>
-__device__ __forceinline__ void worker_body(const FwdDev &f, const ChainsDev &cs, unsigned long long launch)
+__device__ __forceinline__ void worker_body(const FwdDev &f, const ChainsDev &cs)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *s_red = reinterpret_cast<double *>(smem);          // [8]
@@ -818,6 +838,12 @@ __device__ __forceinline__ void worker_body(const FwdDev &f, const ChainsDev &cs
     }
 
     int *s_chain = reinterpret_cast<int *>(smem + 136);
+    // launch index: one ticket per block, requested together with the preloads above
+    unsigned long long *s_ticket = reinterpret_cast<unsigned long long *>(smem + 144);
+    if (tid == 0)
+        *s_ticket = __hip_atomic_fetch_add(&cs.ps->arrive, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const unsigned long long launch = *s_ticket / (unsigned long long)(1 + cs.n_workers);
     unsigned last_tag = 0;                 // wave 0, lane <-> chain: the last order of that chain served here
     for (;;) {
         if (wave == 0) {
@@ -938,19 +964,17 @@ template <int NCH>
 __global__ __launch_bounds__(512) void k_mcmc(FwdDev f, ChainsDev cs, int mode, int target_arg,
                                                const double *gathered, int ring_size, int wmax)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    unsigned long long *s_ticket = reinterpret_cast<unsigned long long *>(smem);
-    if (threadIdx.x == 0)
-        *s_ticket = __hip_atomic_fetch_add(&cs.ps->arrive, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const unsigned long long launch = *s_ticket / (unsigned long long)(1 + cs.n_workers);
-    __syncthreads();
     if (blockIdx.x == 0) {
-        step_body<NCH, true>(f, cs, mode, target_arg, gathered, ring_size, wmax, launch);
+        step_body<NCH, true>(f, cs, mode, target_arg, gathered, ring_size, wmax);
+        // every exit of the master comes through here (its returns are uniform over the block): release the workers
+        extern __shared__ __attribute__((aligned(16))) char smem[];
         __syncthreads();
-        if (threadIdx.x == 0) st_agent(&cs.ps->quit, launch + 1ull);    // releases the workers
+        if (threadIdx.x == 0) {
+            const unsigned long long launch = reinterpret_cast<const StepShared *>(smem)->ticket / (unsigned long long)(1 + cs.n_workers);
+            st_agent(&cs.ps->quit, launch + 1ull);
+        }
     } else {
-        worker_body<NCH>(f, cs, launch);
+        worker_body<NCH>(f, cs);
     }
 }
 
