@@ -95,11 +95,11 @@ def cpu_baseline(params, data, seconds_target=10.0):
     out = {"value": port, "unit": "proposal steps/s", "cores": 1, "kind": "port",
            "sample": f"{n_it} iterations x {n_chains} chains of the same {data.n_events}x{data.n_sta} workload "
                      f"on 1 core ({dt:.1f} s), oracle/htm_oracle.c (gcc -O2, no fast-math)"}
-    ref = _reference_baseline(params, data, 6300, 300)
+    ref = _reference_baseline(params, data, 18300, 300)
     if ref is not None:
         out = {"value": ref[0], "unit": "proposal steps/s", "cores": 1, "kind": "reference",
-               "sample": f"6000 iterations x {n_chains} chains of the same workload, 1 MPI rank, main loop only "
-                         f"({ref[1]:.1f} s; difference of a 6300- and a 300-iteration run), reference Fortran "
+               "sample": f"18000 iterations x {n_chains} chains of the same workload, 1 MPI rank, main loop only "
+                         f"({ref[1]:.1f} s; difference of an 18300- and a 300-iteration run), reference Fortran "
                          f"compiled unmodified with AMD flang -O2",
                "port_value": port, "port_sample": out["sample"]}
     return out
@@ -212,18 +212,34 @@ def main():
         n_launch = max(1, st["graph_launches"])
         bytes_region = st["full_evals"] * b_full + st["partial_evals"] * b_part
         achieved = bytes_region / (st["device_us"] * 1e-6) / 1e9
+        # HBM-side bytes per launch from the committed PMC passes (profiles/*_traffic.json: FETCH_SIZE doubled as
+        # MI355X_MICROARCH.md prescribes for gfx950 + WRITE_SIZE, per iteration) x the iterations of a launch
+        traffic, traffic_src = None, None
+        try:
+            import glob
+
+            tf_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+            if tf_files and persistent and (E, S, nc) == (N_EVENTS, N_STA, N_CHAINS):
+                with open(tf_files[-1]) as fh:
+                    tj = json.load(fh)
+                per_it = 2.0 * tj["fetch_bytes_per_iteration_raw"] + tj["write_bytes_per_iteration"]
+                traffic = per_it * args.steps / n_launch
+                traffic_src = os.path.relpath(tf_files[-1], ROOT)
+        except Exception:
+            traffic = None
         out["roofline"] = {
             "bound": "hbm",
             "kernel": "k_mcmc<1> (propose + partial/full log-likelihood + judge + swap, persistent)" if persistent
                       else "k_step<1> + k_full<1,false> (graph of the two-kernel path)",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": traffic, "traffic_source": traffic_src,
             "bytes_per_launch": bytes_region / n_launch, "avg_launch_us": st["device_us"] / n_launch,
             "launches": n_launch, "full_evals": st["full_evals"], "partial_evals": st["partial_evals"],
             "note": "algorithmic bytes = 2 074 568 B per full evaluation + 4 672 B per single-event partial update "
-                    "(SURVEY 8d); at 8 chains/GPU an iteration is a dependent chain of ~12 us that moves ~1.7 MB, "
-                    "so the workload is latency-bound, not HBM-bound (DESIGN.md 5); see roofline_batch64 for the "
-                    "full-evaluation kernel on its own",
+                    "(SURVEY 8d); at 8 chains/GPU an iteration is a dependent chain of ~8 us that touches ~1.7 MB, "
+                    "all of it L2/Infinity-Cache resident (traffic = HBM-side bytes per launch from the committed PMC "
+                    "passes, ~1 % of the algorithmic bytes): the workload is latency-bound, not HBM-bound (DESIGN.md 5); "
+                    "see roofline_batch64 for the full-evaluation kernel on its own",
         }
         # ---- the two stages timed separately (fallback two-kernel path, same arithmetic), HIP events per launch
         n_prof = min(4000, max(500, args.steps // 5))

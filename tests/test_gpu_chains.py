@@ -212,3 +212,12 @@ def test_rccl_lockstep_loop_equals_single_rank_driver_bitwise(graph, monkeypatch
     for c in range(2):
         assert np.array_equal(a[0].state(c).hypo, b[0].state(c).hypo)
         assert a[0].state(c).temp == b[0].state(c).temp
+
+
+def test_two_kernel_fallback_matches_reference_trace(monkeypatch):
+    """HTM_PERSIST=0: k_step + k_full as separate launches (hipGraph) instead of the persistent k_mcmc"""
+    monkeypatch.setenv("HTM_PERSIST", "0")
+    fx, data, params = load_case("c2")
+    fwd, sets = _build_world(data, params)
+    sets[0].run(int(params["n_iter"]))
+    _check_against_fixture(fx, params, sets)

@@ -1,0 +1,45 @@
+#!/bin/bash
+# Run ON THE GPU BOX (through gpurun): rocprofv3 summaries of the default bench for profiles/.
+#   tools/make_profiles.sh <tag>        e.g. r01_c  -> gpurun_out/<tag>_{kernel_stats.csv,pmc_summary.txt,bench.json}
+# Counter passes are separate runs with --kernel-trace only (MI355X_MICROARCH.md, HBM section).
+set -e
+TAG=${1:-r01_x}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+rm -rf "$OUT/prof_${TAG}_stats" "$OUT/prof_${TAG}_fetch" "$OUT/prof_${TAG}_write"
+rocprofv3 --kernel-trace --stats -d "$OUT/prof_${TAG}_stats" -o st --output-format csv -- python3 "$ROOT/bench.py" --no-cpu-baseline \
+    > "$OUT/${TAG}_bench_under_rocprof.json" 2> "$OUT/prof_${TAG}_stats.log"
+echo "stats pass done"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/prof_${TAG}_fetch" -o pf --output-format csv -- python3 "$ROOT/bench.py" --steps 4000 --warmup 500 --no-cpu-baseline \
+    > /dev/null 2> "$OUT/prof_${TAG}_fetch.log"
+echo "fetch pass done"
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/prof_${TAG}_write" -o pw --output-format csv -- python3 "$ROOT/bench.py" --steps 4000 --warmup 500 --no-cpu-baseline \
+    > /dev/null 2> "$OUT/prof_${TAG}_write.log"
+echo "write pass done"
+python3 "$ROOT/bench.py" > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
+python3 - "$OUT" "$TAG" <<'PY'
+import csv, glob, os, sys, collections
+out, tag = sys.argv[1], sys.argv[2]
+st = glob.glob(os.path.join(out, f"prof_{tag}_stats", "**", "*kernel_stats.csv"), recursive=True)
+if st:
+    open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w").write(open(st[0]).read())
+lines = [f"# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace -- python3 bench.py --steps 4000 --warmup 500 --no-cpu-baseline",
+         "# per dispatch, KB as rocprofv3 reports them (raw; gfx950: FETCH_SIZE counts 64 B per 128-B request of wide coalesced reads)",
+         "%-34s %-11s %7s %14s %12s %14s" % ("kernel", "counter", "count", "mean", "min", "max")]
+for sub, cname in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    agg = collections.defaultdict(list)
+    for fn in glob.glob(os.path.join(out, f"prof_{tag}_{sub}", "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(fn)):
+            if row.get("Counter_Name") == cname:
+                k = row["Kernel_Name"].split("(")[0].replace("void ", "")
+                agg[k].append(float(row["Counter_Value"]))
+    for k in sorted(agg):
+        v = agg[k]
+        lines.append("%-34s %-11s %7d %14.3f %12.3f %14.3f" % (k[:34], cname, len(v), sum(v) / len(v), min(v), max(v)))
+open(os.path.join(out, f"{tag}_pmc_summary.txt"), "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
+PY
+cat "$OUT/${TAG}_kernel_stats.csv"
+cat "$OUT/${TAG}_bench.json"
