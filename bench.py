@@ -95,11 +95,11 @@ def cpu_baseline(params, data, seconds_target=10.0):
     out = {"value": port, "unit": "proposal steps/s", "cores": 1, "kind": "port",
            "sample": f"{n_it} iterations x {n_chains} chains of the same {data.n_events}x{data.n_sta} workload "
                      f"on 1 core ({dt:.1f} s), oracle/htm_oracle.c (gcc -O2, no fast-math)"}
-    ref = _reference_baseline(params, data, 18300, 300)
+    ref = _reference_baseline(params, data, 36300, 300)
     if ref is not None:
         out = {"value": ref[0], "unit": "proposal steps/s", "cores": 1, "kind": "reference",
-               "sample": f"18000 iterations x {n_chains} chains of the same workload, 1 MPI rank, main loop only "
-                         f"({ref[1]:.1f} s; difference of an 18300- and a 300-iteration run), reference Fortran "
+               "sample": f"36000 iterations x {n_chains} chains of the same workload, 1 MPI rank, main loop only "
+                         f"({ref[1]:.1f} s; difference of a 36300- and a 300-iteration run), reference Fortran "
                          f"compiled unmodified with AMD flang -O2",
                "port_value": port, "port_sample": out["sample"]}
     return out
