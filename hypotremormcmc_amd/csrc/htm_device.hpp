@@ -100,6 +100,15 @@ struct FwdDev {
     double const_sum;   // sum over used data types of sum_{j,i} (log_2pi_half + log_stdv(j,i))
 };
 
+// Immutable inputs (priors, step sizes, precision sums) at a wave-uniform address: a load through the constant
+// address space is selected as a SCALAR load (K$), which costs no vector-memory slot and no VGPR.  Only for data
+// no kernel ever writes.
+template <class T>
+__device__ __forceinline__ T ld_const(const T *p)
+{
+    typedef const T __attribute__((address_space(4))) *CP;
+    return *(CP)(unsigned long long)p;
+}
 template <int NCH>
 struct StaRegs {
     double sx[NCH], sy[NCH], sz[NCH], tc[NCH], ac[NCH];
@@ -131,8 +140,8 @@ __device__ __forceinline__ void load_obs_regs(ObsRegs<NCH> &ob, const FwdDev &f,
             if (f.use_amp)  { ob.aob[c] = f.a_obs[base + j]; ob.apr[c] = f.a_prec[base + j]; }
         }
     }
-    ob.pst = f.use_time ? f.psum_t[ev] : 1.0;
-    ob.psa = f.use_amp ? f.psum_a[ev] : 1.0;
+    ob.pst = f.use_time ? ld_const(f.psum_t + ev) : 1.0;      // wave-uniform: scalar loads
+    ob.psa = f.use_amp ? ld_const(f.psum_a + ev) : 1.0;
 }
 
 template <int NCH, int NPOS>
@@ -313,14 +322,14 @@ struct PSync {
 
 // Work orders of the persistent kernel as tagged 8-byte granules {tag : 32, payload : 32} (agent-scope
 // stores/loads; the data is the flag: a granule is valid for job `tag` iff its upper half equals `tag`).
-// Every chain has its own order slot and publishes it by itself, as soon as its proposal is known.
-constexpr int kGranPerEntry = 8;       // type, idx, x_new (2), beta (2), q (2), spare
-struct GDesc {
-    // board[c] = (launch << 32) | tag of chain c's latest order; written last, after the owning chain wave has
-    // drained its entry granules and its chain-state stores.  One or two 128-B lines: the workers poll only this.
-    unsigned long long board[kMaxChains];
-    unsigned long long e[kMaxChains][16];      // chain c's order: kGranPerEntry granules
-};
+// Every chain has its own order slot and publishes it by itself, as soon as its proposal is known.  A slot is
+// the whole order, so a worker learns everything with the poll that discovers it:
+//   g0 {tag, launch (low 32 bits)}   g1 {tag, type | element << 3}   g2 {tag, x_new high}   g3 {tag, x_new low}
+// (vs and qs of the evaluated model are chain state unless they are the proposal).  The slots are replicated
+// ChainsDev::slot_rep times, slot_stride words apart (different memory channels), and worker w polls replica
+// w % slot_rep: every poll is served by the memory side, so the pollers of one line queue up behind each other.
+constexpr int kGranPerSlot = 4;
+constexpr int kMaxSlotReplicas = 16;
 
 struct Ctrl {
     int iter_done, iter_target, stage, n_full;
@@ -352,6 +361,11 @@ struct ChainsDev {
     int n_chains, n_procs, rank;
     int S, E;
     ModelDev hypo, tc, vs, ac, qs;
+    // The five groups are carved out of ONE allocation per field, in proposal-type order
+    // [vs | t_corr | qs | a_corr | hypo], so that the element a step perturbs is base + integer offset
+    // (scalar arithmetic) instead of a five-way choice between pointers.
+    double *xall, *muall, *sgall, *stall;
+    int32_t *ptall;
     double *temp, *L;                // [n_chains]
     int32_t *n_propose, *n_accept;   // [n_chains][7]
     double th1, th2, th3, th4;       // cumulative proposal thresholds, cls_mcmc.f90:139-153
@@ -368,8 +382,11 @@ struct ChainsDev {
     int32_t *slog_i; double *slog_d;
     double *swap_rec;                // [4 + 2*n_chains] this rank's record (8-byte words)
     PSync *ps;                       // persistent-worker hand-shake (k_mcmc)
-    GDesc *gdesc;                    // work order, tagged granules
-    unsigned long long *pgran;       // [n_chains][n_workers][2] partial sums, tagged granules (hi, lo)
+    unsigned long long *slots;       // order slots: replica r, chain c, granule g at [r*slot_stride + c*4 + g]
+    int slot_rep, slot_stride;       // replicas (<= kMaxSlotReplicas), words between replicas
+    unsigned long long *pgran;       // partial sums, tagged granules: chain c, worker k at [(c*n_workers + k)*pgran_stride + {0,1}]
+    int pgran_stride;                // words between the granule pairs of two workers (>= 2)
+    int npoll;                       // worker polls kept in flight (1..3)
     int n_workers;                   // worker blocks of a k_mcmc launch
     StreamDev stream;
     unsigned long long *stamps;      // diagnostic builds (-DHTM_STAMPS) only, else nullptr

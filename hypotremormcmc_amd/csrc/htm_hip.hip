@@ -523,20 +523,22 @@ int htm_forward_time_full_batch_dev(htm_forward *h, int n_models, const double *
 // ---------------------------------------------------------------------------------------------------
 // chains
 // ---------------------------------------------------------------------------------------------------
-static int upload_model(htm_chains *hc, ModelDev &m, const htm_model_init &in, int nx, int nc, const char *name)
+// one group of the rank's parameter vector: a window [off, off + nx*nc) of the five per-field allocations
+static int upload_model(htm_chains *hc, ModelDev &m, const htm_model_init &in, int nx, int nc, size_t off, const char *name)
 {
     if (!in.x) return fail(HTM_EINVAL, "%s.x is NULL", name);
     const size_t n = (size_t)nx * nc;
     std::vector<double> zeros(n, 0.0);
     std::vector<double> ones(n, 1.0);
     std::vector<int32_t> izeros(n, 0);
-    int rc;
+    const ChainsDev &d = hc->dev;
     m.nx = nx;
-    if ((rc = dev_upload(hc->pool, &m.x, in.x, n))) return rc;
-    if ((rc = dev_upload(hc->pool, &m.mu, in.mu ? in.mu : zeros.data(), n))) return rc;
-    if ((rc = dev_upload(hc->pool, &m.sigma, in.sigma ? in.sigma : ones.data(), n))) return rc;
-    if ((rc = dev_upload(hc->pool, &m.step, in.step_size ? in.step_size : zeros.data(), n))) return rc;
-    if ((rc = dev_upload(hc->pool, &m.ptype, in.prior_type ? in.prior_type : izeros.data(), n))) return rc;
+    m.x = d.xall + off; m.mu = d.muall + off; m.sigma = d.sgall + off; m.step = d.stall + off; m.ptype = d.ptall + off;
+    HIPCHK(hipMemcpy(m.x, in.x, n * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(m.mu, in.mu ? in.mu : zeros.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(m.sigma, in.sigma ? in.sigma : ones.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(m.step, in.step_size ? in.step_size : zeros.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(m.ptype, in.prior_type ? in.prior_type : izeros.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
     return HTM_OK;
 }
 
@@ -560,11 +562,19 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
     int rc;
     ChainsDev &d = hc->dev;
     d.n_chains = nc; d.n_procs = init->n_procs; d.rank = init->rank; d.S = h->S; d.E = h->E;
-    if ((rc = upload_model(hc, d.hypo, init->hypo, 3 * h->E, nc, "hypo"))) return cleanup(rc);
-    if ((rc = upload_model(hc, d.tc, init->t_corr, h->S, nc, "t_corr"))) return cleanup(rc);
-    if ((rc = upload_model(hc, d.vs, init->vs, 1, nc, "vs"))) return cleanup(rc);
-    if ((rc = upload_model(hc, d.ac, init->a_corr, h->S, nc, "a_corr"))) return cleanup(rc);
-    if ((rc = upload_model(hc, d.qs, init->qs, 1, nc, "qs"))) return cleanup(rc);
+    {
+        // [vs | t_corr | qs | a_corr | hypo], the order of the proposal types (chain_pass computes these offsets too)
+        const size_t S = (size_t)h->S, E = (size_t)h->E, n = (size_t)nc;
+        const size_t total = 2 * n + 2 * n * S + 3 * E * n;
+        if ((rc = dev_alloc(hc->pool, &d.xall, total)) || (rc = dev_alloc(hc->pool, &d.muall, total)) ||
+            (rc = dev_alloc(hc->pool, &d.sgall, total)) || (rc = dev_alloc(hc->pool, &d.stall, total)) ||
+            (rc = dev_alloc(hc->pool, &d.ptall, total))) return cleanup(rc);
+        if ((rc = upload_model(hc, d.vs, init->vs, 1, nc, 0, "vs"))) return cleanup(rc);
+        if ((rc = upload_model(hc, d.tc, init->t_corr, h->S, nc, n, "t_corr"))) return cleanup(rc);
+        if ((rc = upload_model(hc, d.qs, init->qs, 1, nc, n + n * S, "qs"))) return cleanup(rc);
+        if ((rc = upload_model(hc, d.ac, init->a_corr, h->S, nc, 2 * n + n * S, "a_corr"))) return cleanup(rc);
+        if ((rc = upload_model(hc, d.hypo, init->hypo, 3 * h->E, nc, 2 * n + 2 * n * S, "hypo"))) return cleanup(rc);
+    }
     if ((rc = dev_upload(hc->pool, &d.temp, init->temp, nc))) return cleanup(rc);
     std::vector<double> L0(nc, -9.e+300);   // cls_mcmc.f90:88
     if ((rc = dev_upload(hc->pool, &d.L, L0.data(), nc))) return cleanup(rc);
@@ -584,10 +594,22 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
     if ((rc = dev_alloc(hc->pool, &d.partial, (size_t)nc * std::max(h->n_wg, d.n_workers)))) return cleanup(rc);
     if ((rc = dev_alloc(hc->pool, &d.ps, 1))) return cleanup(rc);
     HIPCHK(hipMemset(d.ps, 0, sizeof(PSync)));
-    if ((rc = dev_alloc(hc->pool, &d.gdesc, 1))) return cleanup(rc);
-    HIPCHK(hipMemset(d.gdesc, 0, sizeof(GDesc)));
-    if ((rc = dev_alloc(hc->pool, &d.pgran, (size_t)nc * d.n_workers * 2))) return cleanup(rc);
-    HIPCHK(hipMemset(d.pgran, 0, (size_t)nc * d.n_workers * 2 * sizeof(unsigned long long)));
+    {
+        // hand-off geometry (tuning knobs; defaults measured on MI355X)
+        auto env_int = [](const char *name, int dflt, int lo, int hi) {
+            const char *e = getenv(name);
+            const int v = e ? atoi(e) : dflt;
+            return std::max(lo, std::min(hi, v));
+        };
+        d.slot_rep = env_int("HTM_SLOT_REPLICAS", 8, 1, kMaxSlotReplicas);
+        d.slot_stride = env_int("HTM_SLOT_STRIDE", 4096, kMaxChains * kGranPerSlot * 8, 1 << 22) / 8;     // bytes -> words
+        d.pgran_stride = env_int("HTM_PGRAN_STRIDE", 16, 16, 4096) / 8;
+        d.npoll = env_int("HTM_NPOLL", 1, 1, 3);
+    }
+    if ((rc = dev_alloc(hc->pool, &d.slots, (size_t)d.slot_rep * d.slot_stride))) return cleanup(rc);
+    HIPCHK(hipMemset(d.slots, 0, (size_t)d.slot_rep * d.slot_stride * sizeof(unsigned long long)));
+    if ((rc = dev_alloc(hc->pool, &d.pgran, (size_t)nc * d.n_workers * d.pgran_stride))) return cleanup(rc);
+    HIPCHK(hipMemset(d.pgran, 0, (size_t)nc * d.n_workers * d.pgran_stride * sizeof(unsigned long long)));
     {
         const char *env = getenv("HTM_PERSIST");
         hc->persist = !(env && env[0] == '0');

@@ -142,6 +142,15 @@ __device__ __forceinline__ int opaque_zero()
 }
 __device__ __forceinline__ double ld_state(const double *p, int vz) { return p[vz]; }
 
+// lane l of a double, as a wave-uniform value
+__device__ __forceinline__ double rl_f64(double v, int l)
+{
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)b >> 32), l);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 // agent-scope relaxed accesses: sc1 write-through stores / L1-bypassing loads (MI355X_MICROARCH.md,
 // inter-workgroup visibility).  Used for everything another workgroup of the same launch reads or writes.
 __device__ __forceinline__ void st_agent(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -201,32 +210,43 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
     const bool stamp_me = cs.stamps && lane == 0 && c == cs.n_chains - 1;
     unsigned long long t_last = __builtin_amdgcn_s_memtime();
 #endif
-    const int vz = opaque_zero();
+    p = __builtin_amdgcn_readfirstlane(p);
     const int4 dec = rg.dec[p & M];                 // decoded ahead of time (htm_stream.hpp)
-    const int type = dec.x, idx = dec.y, evt = dec.z;
+    // wave-uniform by construction: keep them in scalar registers (addresses and selects become SALU work)
+    const int type = __builtin_amdgcn_readfirstlane(dec.x), idx = __builtin_amdgcn_readfirstlane(dec.y);
+    const int evt = __builtin_amdgcn_readfirstlane(dec.z), dec_w = __builtin_amdgcn_readfirstlane(dec.w);
     const double g = rg.pg[p & M], r_ring = rg.pr[p & M], logr_ring = rg.plogr[p & M];
     const bool partial = evt > 0 && iter > 1;       // hypo_tremor_mcmc.f90:246
-    const ModelDev Mo = pick_model(cs, type);
-    const size_t o = (size_t)c * Mo.nx + idx;
-    // every global load of the step is issued here, before any dependent arithmetic
-    const double x_old = ld_state(Mo.x + o, vz), mu = Mo.mu[o], sigma = Mo.sigma[o], step = Mo.step[o];
-    const int ptype = Mo.ptype[o];
-    double hx = 0.0, hy = 0.0, hz = 0.0, beta = 1.0, q = 1.0;
+    const int nc_ = cs.n_chains, S_ = cs.S, nh = cs.hypo.nx;
+    const int off_tc = nc_, off_qs = nc_ + nc_ * S_, off_ac = 2 * nc_ + nc_ * S_, off_hy = 2 * nc_ + 2 * nc_ * S_;
+    const int goff = type == 1 ? 0 : type == 2 ? off_tc : type == 3 ? off_qs : type == 4 ? off_ac : off_hy;
+    const int gnx = (type == 1 || type == 3) ? 1 : (type == 2 || type == 4) ? S_ : nh;
+    const int o = goff + c * gnx + idx;             // element of the rank's parameter vector this step perturbs
     const int ev = partial ? evt - 1 : 0;
+    // every global load of the step is issued here, before any dependent arithmetic.  The mutable scalars
+    // (current value, event coordinates, vs, qs) come with ONE gathered vector load, lane k <- item k;
+    // the immutable ones (prior, step size) with scalar loads.
+    const int o_h = off_hy + c * nh + 3 * ev;
+    int goffs = o;
+    goffs = lane == 1 ? o_h : goffs; goffs = lane == 2 ? o_h + 1 : goffs; goffs = lane == 3 ? o_h + 2 : goffs;
+    goffs = lane == 4 ? c : goffs; goffs = lane == 5 ? off_qs + c : goffs;
+    const double gathered_v = cs.xall[goffs];
+    const double mu = ld_const(cs.muall + o), sigma = ld_const(cs.sgall + o), step = ld_const(cs.stall + o);
+    const int ptype = ld_const(cs.ptall + o);
     const double *tc = cs.tc.x + (size_t)c * cs.S, *ac = cs.ac.x + (size_t)c * cs.S;
     StaRegs<(NCH > 0 ? NCH : 1)> st;
     ObsRegs<(NCH > 0 ? NCH : 1)> ob;
     if (partial) {
-        const double *hyp = cs.hypo.x + (size_t)c * cs.hypo.nx + 3 * ev;
-        hx = ld_state(hyp, vz); hy = ld_state(hyp + 1, vz); hz = ld_state(hyp + 2, vz);
-        beta = ld_state(cs.vs.x + c, vz); q = ld_state(cs.qs.x + c, vz);
         if constexpr (NCH > 0) {
             load_sta_regs<NCH>(st, f.S, lane, s_sx, s_sy, s_sz, tc, ac, 0, -1, 0.0);
             load_obs_regs<NCH>(ob, f, ev, lane);      // in flight while the proposal is worked out
         }
     } else if constexpr (PERSIST) {
-        beta = ld_state(cs.vs.x + c, vz); q = ld_state(cs.qs.x + c, vz);   // go out with the work order
+        __builtin_amdgcn_s_setprio(2);      // this wave's step is the long pole of the iteration: issue first
     }
+    const double x_old = rl_f64(gathered_v, 0);
+    const double hx = rl_f64(gathered_v, 1), hy = rl_f64(gathered_v, 2), hz = rl_f64(gathered_v, 3);
+    const double beta = rl_f64(gathered_v, 4), q = rl_f64(gathered_v, 5);
     const double T = sh.temp[c], L_cur = sh.L[c];
     CSTAMP(0);   // decode + load issue
     const double x_new = x_old + g * step;                      // cls_model.f90:172
@@ -238,7 +258,7 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
         else lpr = lpr + log(x_new - mu) - log(x_old - mu);
     }
     const double r = ok ? r_ring : 0.0, logr = ok ? logr_ring : 0.0;
-    const int cnt = dec.w - 1 + ok;                             // the judge draw happens only if prior_ok
+    const int cnt = dec_w - 1 + ok;                             // the judge draw happens only if prior_ok
     CSTAMP(1);   // proposal arithmetic (waits for the model loads)
     // The wave that keeps the LDS window of the stream ahead issues those loads HERE: vector-memory results
     // return in issue order, so issued any earlier their HBM latency would sit in front of this step's loads.
@@ -264,48 +284,61 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
         } else {
             need_full = 1;
             if constexpr (PERSIST) {
-                // ---- work order: tag = ticket (unique over the life of the chain set), entry granules, then --
-                // ---- after this wave's stores (entry + every earlier commit of this chain) have drained -------
-                // ---- the board word that the workers poll ------------------------------------------------------
+                // ---- work order: tag = ticket (unique over the life of the chain set) ------------------------------
                 unsigned long long tk = 0;
                 if (lane == 0) tk = atomicAdd(&sh.c.jobs_total, 1ull) + 1ull;
                 const unsigned tag = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)tk);
-                if (lane == 0) {
-                    unsigned long long *ge = cs.gdesc->e[c];
-                    st_gran(ge + 0, tag, (unsigned)type); st_gran(ge + 1, tag, (unsigned)idx);
-                    st_gran_f64(ge + 2, tag, x_new);
-                    st_gran_f64(ge + 4, tag, type == 1 ? x_new : beta);
-                    st_gran_f64(ge + 6, tag, type == 3 ? x_new : q);
-                }
+                // every chain-state store of this wave (earlier commits, undo) must have landed before a worker
+                // can see the order: write-through stores, drained here; the order itself is one store
+                // instruction (lane -> replica, granule), and its granules carry the tag, so no flag follows
                 drain_vmem();
-                if (lane == 0) st_agent(&cs.gdesc->board[c], (launch << 32) | (unsigned long long)tag);
+                if (lane < cs.slot_rep * kGranPerSlot) {
+                    const int gi = lane & 3;
+                    const unsigned long long xb = (unsigned long long)__double_as_longlong(x_new);
+                    const unsigned pay = gi == 0 ? (unsigned)launch : gi == 1 ? ((unsigned)type | ((unsigned)idx << 3))
+                                       : gi == 2 ? (unsigned)(xb >> 32) : (unsigned)xb;
+                    st_gran(cs.slots + (size_t)(lane >> 2) * cs.slot_stride + c * kGranPerSlot + gi, tag, pay);
+                }
 #ifdef HTM_STAMPS
                 if (lane == 0 && cs.stamps) { atomicAdd(&cs.stamps[20], __builtin_amdgcn_s_memrealtime()); atomicAdd(&cs.stamps[26], 1ull); }
 #endif
-                // ---- the workers' partial sums: tagged granules, fixed summation order ------------------------
-                const unsigned long long *pg = cs.pgran + (size_t)c * cs.n_wg * 2;
+                __builtin_amdgcn_s_setprio(0);
+                // ---- the workers' partial sums: tagged granules, fixed summation order; two rounds of loads are
+                // ---- kept in flight so that a granule is seen at most half a round trip after it lands ----------
+                const unsigned long long *pg = cs.pgran + (size_t)c * cs.n_wg * cs.pgran_stride;
+                const int pgs = cs.pgran_stride;
                 double part = 0.0;
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz
-                constexpr int kSweep = 4;                 // <= 256 workers (host-checked); all sweeps in ONE round
-                unsigned long long hi[kSweep], lo[kSweep];
-                for (;;) {
-                    bool got = true;
+                constexpr int kSweep = 4;                 // <= 256 workers (host-checked)
+                unsigned long long hi[2][kSweep], lo[2][kSweep];
+                int which = 0;
+                auto issue = [&](int b) {
 #pragma unroll
                     for (int j = 0; j < kSweep; ++j) {
                         const int k = j * 64 + lane;
-                        hi[j] = 0; lo[j] = 0;
-                        if (k < cs.n_wg) { hi[j] = ld_agent(pg + 2 * k); lo[j] = ld_agent(pg + 2 * k + 1); }
+                        hi[b][j] = 0; lo[b][j] = 0;
+                        if (k < cs.n_wg) { hi[b][j] = ld_agent(pg + (size_t)pgs * k); lo[b][j] = ld_agent(pg + (size_t)pgs * k + 1); }
                     }
+                };
+                auto complete = [&](int b) {
+                    bool got = true;
 #pragma unroll
                     for (int j = 0; j < kSweep; ++j)
-                        if (j * 64 + lane < cs.n_wg) got = got && (unsigned)(hi[j] >> 32) == tag && (unsigned)(lo[j] >> 32) == tag;
-                    if (__all(got)) break;
+                        if (j * 64 + lane < cs.n_wg) got = got && (unsigned)(hi[b][j] >> 32) == tag && (unsigned)(lo[b][j] >> 32) == tag;
+                    return __all(got);
+                };
+                issue(0);
+                for (;;) {
+                    issue(1);
+                    if (complete(0)) { which = 0; break; }
+                    issue(0);
+                    if (complete(1)) { which = 1; break; }
                     if (__builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) { if (lane == 0) sh.c.err = -8; break; }
-                    __builtin_amdgcn_s_sleep(1);
                 }
 #pragma unroll
                 for (int j = 0; j < kSweep; ++j)            // fixed order: worker lane, lane + 64, ...
-                    if (j * 64 < cs.n_wg) part += (j * 64 + lane < cs.n_wg) ? gran_f64(hi[j], lo[j]) : 0.0;
+                    if (j * 64 < cs.n_wg)
+                        part += (j * 64 + lane < cs.n_wg) ? (which == 0 ? gran_f64(hi[0][j], lo[0][j]) : gran_f64(hi[1][j], lo[1][j])) : 0.0;
                 L_new = -wave_sum1(part) - f.const_sum;                  // cls_forward.f90:277-300
                 acc = metropolis(L_new, L_cur, T, lpr, r, logr) ? 1 : 0;
 #ifdef HTM_STAMPS
@@ -314,6 +347,7 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
             }
         }
     }
+    if constexpr (PERSIST) __builtin_amdgcn_s_setprio(0);
     if (lane == 0) {
         const int cool = (T < 1.0 + kEps) ? 1 : 0;
         Proposal &pr = sh.prop[c];
@@ -324,7 +358,7 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
         sh.start[c] = p; sh.cnt[c] = cnt;
         if (cool) sh.np[c * 7 + type - 1] += 1;                 // cls_mcmc.f90:186-189
         if (acc) {                                              // :207-219
-            st_agent(Mo.x + o, x_new);
+            st_agent(cs.xall + o, x_new);
             sh.L[c] = L_new;
             cs.L[c] = L_new;
             if (cool) sh.na[c * 7 + type - 1] += 1;
@@ -844,30 +878,71 @@ __device__ __forceinline__ void worker_body(const FwdDev &f, const ChainsDev &cs
         *s_ticket = __hip_atomic_fetch_add(&cs.ps->arrive, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const unsigned long long launch = *s_ticket / (unsigned long long)(1 + cs.n_workers);
-    unsigned last_tag = 0;                 // wave 0, lane <-> chain: the last order of that chain served here
+    // wave 0: lane 4k + g holds granule g of chain (16 j + k)'s slot; lane 4k remembers the last tag served
+    constexpr int kGroups = (kMaxChains + 15) / 16;
+    unsigned last_tag[kGroups];
+#pragma unroll
+    for (int j = 0; j < kGroups; ++j) last_tag[j] = 0;
+    unsigned *s_job = reinterpret_cast<unsigned *>(smem + 160);     // [0] type | idx << 3, [1] x_new high, [2] x_new low
+    const unsigned long long *slots = cs.slots + (size_t)(w % cs.slot_rep) * cs.slot_stride;
+    const int npoll = cs.npoll;
     for (;;) {
         if (wave == 0) {
-            // lanes <-> chains: the board is one or two 128-B lines, one request per poll
             unsigned tag = 0;
             int chain = -1;
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();          // 100 MHz
-            for (;;) {
-                // lanes < nc: the board; lane 63: the quit word -- one load instruction per poll
-                const unsigned long long *pa = lane < nc ? &cs.gdesc->board[lane] : &cs.ps->quit;
-                const unsigned long long x = (lane < nc || lane == 63) ? ld_agent(pa) : 0ull;
-                const bool fresh = lane < nc && (x >> 32) == launch && (unsigned)x != last_tag;
-                const unsigned long long mask = __ballot(fresh);
-                if (mask) {
-                    chain = __ffsll((long long)mask) - 1;
-                    tag = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)x, chain);
-                    if (lane == chain) last_tag = tag;
-                    break;
+            // one poll = the slots of all chains (one load per 16 chains) + the quit word; kPolls polls in flight
+            constexpr int kPolls = 3;
+            unsigned long long x[kPolls][kGroups], qw[kPolls];
+            auto issue = [&](int b) {
+#pragma unroll
+                for (int j = 0; j < kGroups; ++j) {
+                    x[b][j] = 0ull;
+                    if (16 * j < nc && 16 * j + (lane >> 2) < nc) x[b][j] = ld_agent(slots + (size_t)(16 * j) * kGranPerSlot + lane);
                 }
-                const unsigned qlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)x, 63);
-                const unsigned qhi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(x >> 32), 63);
-                if ((((unsigned long long)qhi << 32) | qlo) > launch) break;
-                if (__builtin_amdgcn_s_memrealtime() - t0 > 3000000000ull) break;    // never spin forever (30 s)
-                __builtin_amdgcn_s_sleep(1);
+                qw[b] = lane == 63 ? ld_agent(&cs.ps->quit) : 0ull;
+            };
+            // returns 1: an order was taken (tag, chain, s_job set), -1: the master has quit, 0: nothing yet
+            auto check = [&](int b) -> int {
+#pragma unroll
+                for (int j = 0; j < kGroups; ++j) {
+                    if (16 * j >= nc) continue;
+                    const unsigned t = (unsigned)(x[b][j] >> 32), pay = (unsigned)x[b][j];
+                    const unsigned t0q = (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0x00, 0xF, 0xF, false);   // quad_perm [0,0,0,0]
+                    bool ok = t == t0q && t != 0u && 16 * j + (lane >> 2) < nc;
+                    if ((lane & 3) == 0) ok = ok && pay == (unsigned)launch && t != last_tag[j];
+                    unsigned long long m = __ballot(ok);
+                    m = m & (m >> 1) & (m >> 2) & (m >> 3) & 0x1111111111111111ull;
+                    if (m) {
+                        const int l0 = __ffsll((long long)m) - 1;           // lane of granule 0 of the chosen chain
+                        chain = 16 * j + (l0 >> 2);
+                        tag = (unsigned)__builtin_amdgcn_readlane((int)t, l0);
+                        if (lane == l0) last_tag[j] = tag;
+                        const unsigned p1 = (unsigned)__builtin_amdgcn_readlane((int)pay, l0 + 1);
+                        const unsigned p2 = (unsigned)__builtin_amdgcn_readlane((int)pay, l0 + 2);
+                        const unsigned p3 = (unsigned)__builtin_amdgcn_readlane((int)pay, l0 + 3);
+                        if (lane == 0) { s_job[0] = p1; s_job[1] = p2; s_job[2] = p3; }
+                        return 1;
+                    }
+                }
+                const unsigned qlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)qw[b], 63);
+                const unsigned qhi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(qw[b] >> 32), 63);
+                return ((((unsigned long long)qhi << 32) | qlo) > launch) ? -1 : 0;
+            };
+#pragma unroll
+            for (int b = 0; b < kPolls; ++b) if (b < npoll) issue(b);
+            for (bool spin = true; spin;) {
+#pragma unroll
+                for (int b = 0; b < kPolls; ++b) {
+                    if (b >= npoll) continue;
+#ifdef HTM_STAMPS
+                    if (cs.stamps && w == 0 && lane == 0) cs.stamps[27] += 1;      // polls of worker 0
+#endif
+                    const int r = spin ? check(b) : 0;
+                    if (r != 0) spin = false;
+                    if (spin) issue(b);
+                }
+                if (spin && __builtin_amdgcn_s_memrealtime() - t0 > 3000000000ull) spin = false;   // never spin forever (30 s)
             }
             if (lane == 0) { *s_tag = tag; *s_chain = chain; }
         }
@@ -880,22 +955,12 @@ __device__ __forceinline__ void worker_body(const FwdDev &f, const ChainsDev &cs
         if (wstamp) cs.stamps[21] += __builtin_amdgcn_s_memrealtime();
 #endif
         {
-            // The order's granules were drained before the board word moved, so they are there; every wave reads
-            // them itself (lanes <-> granules) together with the chain state below -- one round trip in all.
-            unsigned long long gq = 0;
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            for (;;) {
-                if (lane < kGranPerEntry) gq = ld_agent(&cs.gdesc->e[m][lane]);
-                if (__all(lane >= kGranPerEntry || (unsigned)(gq >> 32) == tag)) break;
-                if (__builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) return;
-                __builtin_amdgcn_s_sleep(1);
-            }
-            unsigned long long e[kGranPerEntry];
-#pragma unroll
-            for (int qn = 0; qn < kGranPerEntry; ++qn)
-                e[qn] = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)gq, qn);
-            const int type = (int)e[0], idx = (int)e[1];
-            const double ov_val = gran_f64(e[2], e[3]), beta = gran_f64(e[4], e[5]), q = gran_f64(e[6], e[7]);
+            const int type = (int)(s_job[0] & 7u), idx = (int)(s_job[0] >> 3);
+            const double ov_val = __longlong_as_double((long long)(((unsigned long long)s_job[1] << 32) | s_job[2]));
+            // vs and qs of the evaluated model: chain state unless they are the proposal (same round of loads as
+            // the corrections and the event coordinates below)
+            const double beta_c = ld_agent(cs.vs.x + m), q_c = ld_agent(cs.qs.x + m);
+            const double beta = type == 1 ? ov_val : beta_c, q = type == 3 ? ov_val : q_c;
             int ov_kind = 0, ov_idx = -1, ov_evt = -1, ov_cmp = 0;
             if (type == 2 || type == 4) { ov_kind = type; ov_idx = idx; }
             else if (type >= 5) { ov_evt = idx / 3; ov_cmp = idx - 3 * ov_evt; }
@@ -952,7 +1017,7 @@ __device__ __forceinline__ void worker_body(const FwdDev &f, const ChainsDev &cs
             if (wstamp) cs.stamps[23] += __builtin_amdgcn_s_memrealtime();
 #endif
             if (tid == 0)
-                st_gran_f64(cs.pgran + ((size_t)m * cs.n_wg + w) * 2, tag,
+                st_gran_f64(cs.pgran + ((size_t)m * cs.n_wg + w) * cs.pgran_stride, tag,
                             ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) + ((s_red[4] + s_red[5]) + (s_red[6] + s_red[7])));
             __syncthreads();
         }

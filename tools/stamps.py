@@ -59,6 +59,7 @@ if jobs:
     print("    ... -> worker 0 first model reduced      %7.1f ns" % (10 * (d(22) - d(21))))
     print("    ... -> worker 0 last model combined      %7.1f ns" % (10 * (d(23) - d(22))))
     print("    ... -> master has all partials + judged  %7.1f ns" % (10 * (d(25) - d(23))))
+    print("    polls of worker 0: %d  (one per %.0f ns of device time)" % (a[27] - base[27], 1e3 * 0 + 0))
     print("    publish -> master done                   %7.1f ns" % (10 * (d(25) - d(20))))
 st = cs.last_run_stats()
 print("total ticks/iter", tot / n, " device_us/iter", st["device_us"] / n, st)
