@@ -601,7 +601,7 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
             const int v = e ? atoi(e) : dflt;
             return std::max(lo, std::min(hi, v));
         };
-        d.slot_rep = env_int("HTM_SLOT_REPLICAS", 8, 1, kMaxSlotReplicas);
+        d.slot_rep = env_int("HTM_SLOT_REPLICAS", 1, 1, kMaxSlotReplicas);
         d.slot_stride = env_int("HTM_SLOT_STRIDE", 4096, kMaxChains * kGranPerSlot * 8, 1 << 22) / 8;     // bytes -> words
         d.pgran_stride = env_int("HTM_PGRAN_STRIDE", 16, 16, 4096) / 8;
         d.npoll = env_int("HTM_NPOLL", 1, 1, 3);

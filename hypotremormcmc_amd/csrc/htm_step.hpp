@@ -31,6 +31,8 @@ struct StepShared {
     int start_fix[kMaxChains];    // corrected starts for a repeat pass (written by wave 0)
     int cnt[kMaxChains];          // draws the step consumed (judge draw included iff prior_ok)
     int slot_l[kMaxChains], slot_s[kMaxChains];
+    int pre_p[kMaxChains];        // >= 0: chain's next step, starting at this position, already has its order out
+    unsigned pre_tag[kMaxChains]; // ... under this tag (k_mcmc, role P)
     int np[kMaxChains * 7], na[kMaxChains * 7];   // proposal / acceptance counters of this launch
     int sw_do, sw_c1, sw_c2;      // swap decided between the barriers; applied by the waves owning the chains
     double sw_T1, sw_T2;          // new temperatures of chains sw_c1 / sw_c2
@@ -207,10 +209,11 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
 {
     const int M = rg.mask;
 #ifdef HTM_STAMPS
-    const bool stamp_me = cs.stamps && lane == 0 && c == cs.n_chains - 1;
+    const bool stamp_me = cs.stamps && lane == 0 && c == 0;
     unsigned long long t_last = __builtin_amdgcn_s_memtime();
 #endif
     p = __builtin_amdgcn_readfirstlane(p);
+    if constexpr (PERSIST) drain_vmem();            // this wave's commits of earlier iterations have landed (role P relies on it)
     const int4 dec = rg.dec[p & M];                 // decoded ahead of time (htm_stream.hpp)
     // wave-uniform by construction: keep them in scalar registers (addresses and selects become SALU work)
     const int type = __builtin_amdgcn_readfirstlane(dec.x), idx = __builtin_amdgcn_readfirstlane(dec.y);
@@ -285,14 +288,15 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
             need_full = 1;
             if constexpr (PERSIST) {
                 // ---- work order: tag = ticket (unique over the life of the chain set) ------------------------------
+                const bool pre = sh.pre_p[c] == p;         // role P of the previous iteration sent it already
                 unsigned long long tk = 0;
-                if (lane == 0) tk = atomicAdd(&sh.c.jobs_total, 1ull) + 1ull;
+                if (lane == 0) { tk = pre ? (unsigned long long)sh.pre_tag[c] : atomicAdd(&sh.c.jobs_total, 1ull) + 1ull; sh.pre_p[c] = -1; }
                 const unsigned tag = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)tk);
                 // every chain-state store of this wave (earlier commits, undo) must have landed before a worker
                 // can see the order: write-through stores, drained here; the order itself is one store
                 // instruction (lane -> replica, granule), and its granules carry the tag, so no flag follows
                 drain_vmem();
-                if (lane < cs.slot_rep * kGranPerSlot) {
+                if (!pre && lane < cs.slot_rep * kGranPerSlot) {
                     const int gi = lane & 3;
                     const unsigned long long xb = (unsigned long long)__double_as_longlong(x_new);
                     const unsigned pay = gi == 0 ? (unsigned)launch : gi == 1 ? ((unsigned)type | ((unsigned)idx << 3))
@@ -300,7 +304,7 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
                     st_gran(cs.slots + (size_t)(lane >> 2) * cs.slot_stride + c * kGranPerSlot + gi, tag, pay);
                 }
 #ifdef HTM_STAMPS
-                if (lane == 0 && cs.stamps) { atomicAdd(&cs.stamps[20], __builtin_amdgcn_s_memrealtime()); atomicAdd(&cs.stamps[26], 1ull); }
+                if (lane == 0 && cs.stamps) { atomicAdd(&cs.stamps[20], __builtin_amdgcn_s_memrealtime()); atomicAdd(&cs.stamps[26], 1ull); if (pre) atomicAdd(&cs.stamps[28], 1ull); }
 #endif
                 __builtin_amdgcn_s_setprio(0);
                 // ---- the workers' partial sums: tagged granules, fixed summation order; two rounds of loads are
@@ -484,6 +488,47 @@ __device__ __forceinline__ bool swap_plan(const ChainsDev &cs, const StepShared 
     return true;
 }
 
+// role P (k_mcmc), lanes <-> chains: the next iteration's steps are already decoded in the stream window, so a
+// chain whose NEXT step needs the full evaluation (types 1..4) can have its order out now -- one roles phase,
+// one post phase and one step front (~2 us) before its own wave would send it.  Only for chains that did not
+// commit in this iteration: their state stores have provably landed (every wave drains at the top of its pass).
+// The chain wave recognises the order by its start position and goes straight to collecting the partial sums.
+__device__ __forceinline__ void role_prepublish(const ChainsDev &cs, StepShared &sh, const Ring &rg, int iter, int pos,
+                                                int wmax, unsigned long long launch, int lane)
+{
+    const int nc = cs.n_chains, M = rg.mask;
+    if (iter + 1 > sh.c.iter_target || sh.fill < pos + wmax) return;      // no next iteration here / window not there yet
+    const bool in = lane < nc && lane <= kHops;
+    const int c = in ? lane : 0;
+    const int p = c == 0 ? pos : pos + rg.hop[(pos & M) * kHops + c - 1];
+    const int4 dec = rg.dec[p & M];
+    const int type = dec.x, idx = dec.y;
+    bool job = in && type >= 1 && type <= 4 && sh.prop[c].accepted == 0;
+    if (job) {
+        const int S_ = cs.S;
+        const int goff = type == 1 ? 0 : type == 2 ? nc : type == 3 ? nc + nc * S_ : 2 * nc + nc * S_;
+        const int gnx = (type == 1 || type == 3) ? 1 : S_;
+        const int o = goff + c * gnx + idx;
+        const double x_old = cs.xall[o], step = cs.stall[o], mu = cs.muall[o];
+        const int ptype = cs.ptall[o];
+        const double x_new = x_old + rg.pg[p & M] * step;               // cls_model.f90:172, as chain_pass computes it
+        if (ptype == 1 && x_new <= mu) job = false;                     // prior rejects: no evaluation (:178-187)
+        if (job) {
+            const unsigned tag = (unsigned)(atomicAdd(&sh.c.jobs_total, 1ull) + 1ull);
+            const unsigned long long xb = (unsigned long long)__double_as_longlong(x_new);
+            for (int r = 0; r < cs.slot_rep; ++r) {
+                unsigned long long *sl = cs.slots + (size_t)r * cs.slot_stride + c * kGranPerSlot;
+                st_gran(sl + 0, tag, (unsigned)launch);
+                st_gran(sl + 1, tag, (unsigned)type | ((unsigned)idx << 3));
+                st_gran(sl + 2, tag, (unsigned)(xb >> 32));
+                st_gran(sl + 3, tag, (unsigned)xb);
+            }
+            sh.pre_tag[c] = tag;
+        }
+    }
+    if (lane < nc) sh.pre_p[lane] = job ? p : -1;
+}
+
 // chain wave, after the second barrier: this iteration's swap (if it touches chain c) and its records
 __device__ __forceinline__ void post_chain(const ChainsDev &cs, StepShared &sh, int c, int iter, int lane)
 {
@@ -587,6 +632,7 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
     const bool lockstep = (mode != MODE_RUN);
     // helper roles between the barriers: validation+bookkeeping on wave 0, records and swap on other waves
     const int wave_R = NW > 1 ? 1 : 0, wave_W = NW > 2 ? 2 : 0, wave_P = NW - 1;   // wave_P extends the window
+    const int wave_Q = NW > 3 ? 3 : 0;             // role P: orders of the NEXT iteration's full evaluations
 #ifdef HTM_STAMPS
     unsigned long long stamp_last_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -625,6 +671,7 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
         sh.fill = 0; sh.base = 0; sh.redo = -1; sh.sw_do = 0; sh.catchup = 0;
         sh.jobs = 0;
     }
+    for (int c = tid; c < kMaxChains; c += blockDim.x) sh.pre_p[c] = -1;
     {
         if (do_apply && tid == 0 && sh.c.stage == ST_WAIT_SWAP && sh.c.err == 0) {
             apply_swap(cs, sh, staged ? s_gath : gathered);
@@ -735,7 +782,7 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
 #endif
                 __syncthreads();                                            // ---- barrier A
                 STAMP(2);   // passes
-                if (wave == 0 || wave == wave_R || wave == wave_W) {
+                if (wave == 0 || wave == wave_R || wave == wave_W || (PERSIST && wave == wave_Q)) {
                     const Valid v = validate<PERSIST>(sh, nc, lane);
                     int pos = 0, i1, i2;
                     double sr, slr;
@@ -781,6 +828,8 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
                             }
                         }
                     }
+                    if (PERSIST && wave == wave_Q && done && !lockstep)
+                        role_prepublish(cs, sh, rg, iter, pos, wmax, launch, lane);
                     if (wave == wave_R && done) role_records(cs, sh, iter, lockstep, lane);
                     if (wave == wave_W && done) role_swap(cs, sh, iter, lockstep, lane, i1, i2, sr, slr);
                 }

@@ -44,7 +44,7 @@ for k, nm in enumerate(names):
     print("%-34s %9.0f ticks/iter  %5.1f %%" % (nm, d / n, 100.0 * d / tot))
 cn = ["decode+load issue", "proposal arith (load wait)", "event_misfit", "final sum+decision", "commit+LDS write-back"]
 for k, nm in enumerate(cn):
-    print("  chain_pass[last chain] %-28s %8.0f ticks/iter" % (nm, (a[32 + k] - base[32 + k]) / n))
+    print("  chain_pass[chain 0] %-28s %8.0f ticks/iter" % (nm, (a[32 + k] - base[32 + k]) / n))
 for wv in range(8):
     for job in (0, 1):
         cnt = a[64 + wv + 8 * job] - base[64 + wv + 8 * job]
@@ -59,6 +59,7 @@ if jobs:
     print("    ... -> worker 0 first model reduced      %7.1f ns" % (10 * (d(22) - d(21))))
     print("    ... -> worker 0 last model combined      %7.1f ns" % (10 * (d(23) - d(22))))
     print("    ... -> master has all partials + judged  %7.1f ns" % (10 * (d(25) - d(23))))
+    print("    orders sent ahead by role P: %d of %d" % (a[28] - base[28], jobs))
     print("    polls of worker 0: %d  (one per %.0f ns of device time)" % (a[27] - base[27], 1e3 * 0 + 0))
     print("    publish -> master done                   %7.1f ns" % (10 * (d(25) - d(20))))
 st = cs.last_run_stats()
