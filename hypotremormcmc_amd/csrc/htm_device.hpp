@@ -325,10 +325,12 @@ struct PSync {
 // Every chain has its own order slot and publishes it by itself, as soon as its proposal is known.  A slot is
 // the whole order, so a worker learns everything with the poll that discovers it:
 //   g0 {tag, launch (low 32 bits)}   g1 {tag, type | element << 3}   g2 {tag, x_new high}   g3 {tag, x_new low}
-// (vs and qs of the evaluated model are chain state unless they are the proposal).  The slots are replicated
+//   g4 {tag, element the chain committed in the iteration before, or ~0}   g5, g6 {tag, its value high / low}   g7 {tag, 0}
+// (vs and qs of the evaluated model are chain state unless they are the proposal).  g4..g6: an order sent ahead
+// by role P may overtake the chain's latest commit store; the worker waits until it reads that value back.  The slots are replicated
 // ChainsDev::slot_rep times, slot_stride words apart (different memory channels), and worker w polls replica
 // w % slot_rep: every poll is served by the memory side, so the pollers of one line queue up behind each other.
-constexpr int kGranPerSlot = 4;
+constexpr int kGranPerSlot = 8;
 constexpr int kMaxSlotReplicas = 16;
 
 struct Ctrl {
@@ -387,6 +389,8 @@ struct ChainsDev {
     unsigned long long *pgran;       // partial sums, tagged granules: chain c, worker k at [(c*n_workers + k)*pgran_stride + {0,1}]
     int pgran_stride;                // words between the granule pairs of two workers (>= 2)
     int npoll;                       // worker polls kept in flight (1..3)
+    int mirror_n;                    // doubles of the LDS mirror of xall (vs, t_corr, qs, a_corr of all chains), 0 = none
+    int rayleigh14;                  // some element of those four groups has a Rayleigh prior (prior_type 1)
     int n_workers;                   // worker blocks of a k_mcmc launch
     StreamDev stream;
     unsigned long long *stamps;      // diagnostic builds (-DHTM_STAMPS) only, else nullptr

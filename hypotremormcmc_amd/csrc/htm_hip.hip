@@ -574,6 +574,14 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
         if ((rc = upload_model(hc, d.qs, init->qs, 1, nc, n + n * S, "qs"))) return cleanup(rc);
         if ((rc = upload_model(hc, d.ac, init->a_corr, h->S, nc, 2 * n + n * S, "a_corr"))) return cleanup(rc);
         if ((rc = upload_model(hc, d.hypo, init->hypo, 3 * h->E, nc, 2 * n + 2 * n * S, "hypo"))) return cleanup(rc);
+        d.rayleigh14 = 0;
+        auto any_rayleigh = [](const htm_model_init &m, size_t cnt) {
+            if (!m.prior_type) return false;
+            for (size_t k = 0; k < cnt; ++k) if (m.prior_type[k] == 1) return true;
+            return false;
+        };
+        if (any_rayleigh(init->vs, n) || any_rayleigh(init->qs, n) || any_rayleigh(init->t_corr, n * S) ||
+            any_rayleigh(init->a_corr, n * S)) d.rayleigh14 = 1;
     }
     if ((rc = dev_upload(hc->pool, &d.temp, init->temp, nc))) return cleanup(rc);
     std::vector<double> L0(nc, -9.e+300);   // cls_mcmc.f90:88
@@ -679,6 +687,12 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
     hc->step_smem = ((sizeof(StepShared) + 15) & ~size_t(15)) +
                     (size_t)hc->ring_size * (5 * sizeof(double) + 2 * sizeof(int4) + kHops * sizeof(int)) +
                     3 * (size_t)h->S * sizeof(double) + kGathStage * sizeof(double);
+    {
+        // LDS mirror of (vs, t_corr, qs, a_corr) x all chains + their step sizes, if it fits beside the rest
+        const size_t mir = 2 * (size_t)nc + 2 * (size_t)nc * h->S;
+        hc->dev.mirror_n = 0;
+        if (hc->step_smem + 2 * mir * sizeof(double) <= 96 * 1024) { hc->dev.mirror_n = (int)mir; hc->step_smem += 2 * mir * sizeof(double); }
+    }
     if (hc->step_smem > 150 * 1024) return cleanup(fail(HTM_EINVAL, "n_chains / n_sta too large for k_step's LDS budget"));
     if (hc->step_smem > 48 * 1024) {
         const void *fn = h->nch == 1 ? (const void *)k_step<1> : h->nch == 2 ? (const void *)k_step<2> : (const void *)k_step<0>;

@@ -31,6 +31,7 @@ struct StepShared {
     int start_fix[kMaxChains];    // corrected starts for a repeat pass (written by wave 0)
     int cnt[kMaxChains];          // draws the step consumed (judge draw included iff prior_ok)
     int slot_l[kMaxChains], slot_s[kMaxChains];
+    int redone[kMaxChains];       // the chain repeated its step in this iteration (undo + new commit: role P stays out)
     int pre_p[kMaxChains];        // >= 0: chain's next step, starting at this position, already has its order out
     unsigned pre_tag[kMaxChains]; // ... under this tag (k_mcmc, role P)
     int np[kMaxChains * 7], na[kMaxChains * 7];   // proposal / acceptance counters of this launch
@@ -54,6 +55,11 @@ struct Ring {                     // LDS window of the stream rings, index = rel
     int4 *dec, *sw;
     int *hop;
     int mask;
+    // k_mcmc only: LDS mirror of the non-hypocentre part of the rank's parameter vector (vs, t_corr, qs, a_corr
+    // of every chain; same offsets as ChainsDev::xall) and of its step sizes, kept current by the commits, so
+    // that role P needs no memory round trip.  mir_n = 0: no mirror (too large, or not the persistent kernel)
+    double *mx, *mstep;
+    int mir_n;
 };
 
 // one stream position in flight from the global rings to the LDS window
@@ -204,8 +210,7 @@ __device__ __forceinline__ bool metropolis(double L_new, double L_cur, double T,
 template <int NCH, bool PERSIST>
 __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, StepShared &sh, const Ring &rg,
                                           const double *s_sx, const double *s_sy, const double *s_sz, int c,
-                                          int p, int iter, int lane, unsigned long long launch,
-                                          PfRegs &pf, bool do_pf, int pf_p, int pf_limit)
+                                          int p, int iter, int lane, unsigned long long launch)
 {
     const int M = rg.mask;
 #ifdef HTM_STAMPS
@@ -263,9 +268,6 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
     const double r = ok ? r_ring : 0.0, logr = ok ? logr_ring : 0.0;
     const int cnt = dec_w - 1 + ok;                             // the judge draw happens only if prior_ok
     CSTAMP(1);   // proposal arithmetic (waits for the model loads)
-    // The wave that keeps the LDS window of the stream ahead issues those loads HERE: vector-memory results
-    // return in issue order, so issued any earlier their HBM latency would sit in front of this step's loads.
-    if (do_pf) pf_load(pf, cs, sh, pf_p, pf_limit);
 
     double L_new = 0.0;
     int need_full = 0, acc = 0;
@@ -290,18 +292,19 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
                 // ---- work order: tag = ticket (unique over the life of the chain set) ------------------------------
                 const bool pre = sh.pre_p[c] == p;         // role P of the previous iteration sent it already
                 unsigned long long tk = 0;
-                if (lane == 0) { tk = pre ? (unsigned long long)sh.pre_tag[c] : atomicAdd(&sh.c.jobs_total, 1ull) + 1ull; sh.pre_p[c] = -1; }
+                if (lane == 0) { tk = pre ? (unsigned long long)sh.pre_tag[c] : ((atomicAdd(&sh.c.jobs_total, 1ull) + 1ull) & 0x7fffffffull); sh.pre_p[c] = -1; }
                 const unsigned tag = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)tk);
                 // every chain-state store of this wave (earlier commits, undo) must have landed before a worker
                 // can see the order: write-through stores, drained here; the order itself is one store
                 // instruction (lane -> replica, granule), and its granules carry the tag, so no flag follows
                 drain_vmem();
                 if (!pre && lane < cs.slot_rep * kGranPerSlot) {
-                    const int gi = lane & 3;
+                    const int gi = lane & 7;
                     const unsigned long long xb = (unsigned long long)__double_as_longlong(x_new);
                     const unsigned pay = gi == 0 ? (unsigned)launch : gi == 1 ? ((unsigned)type | ((unsigned)idx << 3))
-                                       : gi == 2 ? (unsigned)(xb >> 32) : (unsigned)xb;
-                    st_gran(cs.slots + (size_t)(lane >> 2) * cs.slot_stride + c * kGranPerSlot + gi, tag, pay);
+                                       : gi == 2 ? (unsigned)(xb >> 32) : gi == 3 ? (unsigned)xb
+                                       : gi == 4 ? 0xffffffffu : 0u;          // no commit to wait for: drained above
+                    st_gran(cs.slots + (size_t)(lane >> 3) * cs.slot_stride + c * kGranPerSlot + gi, tag, pay);
                 }
 #ifdef HTM_STAMPS
                 if (lane == 0 && cs.stamps) { atomicAdd(&cs.stamps[20], __builtin_amdgcn_s_memrealtime()); atomicAdd(&cs.stamps[26], 1ull); if (pre) atomicAdd(&cs.stamps[28], 1ull); }
@@ -363,6 +366,7 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
         if (cool) sh.np[c * 7 + type - 1] += 1;                 // cls_mcmc.f90:186-189
         if (acc) {                                              // :207-219
             st_agent(cs.xall + o, x_new);
+            if (o < rg.mir_n) rg.mx[o] = x_new;
             sh.L[c] = L_new;
             cs.L[c] = L_new;
             if (cool) sh.na[c * 7 + type - 1] += 1;
@@ -373,13 +377,16 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
 }
 
 // lane 0 of the owning wave: take back the speculative effects of chain c's step
-__device__ __forceinline__ void undo_chain(const ChainsDev &cs, StepShared &sh, int c)
+__device__ __forceinline__ void undo_chain(const ChainsDev &cs, StepShared &sh, const Ring &rg, int c)
 {
     Proposal &pr = sh.prop[c];
     if (pr.cool) sh.np[c * 7 + pr.type - 1] -= 1;
     if (pr.accepted) {
         const ModelDev Mo = pick_model(cs, pr.type);
-        st_agent(Mo.x + (size_t)c * Mo.nx + pr.idx, pr.x_old);
+        double *px = Mo.x + (size_t)c * Mo.nx + pr.idx;
+        st_agent(px, pr.x_old);
+        const long long om = px - cs.xall;
+        if (om < rg.mir_n) rg.mx[om] = pr.x_old;
         sh.L[c] = pr.L_old;
         cs.L[c] = pr.L_old;
         if (pr.cool) sh.na[c * 7 + pr.type - 1] -= 1;
@@ -493,40 +500,65 @@ __device__ __forceinline__ bool swap_plan(const ChainsDev &cs, const StepShared 
 // one post phase and one step front (~2 us) before its own wave would send it.  Only for chains that did not
 // commit in this iteration: their state stores have provably landed (every wave drains at the top of its pass).
 // The chain wave recognises the order by its start position and goes straight to collecting the partial sums.
-__device__ __forceinline__ void role_prepublish(const ChainsDev &cs, StepShared &sh, const Ring &rg, int iter, int pos,
-                                                int wmax, unsigned long long launch, int lane)
+struct PreOrder {            // per lane (<-> chain): an order planned before barrier B, sent right after it
+    bool job;
+    int c;
+    unsigned tag, w1, x_hi, x_lo, co, c_hi, c_lo;
+};
+__device__ __forceinline__ PreOrder role_prepublish_plan(const ChainsDev &cs, StepShared &sh, const Ring &rg, int iter,
+                                                         int pos, int wmax, int lane)
 {
+    PreOrder po;
+    po.job = false; po.c = 0; po.tag = 0; po.w1 = 0; po.x_hi = 0; po.x_lo = 0; po.co = 0xffffffffu; po.c_hi = 0; po.c_lo = 0;
     const int nc = cs.n_chains, M = rg.mask;
-    if (iter + 1 > sh.c.iter_target || sh.fill < pos + wmax) return;      // no next iteration here / window not there yet
+    if (rg.mir_n == 0 || iter + 1 > sh.c.iter_target || sh.fill < pos + wmax) return po;   // no mirror / no next iteration here / window not there yet
     const bool in = lane < nc && lane <= kHops;
     const int c = in ? lane : 0;
     const int p = c == 0 ? pos : pos + rg.hop[(pos & M) * kHops + c - 1];
     const int4 dec = rg.dec[p & M];
+    const Proposal pr = sh.prop[c];
     const int type = dec.x, idx = dec.y;
-    bool job = in && type >= 1 && type <= 4 && sh.prop[c].accepted == 0;
-    if (job) {
-        const int S_ = cs.S;
-        const int goff = type == 1 ? 0 : type == 2 ? nc : type == 3 ? nc + nc * S_ : 2 * nc + nc * S_;
-        const int gnx = (type == 1 || type == 3) ? 1 : S_;
-        const int o = goff + c * gnx + idx;
-        const double x_old = cs.xall[o], step = cs.stall[o], mu = cs.muall[o];
-        const int ptype = cs.ptall[o];
-        const double x_new = x_old + rg.pg[p & M] * step;               // cls_model.f90:172, as chain_pass computes it
-        if (ptype == 1 && x_new <= mu) job = false;                     // prior rejects: no evaluation (:178-187)
-        if (job) {
-            const unsigned tag = (unsigned)(atomicAdd(&sh.c.jobs_total, 1ull) + 1ull);
-            const unsigned long long xb = (unsigned long long)__double_as_longlong(x_new);
-            for (int r = 0; r < cs.slot_rep; ++r) {
-                unsigned long long *sl = cs.slots + (size_t)r * cs.slot_stride + c * kGranPerSlot;
-                st_gran(sl + 0, tag, (unsigned)launch);
-                st_gran(sl + 1, tag, (unsigned)type | ((unsigned)idx << 3));
-                st_gran(sl + 2, tag, (unsigned)(xb >> 32));
-                st_gran(sl + 3, tag, (unsigned)xb);
-            }
-            sh.pre_tag[c] = tag;
-        }
+    bool job = in && type >= 1 && type <= 4 && sh.redone[c] == 0;
+    if (lane < nc) sh.redone[lane] = 0;
+    const int S_ = cs.S;
+    const int goff = type == 1 ? 0 : type == 2 ? nc : type == 3 ? nc + nc * S_ : 2 * nc + nc * S_;
+    const int gnx = (type == 1 || type == 3) ? 1 : S_;
+    const int o = job ? goff + c * gnx + idx : 0;
+    const double x_old = rg.mx[o], step = rg.mstep[o];                  // LDS mirror: no memory round trip here
+    const double x_new = x_old + rg.pg[p & M] * step;                   // cls_model.f90:172, as chain_pass computes it
+    if (job && cs.rayleigh14) {                                         // a Rayleigh prior among vs/qs/corrections (:178-187)
+        if (cs.ptall[o] == 1 && x_new <= cs.muall[o]) job = false;      // prior rejects: no evaluation
     }
-    if (lane < nc) sh.pre_p[lane] = job ? p : -1;
+    // the commit this chain made in the iteration that just ended may still be on its way to memory: the
+    // worker waits until it reads that value back
+    const int ct = pr.type;
+    const int cgoff = ct == 1 ? 0 : ct == 2 ? nc : ct == 3 ? nc + nc * S_ : ct == 4 ? 2 * nc + nc * S_ : 2 * nc + 2 * nc * S_;
+    const int cgnx = (ct == 1 || ct == 3) ? 1 : (ct == 2 || ct == 4) ? S_ : cs.hypo.nx;
+    const unsigned long long xb = (unsigned long long)__double_as_longlong(x_new);
+    const unsigned long long cb = (unsigned long long)__double_as_longlong(pr.x_new);
+    po.job = job; po.c = c;
+    po.tag = 0x80000000u | (((unsigned)(iter + 1) & 0x03ffffffu) << 5) | (unsigned)c;   // own space: chain_pass tags stay below 2^31
+    po.w1 = (unsigned)type | ((unsigned)idx << 3);
+    po.x_hi = (unsigned)(xb >> 32); po.x_lo = (unsigned)xb;
+    po.co = pr.accepted ? (unsigned)(cgoff + c * cgnx + pr.idx) : 0xffffffffu;
+    po.c_hi = (unsigned)(cb >> 32); po.c_lo = (unsigned)cb;
+    if (lane < nc) { sh.pre_p[lane] = job ? p : -1; sh.pre_tag[lane] = po.tag; }
+    return po;
+}
+__device__ __forceinline__ void role_prepublish_send(const ChainsDev &cs, const PreOrder &po, unsigned long long launch)
+{
+    if (!po.job) return;
+    for (int r = 0; r < cs.slot_rep; ++r) {
+        unsigned long long *sl = cs.slots + (size_t)r * cs.slot_stride + po.c * kGranPerSlot;
+        st_gran(sl + 0, po.tag, (unsigned)launch);
+        st_gran(sl + 1, po.tag, po.w1);
+        st_gran(sl + 2, po.tag, po.x_hi);
+        st_gran(sl + 3, po.tag, po.x_lo);
+        st_gran(sl + 4, po.tag, po.co);
+        st_gran(sl + 5, po.tag, po.c_hi);
+        st_gran(sl + 6, po.tag, po.c_lo);
+        st_gran(sl + 7, po.tag, 0u);
+    }
 }
 
 // chain wave, after the second barrier: this iteration's swap (if it touches chain c) and its records
@@ -624,6 +656,9 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
     double *s_sy = s_sx + f.S;
     double *s_sz = s_sy + f.S;
     double *s_gath = s_sz + f.S;                   // [kGathStage] the all-gathered swap records, staged
+    rg.mir_n = (PERSIST && mode == MODE_RUN) ? cs.mirror_n : 0;
+    rg.mx = s_gath + kGathStage;
+    rg.mstep = rg.mx + rg.mir_n;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -631,7 +666,8 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
     const int nc = cs.n_chains;
     const bool lockstep = (mode != MODE_RUN);
     // helper roles between the barriers: validation+bookkeeping on wave 0, records and swap on other waves
-    const int wave_R = NW > 1 ? 1 : 0, wave_W = NW > 2 ? 2 : 0, wave_P = NW - 1;   // wave_P extends the window
+    const int wave_R = NW > 1 ? 1 : 0, wave_W = NW > 2 ? 2 : 0;
+    const int wave_P = NW > 4 ? 4 : NW - 1;        // extends the LDS window during the roles phase (no role of its own if NW > 4)
     const int wave_Q = NW > 3 ? 3 : 0;             // role P: orders of the NEXT iteration's full evaluations
 #ifdef HTM_STAMPS
     unsigned long long stamp_last_ = __builtin_amdgcn_s_memtime();
@@ -651,6 +687,7 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
     for (int j = tid; j < f.S; j += blockDim.x) { s_sx[j] = f.sx[j]; s_sy[j] = f.sy[j]; s_sz[j] = f.sz[j]; }
     for (int c = tid; c < nc; c += blockDim.x) { sh.temp[c] = cs.temp[c]; sh.L[c] = cs.L[c]; }
     for (int k = tid; k < 7 * nc; k += blockDim.x) { sh.np[k] = 0; sh.na[k] = 0; }
+    for (int k = tid; k < rg.mir_n; k += blockDim.x) { rg.mx[k] = cs.xall[k]; rg.mstep[k] = cs.stall[k]; }
     // the gathered records of the previous lock-step iteration come in with the same round of loads
     const bool do_apply = (mode == MODE_APPLY || mode == MODE_ADVANCE) && gathered != nullptr;
     const int n_gath = cs.n_procs * (4 + 2 * nc);
@@ -671,7 +708,7 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
         sh.fill = 0; sh.base = 0; sh.redo = -1; sh.sw_do = 0; sh.catchup = 0;
         sh.jobs = 0;
     }
-    for (int c = tid; c < kMaxChains; c += blockDim.x) sh.pre_p[c] = -1;
+    for (int c = tid; c < kMaxChains; c += blockDim.x) { sh.pre_p[c] = -1; sh.redone[c] = 0; }
     {
         if (do_apply && tid == 0 && sh.c.stage == ST_WAIT_SWAP && sh.c.err == 0) {
             apply_swap(cs, sh, staged ? s_gath : gathered);
@@ -719,6 +756,7 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
     prefetch_all(cs, sh, rg, 2 * wmax);           // ends with a barrier
     STAMP(1);   // P0
 
+    int fill_next = 0;               // wave_P: window extent staged in the last roles phase, published before the next barrier A
     for (;;) {
         const int iter = sh.c.iter_done + 1;
         if (!resume) {
@@ -744,34 +782,25 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
             const unsigned long long t_top = __builtin_amdgcn_s_memtime();
 #endif
             for (;;) {
-                // one wave keeps the LDS window ahead: loads issued before its pass, stored after it
-                PfRegs pf;
-                pf.p = -1;
-                const bool extend = first && wave == wave_P;
+                // window bounds for this iteration's extension of the LDS window (done in the roles phase below)
                 const int pf_limit = min(min(sh.base + 3 * wmax, sh.avail), sh.base + rg.mask + 1 - 8);
-                const int pf_p = sh.fill + lane;
-                bool pf_due = extend;
                 int p = 0;
                 bool have_p = false;
                 for (int c = wave; c < nc; c += NW) {
                     if (c < redo) continue;
                     if (!first) {
-                        if (lane == 0) undo_chain(cs, sh, c);
+                        if (lane == 0) { undo_chain(cs, sh, rg, c); sh.redone[c] = 1; }
                         p = sh.start_fix[c];                                // corrected by the validation
                     } else if (!have_p) {                                   // optimistic start: c steps after base
                         p = c == 0 ? sh.base : sh.base + rg.hop[(sh.base & rg.mask) * kHops + c - 1];
                     }
-                    p = chain_pass<NCH, PERSIST>(f, cs, sh, rg, s_sx, s_sy, s_sz, c, p, iter, lane, launch,
-                                                 pf, pf_due, pf_p, pf_limit);
-                    pf_due = false;
+                    p = chain_pass<NCH, PERSIST>(f, cs, sh, rg, s_sx, s_sy, s_sz, c, p, iter, lane, launch);
                     have_p = true;
                     if (NW > 1 && c + NW < nc) p += rg.hop[(p & rg.mask) * kHops + NW - 2];   // skip NW-1 steps
                 }
-                if (extend) {
-                    if (pf_due) pf_load(pf, cs, sh, pf_p, pf_limit);        // this wave owns no chain
-                    pf_store(pf, rg);
-                    if (lane == 0) sh.fill = max(sh.fill, min(sh.fill + 64, pf_limit));
-                }
+                // what wave_P staged during the previous roles phase becomes part of the window now: sh.fill is
+                // stable between two barriers A, so every role sees the same window
+                if (wave == wave_P && lane == 0 && fill_next > sh.fill) sh.fill = fill_next;
 #ifdef HTM_STAMPS
                 if (lane == 0 && cs.stamps && first) {
                     const unsigned long long ta = __builtin_amdgcn_s_memtime();
@@ -782,6 +811,14 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
 #endif
                 __syncthreads();                                            // ---- barrier A
                 STAMP(2);   // passes
+                if (wave == wave_P && first) {
+                    // one wave without a role keeps the LDS window of the stream ahead while the roles run: 64 more
+                    // positions per iteration; the memory latency hides behind the roles phase
+                    PfRegs pf;
+                    pf_load(pf, cs, sh, sh.fill + lane, pf_limit);
+                    pf_store(pf, rg);
+                    fill_next = max(sh.fill, min(sh.fill + 64, pf_limit));
+                }
                 if (wave == 0 || wave == wave_R || wave == wave_W || (PERSIST && wave == wave_Q)) {
                     const Valid v = validate<PERSIST>(sh, nc, lane);
                     int pos = 0, i1, i2;
@@ -829,7 +866,7 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
                         }
                     }
                     if (PERSIST && wave == wave_Q && done && !lockstep)
-                        role_prepublish(cs, sh, rg, iter, pos, wmax, launch, lane);
+                        role_prepublish_send(cs, role_prepublish_plan(cs, sh, rg, iter, pos, wmax, lane), launch);
                     if (wave == wave_R && done) role_records(cs, sh, iter, lockstep, lane);
                     if (wave == wave_W && done) role_swap(cs, sh, iter, lockstep, lane, i1, i2, sr, slr);
                 }
@@ -841,7 +878,7 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
             }
             if (sh.redo == -2) {                 // aborted: take everything back, retry in the next launch
                 for (int c = wave; c < nc; c += NW)
-                    if (lane == 0) undo_chain(cs, sh, c);
+                    if (lane == 0) undo_chain(cs, sh, rg, c);
                 break;
             }
             if (sh.c.n_full > 0) {
@@ -927,12 +964,13 @@ __device__ __forceinline__ void worker_body(const FwdDev &f, const ChainsDev &cs
         *s_ticket = __hip_atomic_fetch_add(&cs.ps->arrive, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const unsigned long long launch = *s_ticket / (unsigned long long)(1 + cs.n_workers);
-    // wave 0: lane 4k + g holds granule g of chain (16 j + k)'s slot; lane 4k remembers the last tag served
-    constexpr int kGroups = (kMaxChains + 15) / 16;
+    // wave 0: lane 8k + g holds granule g of chain (8 j + k)'s slot; lane 8k remembers the last tag served
+    constexpr int kGroups = (kMaxChains + 7) / 8;
     unsigned last_tag[kGroups];
 #pragma unroll
     for (int j = 0; j < kGroups; ++j) last_tag[j] = 0;
-    unsigned *s_job = reinterpret_cast<unsigned *>(smem + 160);     // [0] type | idx << 3, [1] x_new high, [2] x_new low
+    // [0] type | idx << 3, [1] x_new high, [2] x_new low, [3] committed element or ~0, [4] its value high, [5] low
+    unsigned *s_job = reinterpret_cast<unsigned *>(smem + 160);
     const unsigned long long *slots = cs.slots + (size_t)(w % cs.slot_rep) * cs.slot_stride;
     const int npoll = cs.npoll;
     for (;;) {
@@ -940,14 +978,14 @@ __device__ __forceinline__ void worker_body(const FwdDev &f, const ChainsDev &cs
             unsigned tag = 0;
             int chain = -1;
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();          // 100 MHz
-            // one poll = the slots of all chains (one load per 16 chains) + the quit word; kPolls polls in flight
+            // one poll = the slots of all chains (one load per 8 chains) + the quit word; npoll polls in flight
             constexpr int kPolls = 3;
             unsigned long long x[kPolls][kGroups], qw[kPolls];
             auto issue = [&](int b) {
 #pragma unroll
                 for (int j = 0; j < kGroups; ++j) {
                     x[b][j] = 0ull;
-                    if (16 * j < nc && 16 * j + (lane >> 2) < nc) x[b][j] = ld_agent(slots + (size_t)(16 * j) * kGranPerSlot + lane);
+                    if (8 * j < nc && 8 * j + (lane >> 3) < nc) x[b][j] = ld_agent(slots + (size_t)(8 * j) * kGranPerSlot + lane);
                 }
                 qw[b] = lane == 63 ? ld_agent(&cs.ps->quit) : 0ull;
             };
@@ -955,22 +993,27 @@ __device__ __forceinline__ void worker_body(const FwdDev &f, const ChainsDev &cs
             auto check = [&](int b) -> int {
 #pragma unroll
                 for (int j = 0; j < kGroups; ++j) {
-                    if (16 * j >= nc) continue;
+                    if (8 * j >= nc) continue;
                     const unsigned t = (unsigned)(x[b][j] >> 32), pay = (unsigned)x[b][j];
-                    const unsigned t0q = (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0x00, 0xF, 0xF, false);   // quad_perm [0,0,0,0]
-                    bool ok = t == t0q && t != 0u && 16 * j + (lane >> 2) < nc;
-                    if ((lane & 3) == 0) ok = ok && pay == (unsigned)launch && t != last_tag[j];
+                    const unsigned tq = (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0x00, 0xF, 0xF, false);    // quad_perm [0,0,0,0]
+                    const unsigned t4 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0x114, 0xF, 0xF, false);   // row_shr:4
+                    bool ok = t == tq && t != 0u && 8 * j + (lane >> 3) < nc;
+                    if ((lane & 7) == 4) ok = ok && t == t4;                 // second quad agrees with the first
+                    if ((lane & 7) == 0) ok = ok && pay == (unsigned)launch && t != last_tag[j];
                     unsigned long long m = __ballot(ok);
-                    m = m & (m >> 1) & (m >> 2) & (m >> 3) & 0x1111111111111111ull;
+                    m &= m >> 1; m &= m >> 2; m &= m >> 4; m &= 0x0101010101010101ull;
                     if (m) {
                         const int l0 = __ffsll((long long)m) - 1;           // lane of granule 0 of the chosen chain
-                        chain = 16 * j + (l0 >> 2);
+                        chain = 8 * j + (l0 >> 3);
                         tag = (unsigned)__builtin_amdgcn_readlane((int)t, l0);
                         if (lane == l0) last_tag[j] = tag;
-                        const unsigned p1 = (unsigned)__builtin_amdgcn_readlane((int)pay, l0 + 1);
-                        const unsigned p2 = (unsigned)__builtin_amdgcn_readlane((int)pay, l0 + 2);
-                        const unsigned p3 = (unsigned)__builtin_amdgcn_readlane((int)pay, l0 + 3);
-                        if (lane == 0) { s_job[0] = p1; s_job[1] = p2; s_job[2] = p3; }
+                        unsigned pv[6];
+#pragma unroll
+                        for (int q = 0; q < 6; ++q) pv[q] = (unsigned)__builtin_amdgcn_readlane((int)pay, l0 + 1 + q);
+                        if (lane == 0) {
+#pragma unroll
+                            for (int q = 0; q < 6; ++q) s_job[q] = pv[q];
+                        }
                         return 1;
                     }
                 }
@@ -1006,6 +1049,15 @@ __device__ __forceinline__ void worker_body(const FwdDev &f, const ChainsDev &cs
         {
             const int type = (int)(s_job[0] & 7u), idx = (int)(s_job[0] >> 3);
             const double ov_val = __longlong_as_double((long long)(((unsigned long long)s_job[1] << 32) | s_job[2]));
+            if (s_job[3] != 0xffffffffu) {
+                // sent ahead of the chain's latest commit: wait until that store is what memory returns
+                const unsigned long long want = ((unsigned long long)s_job[4] << 32) | s_job[5];
+                const unsigned long long t0c = __builtin_amdgcn_s_memrealtime();
+                while ((unsigned long long)__double_as_longlong(ld_agent(cs.xall + s_job[3])) != want) {
+                    if (__builtin_amdgcn_s_memrealtime() - t0c > 500000000ull) return;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
             // vs and qs of the evaluated model: chain state unless they are the proposal (same round of loads as
             // the corrections and the event coordinates below)
             const double beta_c = ld_agent(cs.vs.x + m), q_c = ld_agent(cs.qs.x + m);
