@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libhtm_hip.so")
+LIB_PATH = os.environ.get("HTM_LIB") or os.path.join(_HERE, "lib", "libhtm_hip.so")   # HTM_LIB: A/B builds
 
 dp = C.POINTER(C.c_double)
 ip = C.POINTER(C.c_int32)
