@@ -26,8 +26,11 @@ template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_mov_f64(double v)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false);
+    // every lane written (full row mask, in-range source): bound_ctrl tells the compiler the old value is dead,
+    // which saves the two zero-initialising moves per step; the row_bcast steps need old = 0 in the rows they skip
+    constexpr bool kAll = ROW_MASK == 0xF;
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, kAll);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, kAll);
     return __hiloint2double(hi, lo);
 }
 
