@@ -318,8 +318,6 @@ struct FullDesc {
 // k_mcmc launch.  Every word is polled / updated with agent-scope accesses only and sits on its own 128-B line.
 struct PSync {
     unsigned long long arrive; char p0[120];   // ticket counter: launch index = ticket / (1 + W)
-    unsigned long long job;    char p1[120];   // (launch << 32) | number of jobs published in that launch
-    unsigned long long done;   char p2[120];   // worker blocks that finished a job, ever
     unsigned long long quit;   char p3[120];   // launches whose master has finished
 };
 

@@ -1,21 +1,23 @@
-// htm_step.hpp -- k_step: one workgroup drives all chains of a rank through MCMC iterations.
+// htm_step.hpp -- k_mcmc / k_step: the main loop of a rank (hypo_tremor_mcmc.f90:236-284) on the device.
 //
-// Roles inside the workgroup
-//   chain waves 0..NW-1   wave <-> chain (chains c = wave, wave+NW, ...), lane <-> station.  Per iteration a
-//                         chain wave looks up where its step starts in the rank's random stream, reads the
-//                         pre-decoded proposal found there (cls_mcmc.f90:134-165), perturbs the model
-//                         (cls_model.f90:162-190), evaluates the single-event partial update
-//                         (cls_forward.f90:307-362) and takes the Metropolis decision (cls_mcmc.f90:193-203)
-//                         -- no workgroup barrier in between.
-//   prefetch wave NW      copies the window of the stream rings (htm_stream.hpp) that the next iterations
-//                         will touch from HBM/L2 into an LDS ring, concurrently with the chain waves.
-//   waves 0 and 1, lanes <-> chains   between the two barriers of an iteration: validate the optimistic
-//                         stream positions (a Rayleigh-prior rejection makes a step one draw shorter,
-//                         cls_mcmc.f90:193), plan the temperature swap (cls_parallel.f90:226-230,:292-299),
-//                         assign record slots, build the list of chains that need k_full -- lane-parallel
-//                         (ballot / DPP scan), no serial loops over chains.
-// The kernel loops over iterations until a chain needs a full evaluation (hand-over to k_full, resume in
-// the next launch), the target is reached, a record buffer is full or the produced stream runs out.
+// k_mcmc (the product path): block 0 = chain MASTER, blocks 1..W = full-evaluation WORKERS, one persistent launch.
+// k_step  (fallback, HTM_PERSIST=0): the master's code alone; exits at every full evaluation, k_full is its own launch.
+//
+// Master workgroup, per iteration
+//   passes   chain waves, wave <-> chain (chains c = wave, wave+NW, ...), lane <-> station: look up where the step
+//            starts in the rank's random stream, read the pre-decoded proposal found there (cls_mcmc.f90:134-165),
+//            perturb the model (cls_model.f90:162-190), evaluate the single-event partial update
+//            (cls_forward.f90:307-362) -- or collect the workers' partial sums of the full evaluation
+//            (cls_forward.f90:268-303) --, Metropolis decision (cls_mcmc.f90:193-203), speculative commit.
+//            No workgroup barrier in between.
+//   roles    between the two barriers, lanes <-> chains, one wave each: V validates the optimistic stream
+//            positions (a Rayleigh-prior rejection makes a step one draw shorter, cls_mcmc.f90:193) and commits the
+//            RNG position; R record slots and step log; W temperature swap (cls_parallel.f90:121-136,:226-230);
+//            P (k_mcmc) publishes the work orders of the NEXT iteration's full evaluations; one more wave extends
+//            the LDS window of the stream rings (htm_stream.hpp).  Lane-parallel (ballot / DPP scan), no serial
+//            loops over chains.
+//   post     swap applied by the waves owning the two chains, samples recorded.
+// The loop ends when the target is reached, a record buffer is full or the produced stream runs out.
 #pragma once
 #include "htm_device.hpp"
 #include "htm_stream.hpp"
@@ -37,8 +39,6 @@ struct StepShared {
     int np[kMaxChains * 7], na[kMaxChains * 7];   // proposal / acceptance counters of this launch
     int sw_do, sw_c1, sw_c2;      // swap decided between the barriers; applied by the waves owning the chains
     double sw_T1, sw_T2;          // new temperatures of chains sw_c1 / sw_c2
-    unsigned long long done_base; // PSync::done when this launch started
-    int jobs;                     // full-evaluation jobs published in this launch
     long long origin;             // absolute stream position of relative position 0 (= spos at launch)
     long long hop_end;            // StreamDev::hop_end when this launch started
     unsigned long long ticket;    // k_mcmc: this block's arrival ticket (launch index = ticket / blocks per launch)
@@ -706,7 +706,6 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
         const long long av = sh.hop_end - sh.c.spos;
         sh.avail = av > (1 << 30) ? (1 << 30) : (int)av;
         sh.fill = 0; sh.base = 0; sh.redo = -1; sh.sw_do = 0; sh.catchup = 0;
-        sh.jobs = 0;
     }
     for (int c = tid; c < kMaxChains; c += blockDim.x) { sh.pre_p[c] = -1; sh.redone[c] = 0; }
     {
