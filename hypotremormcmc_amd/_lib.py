@@ -68,6 +68,9 @@ SIGNATURES = {
     "htm_chains_iterations_done": (C.c_int, [vp, C.POINTER(C.c_int)]),
     "htm_chains_get_state": (C.c_int, [vp, C.c_int, dp, dp, dp, dp, dp, dp, dp, ip, ip]),
     "htm_chains_get_rng": (C.c_int, [vp, up]),
+    "htm_chains_checkpoint_size": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
+    "htm_chains_checkpoint_save": (C.c_int, [vp, vp, C.c_size_t]),
+    "htm_chains_checkpoint_load": (C.c_int, [vp, vp, C.c_size_t]),
     "htm_chains_lik_count": (C.c_int, [vp, C.POINTER(C.c_int)]),
     "htm_chains_lik_read": (C.c_int, [vp, ip, ip, dp]),
     "htm_chains_sample_count": (C.c_int, [vp, C.POINTER(C.c_int)]),

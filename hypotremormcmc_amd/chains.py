@@ -129,6 +129,21 @@ class ChainSet:
                                              npr.ctypes.data_as(ip), nac.ctypes.data_as(ip)))
         return ChainState(hypo, tc, vs.value, ac, qs.value, temp.value, ll.value, npr, nac)
 
+    def checkpoint(self) -> bytes:
+        """Everything the main loop carries between iterations (htm_chains_checkpoint_save): iteration counter,
+        mod_random state, parameter vectors, temperatures, log-likelihoods, proposal counters."""
+        n = C.c_size_t()
+        check(self._lib.htm_chains_checkpoint_size(self.handle, C.byref(n)))
+        buf = C.create_string_buffer(n.value)
+        check(self._lib.htm_chains_checkpoint_save(self.handle, buf, n.value))
+        return buf.raw
+
+    def restore(self, blob: bytes):
+        """Load a checkpoint into a chain set created from the same inputs; continuing gives the bits of the
+        uninterrupted run.  Records held so far are dropped."""
+        buf = C.create_string_buffer(blob, len(blob))
+        check(self._lib.htm_chains_checkpoint_load(self.handle, buf, len(blob)))
+
     def rng_state(self):
         st = (C.c_uint32 * 4)()
         check(self._lib.htm_chains_get_rng(self.handle, st))

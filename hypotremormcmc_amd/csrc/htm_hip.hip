@@ -1120,6 +1120,107 @@ int htm_chains_iterations_done(htm_chains *hc, int *n)
     return HTM_OK;
 }
 
+// ---- checkpoint / resume ------------------------------------------------------------------------------
+namespace {
+struct CkptHeader {
+    uint32_t magic, version;
+    int32_t n_chains, n_sta, n_events, n_procs, rank, iter_done;
+    uint32_t rng_state[4];
+    int64_t n_full_evals, n_partial_evals;
+    uint64_t jobs_total;
+    uint64_t total;           // doubles in the parameter vector
+};
+constexpr uint32_t kCkptMagic = 0x48544d43u;   // "HTMC"
+size_t ckpt_total(const htm_chains *hc)
+{
+    const size_t n = hc->dev.n_chains, S = hc->dev.S, E = hc->dev.E;
+    return 2 * n + 2 * n * S + 3 * E * n;
+}
+size_t ckpt_bytes(const htm_chains *hc)
+{
+    const size_t n = hc->dev.n_chains;
+    return sizeof(CkptHeader) + (ckpt_total(hc) + 2 * n) * sizeof(double) + 2 * 7 * n * sizeof(int32_t);
+}
+}  // namespace
+
+int htm_chains_checkpoint_size(htm_chains *hc, size_t *bytes)
+{
+    if (!hc || !bytes) return fail(HTM_EINVAL, "NULL argument");
+    *bytes = ckpt_bytes(hc);
+    return HTM_OK;
+}
+
+int htm_chains_checkpoint_save(htm_chains *hc, void *blob, size_t bytes)
+{
+    if (!hc || !blob) return fail(HTM_EINVAL, "NULL argument");
+    if (bytes < ckpt_bytes(hc)) return fail(HTM_EINVAL, "checkpoint buffer too small (%zu < %zu)", bytes, ckpt_bytes(hc));
+    int rc = htm_chains_sync(hc);            // flushes a pending swap, raises device error flags
+    if (rc) return rc;
+    if (hc->h_ctrl.stage != ST_IDLE) return fail(HTM_ESTATE, "a lock-step iteration is in flight");
+    CkptHeader h{};
+    h.magic = kCkptMagic; h.version = 1;
+    h.n_chains = hc->dev.n_chains; h.n_sta = hc->dev.S; h.n_events = hc->dev.E; h.n_procs = hc->dev.n_procs; h.rank = hc->dev.rank;
+    h.iter_done = hc->h_ctrl.iter_done;
+    if ((rc = htm_chains_get_rng(hc, h.rng_state))) return rc;
+    h.n_full_evals = hc->h_ctrl.n_full_evals; h.n_partial_evals = hc->h_ctrl.n_partial_evals;
+    h.jobs_total = hc->h_ctrl.jobs_total;
+    h.total = ckpt_total(hc);
+    char *p = static_cast<char *>(blob);
+    std::memcpy(p, &h, sizeof(h)); p += sizeof(h);
+    const size_t n = hc->dev.n_chains;
+    HIPCHK(hipMemcpy(p, hc->dev.xall, h.total * sizeof(double), hipMemcpyDeviceToHost)); p += h.total * sizeof(double);
+    HIPCHK(hipMemcpy(p, hc->dev.temp, n * sizeof(double), hipMemcpyDeviceToHost)); p += n * sizeof(double);
+    HIPCHK(hipMemcpy(p, hc->dev.L, n * sizeof(double), hipMemcpyDeviceToHost)); p += n * sizeof(double);
+    HIPCHK(hipMemcpy(p, hc->dev.n_propose, 7 * n * sizeof(int32_t), hipMemcpyDeviceToHost)); p += 7 * n * sizeof(int32_t);
+    HIPCHK(hipMemcpy(p, hc->dev.n_accept, 7 * n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return HTM_OK;
+}
+
+int htm_chains_checkpoint_load(htm_chains *hc, const void *blob, size_t bytes)
+{
+    if (!hc || !blob) return fail(HTM_EINVAL, "NULL argument");
+    if (bytes < sizeof(CkptHeader)) return fail(HTM_EINVAL, "checkpoint blob truncated");
+    CkptHeader h{};
+    std::memcpy(&h, blob, sizeof(h));
+    if (h.magic != kCkptMagic || h.version != 1) return fail(HTM_EINVAL, "not a checkpoint of this library (magic/version)");
+    if (h.n_chains != hc->dev.n_chains || h.n_sta != hc->dev.S || h.n_events != hc->dev.E || h.n_procs != hc->dev.n_procs ||
+        h.rank != hc->dev.rank || h.total != ckpt_total(hc))
+        return fail(HTM_EINVAL, "checkpoint shape (%d chains, %d x %d, rank %d/%d) does not match this chain set", h.n_chains,
+                    h.n_events, h.n_sta, h.rank, h.n_procs);
+    if (bytes < ckpt_bytes(hc)) return fail(HTM_EINVAL, "checkpoint blob truncated");
+    int rc = htm_chains_sync(hc);
+    if (rc) return rc;
+    if (hc->h_ctrl.stage != ST_IDLE) return fail(HTM_ESTATE, "a lock-step iteration is in flight");
+    HIPCHK(hipStreamSynchronize(hc->side));
+    const char *p = static_cast<const char *>(blob) + sizeof(h);
+    const size_t n = hc->dev.n_chains;
+    HIPCHK(hipMemcpy(hc->dev.xall, p, h.total * sizeof(double), hipMemcpyHostToDevice)); p += h.total * sizeof(double);
+    HIPCHK(hipMemcpy(hc->dev.temp, p, n * sizeof(double), hipMemcpyHostToDevice)); p += n * sizeof(double);
+    HIPCHK(hipMemcpy(hc->dev.L, p, n * sizeof(double), hipMemcpyHostToDevice)); p += n * sizeof(double);
+    HIPCHK(hipMemcpy(hc->dev.n_propose, p, 7 * n * sizeof(int32_t), hipMemcpyHostToDevice)); p += 7 * n * sizeof(int32_t);
+    HIPCHK(hipMemcpy(hc->dev.n_accept, p, 7 * n * sizeof(int32_t), hipMemcpyHostToDevice));
+    // the random stream restarts at the saved generator state: position 0 of a fresh stream
+    for (int k = 0; k < 4; ++k) hc->init_state[k] = h.rng_state[k];
+    HIPCHK(hipMemcpy(hc->dev.stream.gen, hc->init_state, 4 * sizeof(uint32_t), hipMemcpyHostToDevice));
+    const long long zero = 0;
+    HIPCHK(hipMemcpy(hc->dev.stream.hop_end, &zero, sizeof(zero), hipMemcpyHostToDevice));
+    hc->n_raw = hc->n_tr = hc->n_rec = hc->n_hop = 0;
+    hc->spos_lo = hc->spos_hi = 0;
+    Ctrl c{};
+    c.stage = ST_IDLE; c.spos = 0; c.iter_done = h.iter_done; c.iter_target = h.iter_done;
+    c.n_full_evals = h.n_full_evals; c.n_partial_evals = h.n_partial_evals; c.jobs_total = h.jobs_total;
+    c.slog_n = 0; c.slog_cap = hc->h_ctrl.slog_cap;
+    hc->h_ctrl = c;
+    hc->h_target = h.iter_done;
+    hc->pending_gathered = nullptr;
+    HIPCHK(hipMemcpy(hc->dev.ctrl, &c, sizeof(Ctrl), hipMemcpyHostToDevice));
+    hc->lik_iter.clear(); hc->lik_chain.clear(); hc->lik_val.clear();
+    hc->smp_iter.clear(); hc->smp_chain.clear(); hc->smp_data.clear();
+    if ((rc = stream_produce(hc, 1 << 16))) return rc;
+    HIPCHK(hipStreamSynchronize(hc->side));
+    return HTM_OK;
+}
+
 int htm_chains_get_state(htm_chains *hc, int chain, double *hypo, double *t_corr, double *vs, double *a_corr,
                          double *qs, double *temp, double *log_likelihood, int32_t n_propose[7], int32_t n_accept[7])
 {

@@ -11,6 +11,7 @@ module htm_c_api
   public :: htm_chains_create, htm_chains_destroy, htm_chains_run, htm_chains_get_state, htm_chains_get_rng
   public :: htm_chains_lik_count, htm_chains_lik_read, htm_chains_sample_count, htm_chains_sample_read
   public :: htm_chains_iterations_done
+  public :: htm_chains_checkpoint_size, htm_chains_checkpoint_save, htm_chains_checkpoint_load
 
   !> one `type model` group stacked over the chains of the rank (include/htm_hip.h: htm_model_init)
   type, bind(C) :: htm_model_init
@@ -139,6 +140,26 @@ module htm_c_api
        integer(c_int), intent(out) :: n
        integer(c_int) :: rc
      end function htm_chains_iterations_done
+
+     !> checkpoint / resume (include/htm_hip.h); blob = c_loc of a byte buffer of htm_chains_checkpoint_size bytes
+     function htm_chains_checkpoint_size(handle, bytes) bind(C, name="htm_chains_checkpoint_size") result(rc)
+       import :: c_int, c_size_t, c_ptr
+       type(c_ptr), value :: handle
+       integer(c_size_t), intent(out) :: bytes
+       integer(c_int) :: rc
+     end function htm_chains_checkpoint_size
+     function htm_chains_checkpoint_save(handle, blob, bytes) bind(C, name="htm_chains_checkpoint_save") result(rc)
+       import :: c_int, c_size_t, c_ptr
+       type(c_ptr), value :: handle, blob
+       integer(c_size_t), value :: bytes
+       integer(c_int) :: rc
+     end function htm_chains_checkpoint_save
+     function htm_chains_checkpoint_load(handle, blob, bytes) bind(C, name="htm_chains_checkpoint_load") result(rc)
+       import :: c_int, c_size_t, c_ptr
+       type(c_ptr), value :: handle, blob
+       integer(c_size_t), value :: bytes
+       integer(c_int) :: rc
+     end function htm_chains_checkpoint_load
 
      function htm_chains_get_state(handle, chain, hypo, t_corr, vs, a_corr, qs, temp, log_likelihood, &
           & n_propose, n_accept) bind(C, name="htm_chains_get_state") result(rc)

@@ -173,6 +173,17 @@ int htm_chains_drain(htm_chains *hc);       /* sync + move device record buffers
 
 int htm_chains_iterations_done(htm_chains *hc, int *n);
 
+/* Checkpoint / resume of a chain set (the reference has none, a 4 M-iteration production run
+ * restarts from scratch).  The blob holds everything the main loop carries from one iteration to the next:
+ * iteration counter, mod_random state at the consumed position, the five parameter vectors, temperatures,
+ * log-likelihoods and proposal counters of every chain.  Priors, step sizes, observations and record
+ * buffers are NOT in it: load into a chain set created from the same inputs (shapes are checked).
+ * Continuing after load gives the bits of the uninterrupted run.  Not valid while a lock-step iteration is
+ * in flight (between step_begin and step_end). */
+int htm_chains_checkpoint_size(htm_chains *hc, size_t *bytes);
+int htm_chains_checkpoint_save(htm_chains *hc, void *blob, size_t bytes);
+int htm_chains_checkpoint_load(htm_chains *hc, const void *blob, size_t bytes);
+
 /* chain state (`pt%get_mc(j)` + getters of src/cls_mcmc.f90:252-420); chain is 0-based; NULLs skipped */
 int htm_chains_get_state(htm_chains *hc, int chain, double *hypo, double *t_corr, double *vs,
                          double *a_corr, double *qs, double *temp, double *log_likelihood,

@@ -221,3 +221,36 @@ def test_two_kernel_fallback_matches_reference_trace(monkeypatch):
     fwd, sets = _build_world(data, params)
     sets[0].run(int(params["n_iter"]))
     _check_against_fixture(fx, params, sets)
+
+
+def test_checkpoint_resume_is_bitwise_and_checks_shapes():
+    """run(700) == run(300) -> checkpoint -> a NEW chain set from the same inputs -> restore -> run(400)"""
+    from hypotremormcmc_amd._lib import HtmError
+
+    fx, data, params = load_case("c2")
+    _, a = _build_world(data, params)
+    a[0].run(700)
+    _, b = _build_world(data, params)
+    b[0].run(300)
+    blob = b[0].checkpoint()
+    _, c = _build_world(data, params)
+    c[0].restore(blob)
+    assert c[0].iterations_done == 300 and c[0].rng_state() == b[0].rng_state()
+    c[0].run(400)
+    assert c[0].iterations_done == 700 and c[0].rng_state() == a[0].rng_state()
+    ia, ca, la = a[0].likelihood_trace(); ic, cc, lc = c[0].likelihood_trace()
+    keep = ia > 300
+    assert np.array_equal(ia[keep], ic) and np.array_equal(ca[keep], cc) and np.array_equal(la[keep], lc)
+    for k in range(2):
+        sa, sc = a[0].state(k), c[0].state(k)
+        assert np.array_equal(sa.hypo, sc.hypo) and np.array_equal(sa.t_corr, sc.t_corr) and sa.temp == sc.temp
+        assert sa.log_likelihood == sc.log_likelihood
+        assert np.array_equal(sa.n_propose, sc.n_propose) and np.array_equal(sa.n_accept, sc.n_accept)
+    # a blob of another shape is refused
+    fx3, data3, params3 = load_case("missing")
+    _, d = _build_world(data3, params3)
+    if (data3.t_obs.shape != data.t_obs.shape) or int(params3["n_chains"]) != int(params["n_chains"]):
+        with pytest.raises(HtmError):
+            d[0].restore(blob)
+    with pytest.raises(HtmError):
+        c[0].restore(blob[:64])
