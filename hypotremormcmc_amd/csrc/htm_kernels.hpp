@@ -49,6 +49,14 @@ __global__ __launch_bounds__(256) void k_full(FwdDev f, FullJob jb)
         if ((int)blockIdx.y >= n) return;
         kstep = 1 << 30; nm = blockIdx.y + 1;       // exactly one model per block
     }
+    // one event per wave (E <= 4 * event tiles): the wave's observation rows do not depend on the model -- load
+    // them once and keep them in registers over all models of this block
+    constexpr int NR = NCH > 0 ? NCH : 1;
+    ObsRegs<NR> ob_keep;
+    const bool keep_obs = NCH > 0 && jb.epw == 1 && (int)(blockIdx.x * 4 + wave) < f.E;
+    if constexpr (NCH > 0) {
+        if (keep_obs) load_obs_regs<NCH>(ob_keep, f, blockIdx.x * 4 + wave, lane);
+    }
     for (int k = k0; k < nm; k += kstep) {
         const int m = jb.desc ? en.chain : k;
         double beta, q;
@@ -79,9 +87,13 @@ __global__ __launch_bounds__(256) void k_full(FwdDev f, FullJob jb)
                     const double py[1] = {(ov && ov_cmp == 1) ? ov_val : hyp[3 * ev + 1]};
                     const double pz[1] = {(ov && ov_cmp == 2) ? ov_val : hyp[3 * ev + 2]};
                     double out[1];
-                    ObsRegs<NCH> ob;
-                    load_obs_regs<NCH>(ob, f, ev, lane);
-                    event_misfit<NCH, 1>(f, ob, lane, st, px, py, pz, beta, q, out);
+                    if (keep_obs) {
+                        event_misfit<NCH, 1>(f, ob_keep, lane, st, px, py, pz, beta, q, out);
+                    } else {
+                        ObsRegs<NCH> ob;
+                        load_obs_regs<NCH>(ob, f, ev, lane);
+                        event_misfit<NCH, 1>(f, ob, lane, st, px, py, pz, beta, q, out);
+                    }
                     lane_acc += out[0];
                 }
             }
