@@ -254,3 +254,29 @@ def test_checkpoint_resume_is_bitwise_and_checks_shapes():
             d[0].restore(blob)
     with pytest.raises(HtmError):
         c[0].restore(blob[:64])
+
+
+def test_c5_size_16_chains_against_oracle():
+    """BASELINE configs[4] per-GPU shape in fp64: 10 000 events x 128 stations (2 stations per lane), 16 chains
+    (two rounds of chain waves), every recorded log-likelihood and the RNG consumption against the oracle.
+    150 iterations: the all-full first iteration, ~240 full evaluations of 41 MB each, ~2 100 partial updates."""
+    from hypotremormcmc_amd import synth
+    from oracle import oracle
+
+    E, S, nc, n_iter = 10000, 128, 16, 150
+    data = synth.make_synthetic(E, S, 5)
+    params = dict(synth.DEFAULT_PARAMS, n_procs=1, n_chains=nc, n_cool=2, n_iter=n_iter, n_burn=50, n_interval=3)
+    job = oracle.Job(params, data); job.run(n_iter)
+    _, sets = _build_world(data, params)
+    sets[0].run(n_iter)
+    it, lk = job.likelihood_trace(0)
+    gi, _, gl = sets[0].likelihood_trace()
+    assert len(gi) > 50 and np.array_equal(gi, it)
+    np.testing.assert_allclose(gl, lk, rtol=RTOL_TRACE)
+    assert sets[0].rng_state() == job.rng_state(0)
+    a, b = sets[0].counts(); oa, ob = job.counts()
+    assert np.array_equal(a, oa) and np.array_equal(b, ob)
+    for c in (0, nc - 1):
+        s, o = sets[0].state(c), job.chain(0, c)
+        np.testing.assert_allclose(s.hypo, o["hypo"], rtol=1e-11, atol=1e-12)
+        assert s.temp == o["temp"]
