@@ -648,6 +648,11 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
     hc->th[0] = d.th1; hc->th[1] = d.th2; hc->th[2] = d.th3; hc->th[3] = d.th4;
     for (int k = 0; k < 4; ++k) hc->init_state[k] = init->rng_state[k];
     hc->cap = 1 << 20;     // stream positions kept in HBM (~100 B each)
+    if (const char *e = getenv("HTM_STREAM_CAP")) {          // power of two >= 2^17 (tests: ring wrap-around in short runs)
+        long long v = atoll(e), c2 = 1 << 17;
+        while (c2 < v && c2 < (1ll << 24)) c2 <<= 1;
+        hc->cap = c2;
+    }
     {
         StreamDev &sd = d.stream;
         const size_t n = (size_t)hc->cap;

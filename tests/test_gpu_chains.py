@@ -280,3 +280,30 @@ def test_c5_size_16_chains_against_oracle():
         s, o = sets[0].state(c), job.chain(0, c)
         np.testing.assert_allclose(s.hypo, o["hypo"], rtol=1e-11, atol=1e-12)
         assert s.temp == o["temp"]
+
+
+@pytest.mark.parametrize("lockstep", [False, True])
+def test_random_stream_ring_wraps_around(lockstep, monkeypatch):
+    """The rank's random stream lives in rings over the absolute position (2^20 by default, i.e. one wrap every
+    ~25 000 iterations at 8 chains).  With the smallest ring (2^17) a 5 000-iteration run of 19 chains goes
+    round it three to four times, in the persistent driver and in the per-iteration lock-step driver."""
+    from hypotremormcmc_amd.parallel import LocalWorld
+    from oracle import oracle
+
+    monkeypatch.setenv("HTM_STREAM_CAP", str(1 << 17))
+    fx, data, params = load_case("c1")
+    n_iter = 5000
+    params = dict(params, n_procs="1", n_chains="19", n_cool="3", n_iter=str(n_iter), n_burn="100", n_interval="11")
+    job = oracle.Job(params, data); job.run(n_iter)
+    _, sets = _build_world(data, params)
+    if lockstep:
+        LocalWorld(sets).run(n_iter)
+    else:
+        sets[0].run(n_iter)
+    it, lk = job.likelihood_trace(0)
+    gi, _, gl = sets[0].likelihood_trace()
+    assert np.array_equal(gi, it)
+    np.testing.assert_allclose(gl, lk, rtol=RTOL_TRACE)
+    assert sets[0].rng_state() == job.rng_state(0)
+    a, b = sets[0].counts(); oa, ob = job.counts()
+    assert np.array_equal(a, oa) and np.array_equal(b, ob)
