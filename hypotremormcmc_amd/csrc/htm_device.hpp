@@ -317,7 +317,6 @@ struct FullDesc {
 // Hand-shake words between the chain master (block 0) and the full-evaluation workers (blocks 1..W) of one
 // k_mcmc launch.  Every word is polled / updated with agent-scope accesses only and sits on its own 128-B line.
 struct PSync {
-    unsigned long long arrive; char p0[120];   // ticket counter: launch index = ticket / (1 + W)
     unsigned long long quit;   char p3[120];   // launches whose master has finished
 };
 

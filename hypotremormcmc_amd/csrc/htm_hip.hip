@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "htm_kernels.hpp"
+#include "htm_select.hpp"
 
 using namespace htm;
 
@@ -118,11 +119,7 @@ struct htm_chains {
     long long n_raw = 0, n_tr = 0, n_rec = 0, n_hop = 0;   // positions produced per stage (host view)
     long long spos_lo = 0, spos_hi = 0;        // bounds on the consumed position since the last sync
     const double *pending_gathered = nullptr;  // lock-step: records whose swap the next k_step applies
-    // lock-step iterations captured as one graph: kLockGraph x [k_mcmc(advance) -> all-gather]
-    hipGraph_t lgraph = nullptr;
-    hipGraphExec_t lgexec = nullptr;
-    void *lg_fn = nullptr, *lg_comm = nullptr, *lg_buf = nullptr;
-    bool lg_failed = false;
+    unsigned long long launch_seq = 0;         // k_mcmc launches of this chain set so far (the kernels' launch index)
     bool persist = true;                       // k_mcmc (master + resident full-evaluation workers) vs k_step + k_full
     ChainsDev dev_np{};                        // view for the non-persistent kernels (partial sums per k_full tile)
     uint32_t init_state[4] = {0, 0, 0, 0};     // mod_random state at stream position 0
@@ -158,10 +155,11 @@ int launch_mcmc(htm_chains *hc, int mode, int target, const double *gathered)
 {
     htm_forward *h = hc->fwd;
     dim3 grid(1 + hc->dev.n_workers), block(512);
+    const unsigned long long seq = ++hc->launch_seq;      // this chain set's k_mcmc launches, counted from 1
     switch (h->nch) {
-    case 1: hipLaunchKernelGGL(k_mcmc<1>, grid, block, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax); break;
-    case 2: hipLaunchKernelGGL(k_mcmc<2>, grid, block, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax); break;
-    default: hipLaunchKernelGGL(k_mcmc<0>, grid, block, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax); break;
+    case 1: hipLaunchKernelGGL(k_mcmc<1>, grid, block, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax, seq); break;
+    case 2: hipLaunchKernelGGL(k_mcmc<2>, grid, block, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax, seq); break;
+    default: hipLaunchKernelGGL(k_mcmc<0>, grid, block, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax, seq); break;
     }
     HIPCHK(hipGetLastError());
     return HTM_OK;
@@ -728,8 +726,6 @@ int htm_chains_destroy(htm_chains *hc)
     if (hc->ev_side) (void)hipEventDestroy(hc->ev_side);
     if (hc->side) (void)hipStreamDestroy(hc->side);
     if (hc->gexec) (void)hipGraphExecDestroy(hc->gexec);
-    if (hc->lgexec) (void)hipGraphExecDestroy(hc->lgexec);
-    if (hc->lgraph) (void)hipGraphDestroy(hc->lgraph);
     if (hc->graph) (void)hipGraphDestroy(hc->graph);
     for (void *p : hc->pool) (void)hipFree(p);
     if (hc->ev0) (void)hipEventDestroy(hc->ev0);
@@ -992,47 +988,6 @@ int htm_chains_step_begin(htm_chains *hc)
     return launch_step(hc, MODE_FINISH, hc->h_target, nullptr);
 }
 
-// kLockGraph lock-step iterations as ONE hipGraph: [k_mcmc(apply previous swap, advance) -> all-gather] x K.
-// The collective is captured like any other stream operation (RCCL enqueues its kernel into the capture), so
-// a replay costs one host call per K iterations instead of two launches per iteration.
-static constexpr int kLockGraph = 16;
-
-static int build_lockstep_graph(htm_chains *hc, htm_allgather_fn allgather, void *comm, void *d_gathered)
-{
-    if (hc->lgexec && hc->lg_fn == (void *)allgather && hc->lg_comm == comm && hc->lg_buf == d_gathered) return HTM_OK;
-    if (hc->lgexec) { (void)hipGraphExecDestroy(hc->lgexec); hc->lgexec = nullptr; }
-    if (hc->lgraph) { (void)hipGraphDestroy(hc->lgraph); hc->lgraph = nullptr; }
-    htm_forward *h = hc->fwd;
-    const size_t words = 4 + 2 * (size_t)hc->dev.n_chains;
-    hipStream_t cap = nullptr;
-    HIPCHK(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
-    hipStream_t saved = h->stream;
-    h->stream = cap;
-    int rc = HTM_OK;
-    hipError_t e = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
-    if (e != hipSuccess) rc = fail(HTM_EHIP, "hipStreamBeginCapture: %s", hipGetErrorString(e));
-    for (int k = 0; k < kLockGraph && rc == HTM_OK; ++k) {
-        rc = launch_mcmc(hc, MODE_ADVANCE, -2, static_cast<const double *>(d_gathered));
-        if (rc == HTM_OK && allgather(hc->dev.swap_rec, d_gathered, words, 8, comm, cap) != 0)
-            rc = fail(HTM_EHIP, "all-gather refused stream capture");
-    }
-    hipGraph_t g = nullptr;
-    if (e == hipSuccess) {
-        e = hipStreamEndCapture(cap, &g);
-        if (rc == HTM_OK && e != hipSuccess) rc = fail(HTM_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
-    }
-    h->stream = saved;
-    if (rc == HTM_OK) {
-        e = hipGraphInstantiate(&hc->lgexec, g, nullptr, nullptr, 0);
-        if (e != hipSuccess) { rc = fail(HTM_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); hc->lgexec = nullptr; }
-    }
-    if (rc == HTM_OK) { hc->lgraph = g; hc->lg_fn = (void *)allgather; hc->lg_comm = comm; hc->lg_buf = d_gathered; }
-    else if (g) (void)hipGraphDestroy(g);
-    (void)hipStreamDestroy(cap);
-    (void)hipGetLastError();
-    return rc;
-}
-
 int htm_chains_run_lockstep(htm_chains *hc, int n_iter, htm_allgather_fn allgather, void *comm, void *d_gathered)
 {
     if (!hc || !allgather || !d_gathered || n_iter < 0) return fail(HTM_EINVAL, "bad argument");
@@ -1042,34 +997,6 @@ int htm_chains_run_lockstep(htm_chains *hc, int n_iter, htm_allgather_fn allgath
     // records a rank may hold on the device between drains: n_chains per iteration at most
     const int drain_every = std::max(1, std::min(hc->dev.cap_lik, hc->dev.cap_smp) / (2 * hc->dev.n_chains) - 2);
     int k = 0, since_drain = 0, rc;
-    // Opt-in (HTM_LOCKSTEP_GRAPH=1): measured 19.4 vs 19.8 us per iteration on one rank -- the loop is not
-    // host-bound -- so the default stays the plain enqueue loop, which needs nothing special from the collective.
-    const char *env = std::getenv("HTM_LOCKSTEP_GRAPH");
-    const bool want_graph = hc->persist && !hc->lg_failed && n_iter >= kLockGraph && drain_every >= kLockGraph &&
-                            env && env[0] == '1';
-    if (want_graph) {
-        if (build_lockstep_graph(hc, allgather, comm, d_gathered) != HTM_OK) hc->lg_failed = true;   // eager loop below
-    }
-    if (want_graph && !hc->lg_failed) {
-        // an earlier eager iteration may have left its swap pending on another buffer: apply it first
-        if (hc->pending_gathered && hc->pending_gathered != d_gathered && (rc = flush_pending(hc))) return rc;
-        while (n_iter - k >= kLockGraph) {
-            // a replay consumes at most kLockGraph * wmax draws; keep the produced stream ahead of that bound
-            hc->spos_hi += (long long)kLockGraph * hc->wmax;
-            if (hc->n_hop - hc->spos_hi < 4 * (long long)hc->wmax) {
-                if ((rc = read_ctrl(hc))) return rc;
-                if ((rc = ctrl_error(hc))) return rc;
-                hc->spos_hi += (long long)kLockGraph * hc->wmax;
-                if ((rc = stream_produce(hc, 1 << 17))) return rc;
-                HIPCHK(hipStreamWaitEvent(h->stream, hc->ev_side, 0));
-            }
-            HIPCHK(hipGraphLaunch(hc->lgexec, h->stream));
-            hc->h_target += kLockGraph;
-            hc->pending_gathered = static_cast<const double *>(d_gathered);
-            k += kLockGraph; since_drain += kLockGraph;
-            if (since_drain + kLockGraph > drain_every) { if ((rc = htm_chains_drain(hc))) return rc; since_drain = 0; }
-        }
-    }
     for (; k < n_iter; ++k) {
         rc = htm_chains_step_begin(hc);
         if (rc) return rc;
@@ -1361,6 +1288,43 @@ int htm_chains_read_stamps(htm_chains *hc, unsigned long long out[128])
     return HTM_OK;
 }
 #endif
+
+int htm_quantiles_dev(int device, const double *d_samples, long n_mod, long n_par, long ld, const int ranks_1based[3],
+                      double *d_out, void *hip_stream)
+{
+    if (!d_samples || !d_out || !ranks_1based) return fail(HTM_EINVAL, "NULL argument");
+    if (n_mod < 1 || n_par < 1 || ld < n_par) return fail(HTM_EINVAL, "bad shape (n_mod %ld, n_par %ld, ld %ld)", n_mod, n_par, ld);
+    for (int r = 0; r < 3; ++r)
+        if (ranks_1based[r] < 1 || ranks_1based[r] > n_mod)
+            return fail(HTM_EINVAL, "rank %d outside 1..%ld (the reference would index outside its sorted column)", ranks_1based[r], n_mod);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(HTM_ENODEVICE, "no HIP device");
+    HIPCHK(hipSetDevice(device));
+    const dim3 grid((unsigned)((n_par + 63) / 64)), block(64 * kSelRG);
+    hipLaunchKernelGGL(k_select, grid, block, 0, static_cast<hipStream_t>(hip_stream), d_samples, n_mod, n_par, ld,
+                       ranks_1based[0] - 1, ranks_1based[1] - 1, ranks_1based[2] - 1, d_out);
+    HIPCHK(hipGetLastError());
+    return HTM_OK;
+}
+
+int htm_quantiles(int device, const double *samples, long n_mod, long n_par, const int ranks_1based[3], double *out)
+{
+    if (!samples || !out) return fail(HTM_EINVAL, "NULL argument");
+    if (n_mod < 1 || n_par < 1) return fail(HTM_EINVAL, "bad shape");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(HTM_ENODEVICE, "no HIP device");
+    HIPCHK(hipSetDevice(device));
+    double *d_x = nullptr, *d_o = nullptr;
+    const size_t nb = (size_t)n_mod * n_par * sizeof(double), ob = (size_t)n_par * 3 * sizeof(double);
+    if (hipMalloc(reinterpret_cast<void **>(&d_x), nb) != hipSuccess) return fail(HTM_EHIP, "hipMalloc of %zu bytes failed", nb);
+    if (hipMalloc(reinterpret_cast<void **>(&d_o), ob) != hipSuccess) { (void)hipFree(d_x); return fail(HTM_EHIP, "hipMalloc failed"); }
+    int rc = HTM_OK;
+    if (hipMemcpy(d_x, samples, nb, hipMemcpyHostToDevice) != hipSuccess) rc = fail(HTM_EHIP, "upload failed");
+    if (rc == HTM_OK) rc = htm_quantiles_dev(device, d_x, n_mod, n_par, n_par, ranks_1based, d_o, nullptr);
+    if (rc == HTM_OK && hipMemcpy(out, d_o, ob, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(HTM_EHIP, "download failed");
+    (void)hipFree(d_x); (void)hipFree(d_o);
+    return rc;
+}
 
 int htm_selftest(int device)
 {

@@ -41,7 +41,6 @@ struct StepShared {
     double sw_T1, sw_T2;          // new temperatures of chains sw_c1 / sw_c2
     long long origin;             // absolute stream position of relative position 0 (= spos at launch)
     long long hop_end;            // StreamDev::hop_end when this launch started
-    unsigned long long ticket;    // k_mcmc: this block's arrival ticket (launch index = ticket / blocks per launch)
     int avail;                    // the produced stream covers relative positions < avail
     int fill;                     // the LDS ring holds relative positions < fill
     int base;                     // relative position at which the current iteration starts
@@ -637,7 +636,7 @@ __device__ __forceinline__ void apply_swap(const ChainsDev &cs, StepShared &sh, 
 // as its own launch (fallback path, also used for profiling the two stages separately).
 template <int NCH, bool PERSIST>
 __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, int mode, int target_arg,
-                                          const double *gathered, int ring_size, int wmax)
+                                          const double *gathered, int ring_size, int wmax, unsigned long long launch)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     StepShared &sh = *reinterpret_cast<StepShared *>(smem);
@@ -681,8 +680,6 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
         constexpr int kCtrlWords = (int)(sizeof(Ctrl) / sizeof(int));
         if (tid < kCtrlWords) reinterpret_cast<int *>(&sh.c)[tid] = reinterpret_cast<const int *>(cs.ctrl)[tid + vz0];
         if (tid == kCtrlWords) sh.hop_end = cs.stream.hop_end[vz0];
-        if (PERSIST && tid == kCtrlWords + 1)      // launch index: one ticket per block of the launch
-            sh.ticket = __hip_atomic_fetch_add(&cs.ps->arrive, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     for (int j = tid; j < f.S; j += blockDim.x) { s_sx[j] = f.sx[j]; s_sy[j] = f.sy[j]; s_sz[j] = f.sz[j]; }
     for (int c = tid; c < nc; c += blockDim.x) { sh.temp[c] = cs.temp[c]; sh.L[c] = cs.L[c]; }
@@ -695,13 +692,11 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
     if (staged)
         for (int k = tid; k < n_gath; k += blockDim.x) s_gath[k] = gathered[k];
     __syncthreads();
-    const unsigned long long launch = PERSIST ? sh.ticket / (unsigned long long)(1 + cs.n_workers) : 0ull;
 
     // ---------------- swap of the previous lock-step iteration (cls_parallel.f90:118-213) --------------
     // MODE_APPLY does only this; MODE_ADVANCE does it first when the host passes the gathered records along
     if (tid == 0) {
         if (target_arg >= 0) sh.c.iter_target = target_arg;
-        else if (target_arg == -2) sh.c.iter_target = 0x7fffffff;   // lock-step graph replay: one iteration per launch
         sh.origin = sh.c.spos;
         const long long av = sh.hop_end - sh.c.spos;
         sh.avail = av > (1 << 30) ? (1 << 30) : (int)av;
@@ -920,7 +915,7 @@ template <int NCH>
 __global__ __launch_bounds__(512) void k_step(FwdDev f, ChainsDev cs, int mode, int target_arg,
                                                const double *gathered, int ring_size, int wmax)
 {
-    step_body<NCH, false>(f, cs, mode, target_arg, gathered, ring_size, wmax);
+    step_body<NCH, false>(f, cs, mode, target_arg, gathered, ring_size, wmax, 0ull);
 }
 
 // Worker block of a k_mcmc launch: waits for work orders of its own launch and evaluates its event tile of
@@ -931,7 +926,7 @@ __global__ __launch_bounds__(512) void k_step(FwdDev f, ChainsDev cs, int mode, 
 // (the master drained its stores before publishing it).  Leaves when the master has finished (PSync::quit)
 // or after a bounded wait.
 template <int NCH>
-__device__ __forceinline__ void worker_body(const FwdDev &f, const ChainsDev &cs)
+__device__ __forceinline__ void worker_body(const FwdDev &f, const ChainsDev &cs, unsigned long long launch)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *s_red = reinterpret_cast<double *>(smem);          // [8]
@@ -957,12 +952,6 @@ __device__ __forceinline__ void worker_body(const FwdDev &f, const ChainsDev &cs
     }
 
     int *s_chain = reinterpret_cast<int *>(smem + 136);
-    // launch index: one ticket per block, requested together with the preloads above
-    unsigned long long *s_ticket = reinterpret_cast<unsigned long long *>(smem + 144);
-    if (tid == 0)
-        *s_ticket = __hip_atomic_fetch_add(&cs.ps->arrive, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const unsigned long long launch = *s_ticket / (unsigned long long)(1 + cs.n_workers);
     // wave 0: lane 8k + g holds granule g of chain (8 j + k)'s slot; lane 8k remembers the last tag served
     constexpr int kGroups = (kMaxChains + 7) / 8;
     unsigned last_tag[kGroups];
@@ -1125,21 +1114,20 @@ __device__ __forceinline__ void worker_body(const FwdDev &f, const ChainsDev &cs
 }
 
 // One launch = the chain master (block 0) + W full-evaluation workers (blocks 1..W), all resident.
+// `launch` = the host's count of k_mcmc launches of this chain set (1, 2, ...): orders and the quit word carry it, so
+// nothing a previous launch left in memory can be mistaken for this launch's.
 template <int NCH>
 __global__ __launch_bounds__(512) void k_mcmc(FwdDev f, ChainsDev cs, int mode, int target_arg,
-                                               const double *gathered, int ring_size, int wmax)
+                                               const double *gathered, int ring_size, int wmax,
+                                               unsigned long long launch)
 {
     if (blockIdx.x == 0) {
-        step_body<NCH, true>(f, cs, mode, target_arg, gathered, ring_size, wmax);
+        step_body<NCH, true>(f, cs, mode, target_arg, gathered, ring_size, wmax, launch);
         // every exit of the master comes through here (its returns are uniform over the block): release the workers
-        extern __shared__ __attribute__((aligned(16))) char smem[];
         __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned long long launch = reinterpret_cast<const StepShared *>(smem)->ticket / (unsigned long long)(1 + cs.n_workers);
-            st_agent(&cs.ps->quit, launch + 1ull);
-        }
+        if (threadIdx.x == 0) st_agent(&cs.ps->quit, launch + 1ull);
     } else {
-        worker_body<NCH>(f, cs);
+        worker_body<NCH>(f, cs, launch);
     }
 }
 

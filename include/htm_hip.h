@@ -220,6 +220,19 @@ int htm_chains_profile(htm_chains *hc, int n_iter, double *step_us, int *step_la
 
 /* self-test of the wave-level reduction and RNG device code against straightforward device loops;
  * returns 0 when they agree bit for bit */
+/* ------------------------------------------------------------------------------------------------
+ * Step-6 order statistics       reference: src/cls_statistics.f90:216-264, :345-431
+ * The reference sorts every parameter's n_mod recorded samples (quick_sort, src/mod_sort.f90) and prints
+ * the elements il = int(0.025*n_mod), im = int(0.5*n_mod), iu = int(0.975*n_mod) (1-based, single-
+ * precision products) of the sorted column.  htm_quantiles returns exactly those elements without sorting:
+ * samples [n_mod][n_par] row-major (one recorded model per row), ranks_1based[3] = {il, im, iu} or any other
+ * three ranks in 1..n_mod, out [n_par][3].  Host pointers; synchronous.  The _dev form takes device
+ * pointers (ld = row stride in doubles) and is asynchronous on `hip_stream` (NULL = the null stream). */
+int htm_quantiles(int device, const double *samples, long n_mod, long n_par, const int ranks_1based[3],
+                  double *out);
+int htm_quantiles_dev(int device, const double *d_samples, long n_mod, long n_par, long ld,
+                      const int ranks_1based[3], double *d_out, void *hip_stream);
+
 int htm_selftest(int device);
 
 #ifdef __cplusplus

@@ -34,6 +34,8 @@ from hypotremormcmc_amd import synth  # noqa: E402
 
 REF_BIN = os.path.join(ROOT, "oracle", "_ref", "hypo_tremor_mcmc_ref")
 PROBE_BIN = os.path.join(ROOT, "oracle", "_ref", "ref_probe")
+STATS_BIN = os.path.join(ROOT, "oracle", "_ref", "hypo_tremor_statistics_ref")
+STAT_FILES = ("uniform_structure.stat", "station_corrections.stat", "hypo.stat", "hypo.stat.removed")
 MPIEXEC = "/opt/conda/bin/mpiexec"
 OUT = os.path.dirname(os.path.abspath(__file__))
 
@@ -157,6 +159,20 @@ def run_case(name, spec):
                     it = it[-2:]
                 fx[f"{nm}_iter_{r}"] = it
                 fx[f"{nm}_{r}"] = v
+        # step 6 of the reference on the files step 5 just wrote: the four .stat files, as text.
+        # Needs il = int(0.025 * n_mod) >= 1, i.e. n_mod >= 40 (below that the reference indexes element 0).
+        p_ = {k: int(params[k]) for k in ("n_iter", "n_burn", "n_procs", "n_cool", "n_interval")}
+        n_mod = (p_["n_iter"] - p_["n_burn"]) * p_["n_procs"] * p_["n_cool"] // p_["n_interval"]
+        if n_mod >= 40:
+            # step 6 reads its parameter file in the step-4 ("select") mode, which insists on five keys it never uses
+            with open(os.path.join(work, "stats.in"), "w") as fh:
+                fh.write(open(os.path.join(work, "run.in")).read())
+                fh.write("z_guess = 7.0\nvs_min = 2.0\nvs_max = 4.0\nb_min = 0.0\nb_max = 1.0\n")
+            subprocess.check_call([MPIEXEC, "-np", str(n_procs), STATS_BIN, "stats.in"], cwd=work,
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            for fn in STAT_FILES:
+                fx["stat_" + fn.replace(".", "_")] = np.array(open(os.path.join(work, fn)).read())
+            fx["stat_n_mod"] = np.array(n_mod)
         rows = [ln.split('"') for ln in open(os.path.join(work, "proposal_count.txt"))]
         fx["count_labels"] = np.array([r[1] for r in rows])
         fx["n_propose"] = np.array([int(r[2].split()[0]) for r in rows], dtype=np.int64)
@@ -179,7 +195,7 @@ def run_case(name, spec):
 
 
 if __name__ == "__main__":
-    if not (os.path.exists(REF_BIN) and os.path.exists(PROBE_BIN)):
+    if not (os.path.exists(REF_BIN) and os.path.exists(PROBE_BIN) and os.path.exists(STATS_BIN)):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
     for nm in (sys.argv[1:] or list(CASES)):
         run_case(nm, CASES[nm])

@@ -174,11 +174,9 @@ def test_many_chains_per_rank():
     assert np.array_equal(a, oa) and np.array_equal(b, ob)
 
 
-@pytest.mark.parametrize("graph", ["1", "0"])
-def test_rccl_lockstep_loop_equals_single_rank_driver_bitwise(graph, monkeypatch):
-    """The multi-GPU driver loop (htm_chains_run_lockstep: k_mcmc + ncclAllGather per iteration, replayed as a
-    hipGraph of 16 iterations or enqueued one by one) on a real RCCL communicator of one rank must produce the
-    bits of the single-rank driver; 700 iterations = graph replays + an eager tail."""
+def test_rccl_lockstep_loop_equals_single_rank_driver_bitwise():
+    """The multi-GPU driver loop (htm_chains_run_lockstep: one k_mcmc launch + one ncclAllGather per iteration,
+    enqueued from C) on a real RCCL communicator of one rank must produce the bits of the single-rank driver."""
     import socket
 
     import torch
@@ -186,7 +184,6 @@ def test_rccl_lockstep_loop_equals_single_rank_driver_bitwise(graph, monkeypatch
 
     from hypotremormcmc_amd.parallel import TorchWorld
 
-    monkeypatch.setenv("HTM_LOCKSTEP_GRAPH", graph)
     fx, data, params = load_case("c2")
     n_iter = 700
     _, a = _build_world(data, params)
