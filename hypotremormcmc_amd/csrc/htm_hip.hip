@@ -11,7 +11,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -90,7 +92,7 @@ struct htm_forward {
     // scratch for batches
     double *d_bpartial = nullptr; size_t bpartial_cap = 0;
     double *d_bmodels = nullptr;  size_t bmodels_cap = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_wd = nullptr;
 };
 
 struct htm_chains {
@@ -111,7 +113,7 @@ struct htm_chains {
     double last_device_us = 0.0;
     int last_graph_launches = 0;
     long long run_full0 = 0, run_part0 = 0, last_full = 0, last_part = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_wd = nullptr;
     // random-stream service (htm_stream.hpp): produced on a side stream ahead of consumption
     hipStream_t side = nullptr;
     hipEvent_t ev_side = nullptr;
@@ -701,6 +703,7 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
         const void *fn = h->nch == 1 ? (const void *)k_step<1> : h->nch == 2 ? (const void *)k_step<2> : (const void *)k_step<0>;
         HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hc->step_smem));
     }
+    if (hipEventCreateWithFlags(&hc->ev_wd, hipEventDisableTiming) != hipSuccess) return cleanup(fail(HTM_EHIP, "hipEventCreate failed"));
     if (hipEventCreate(&hc->ev0) != hipSuccess || hipEventCreate(&hc->ev1) != hipSuccess)
         return cleanup(fail(HTM_EHIP, "hipEventCreate failed"));
     hc->dev_np = hc->dev;                       // same state; partial sums laid out per k_full tile
@@ -728,6 +731,7 @@ int htm_chains_destroy(htm_chains *hc)
     if (hc->gexec) (void)hipGraphExecDestroy(hc->gexec);
     if (hc->graph) (void)hipGraphDestroy(hc->graph);
     for (void *p : hc->pool) (void)hipFree(p);
+    if (hc->ev_wd) (void)hipEventDestroy(hc->ev_wd);
     if (hc->ev0) (void)hipEventDestroy(hc->ev0);
     if (hc->ev1) (void)hipEventDestroy(hc->ev1);
     delete hc;
@@ -742,12 +746,34 @@ static int flush_pending(htm_chains *hc)
     return launch_step(hc, MODE_APPLY, hc->h_target, g);
 }
 
+// Wait for the chain kernels' stream, but never forever: every device-side wait is bounded (workers 30 s, master
+// 5 s per hand-over), so a stream that has not drained after kWatchdogSeconds means the device is wedged -- report
+// it instead of hanging the caller (HTM_WATCHDOG_S overrides the limit; 0 = wait without limit).
+static int bounded_stream_sync(htm_chains *hc, const char *what)
+{
+    static const double limit = [] { const char *e = getenv("HTM_WATCHDOG_S"); return e ? atof(e) : 300.0; }();
+    hipStream_t st = hc->fwd->stream;
+    if (limit <= 0.0) { HIPCHK(hipStreamSynchronize(st)); return HTM_OK; }
+    HIPCHK(hipEventRecord(hc->ev_wd, st));
+    const auto t0 = std::chrono::steady_clock::now();
+    for (long spin = 0;; ++spin) {
+        const hipError_t e = hipEventQuery(hc->ev_wd);
+        if (e == hipSuccess) return HTM_OK;
+        if (e != hipErrorNotReady) return fail(HTM_EHIP, "%s: %s", what, hipGetErrorString(e));
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (dt > limit)
+            return fail(HTM_ESTATE, "%s: the device made no progress for %.0f s (iteration %d + in-flight work, launch %llu)",
+                        what, dt, hc->h_ctrl.iter_done, hc->launch_seq);
+        if (spin > 2000) std::this_thread::sleep_for(std::chrono::microseconds(dt > 0.01 ? 200 : 5));
+    }
+}
+
 static int read_ctrl(htm_chains *hc)
 {
     int rc_ = flush_pending(hc);
     if (rc_) return rc_;
     HIPCHK(hipMemcpyAsync(&hc->h_ctrl, hc->dev.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, hc->fwd->stream));
-    HIPCHK(hipStreamSynchronize(hc->fwd->stream));
+    if ((rc_ = bounded_stream_sync(hc, "waiting for the chain kernels"))) return rc_;
     hc->spos_lo = hc->spos_hi = hc->h_ctrl.spos;
     return HTM_OK;
 }
@@ -1004,6 +1030,7 @@ int htm_chains_run_lockstep(htm_chains *hc, int n_iter, htm_allgather_fn allgath
         if (st != 0) return fail(HTM_EHIP, "all-gather of the swap records failed with status %d", st);
         if ((rc = htm_chains_step_end(hc, d_gathered))) return rc;
         if (++since_drain >= drain_every) { if ((rc = htm_chains_drain(hc))) return rc; since_drain = 0; }
+        else if ((k & 511) == 511 && (rc = bounded_stream_sync(hc, "lock-step loop"))) return rc;
     }
     return HTM_OK;
 }
