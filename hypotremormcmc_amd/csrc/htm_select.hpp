@@ -16,6 +16,7 @@ namespace htm {
 
 constexpr int kSelRanks = 3;      // il, im, iu
 constexpr int kSelRG = 4;         // row groups (waves) per workgroup
+constexpr int kSelUnroll = 8;     // rows in flight per thread
 
 __device__ __forceinline__ unsigned long long sel_key(double v)
 {
@@ -44,7 +45,24 @@ __global__ __launch_bounds__(64 * kSelRG) void k_select(const double *x, long n_
 #pragma unroll
             for (int d = 0; d < 16; ++d) cnt[r][d][g][lane] = 0;
         if (live) {
-            for (long k = g; k < n_mod; k += kSelRG) {
+            // kSelUnroll rows in flight per thread: the loads are independent, only the LDS counters serialise
+            long k = g;
+            for (; k + (kSelUnroll - 1) * kSelRG < n_mod; k += kSelUnroll * kSelRG) {
+                unsigned long long key[kSelUnroll];
+#pragma unroll
+                for (int u = 0; u < kSelUnroll; ++u) key[u] = sel_key(x[(k + u * kSelRG) * ld + p]);
+#pragma unroll
+                for (int u = 0; u < kSelUnroll; ++u) {
+                    const int dig = (int)((key[u] >> shift) & 15ull);
+                    const unsigned long long hi = shift == 60 ? 0ull : key[u] >> (shift + 4);
+#pragma unroll
+                    for (int r = 0; r < kSelRanks; ++r) {
+                        const unsigned long long want = shift == 60 ? 0ull : prefix[r] >> (shift + 4);
+                        if (hi == want) cnt[r][dig][g][lane] += 1;
+                    }
+                }
+            }
+            for (; k < n_mod; k += kSelRG) {
                 const unsigned long long key = sel_key(x[k * ld + p]);
                 const int dig = (int)((key >> shift) & 15ull);
                 const unsigned long long hi = shift == 60 ? 0ull : key >> (shift + 4);
