@@ -131,6 +131,19 @@ def main():
             raise SystemExit("launch N > 1 with torch.distributed.run (one rank per GPU)")
         args.gpus = world
 
+    # a cold `import torch` on a fresh box can take minutes: a sign of life on stderr meanwhile (rank 0)
+    if rank == 0:
+        import threading
+
+        t_start = time.time()
+
+        def _beat():
+            while True:
+                time.sleep(45)
+                sys.stderr.write("[bench] alive, %d s\n" % (time.time() - t_start))
+                sys.stderr.flush()
+
+        threading.Thread(target=_beat, daemon=True).start()
     import torch  # device plumbing + torch.distributed only
 
     from hypotremormcmc_amd import driver, synth
