@@ -70,6 +70,8 @@ SIGNATURES = {
     "htm_chains_get_rng": (C.c_int, [vp, up]),
     "htm_quantiles": (C.c_int, [C.c_int, dp, C.c_long, C.c_long, C.POINTER(C.c_int), dp]),
     "htm_quantiles_dev": (C.c_int, [C.c_int, vp, C.c_long, C.c_long, C.c_long, C.POINTER(C.c_int), vp, vp]),
+    "htm_chains_swap_record_host": (C.c_int, [vp, dp]),
+    "htm_chains_step_end_host": (C.c_int, [vp, dp]),
     "htm_chains_checkpoint_size": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
     "htm_chains_checkpoint_save": (C.c_int, [vp, vp, C.c_size_t]),
     "htm_chains_checkpoint_load": (C.c_int, [vp, vp, C.c_size_t]),

@@ -121,6 +121,7 @@ struct htm_chains {
     long long n_raw = 0, n_tr = 0, n_rec = 0, n_hop = 0;   // positions produced per stage (host view)
     long long spos_lo = 0, spos_hi = 0;        // bounds on the consumed position since the last sync
     const double *pending_gathered = nullptr;  // lock-step: records whose swap the next k_step applies
+    double *d_gath_host = nullptr, *h_gath_pinned = nullptr;   // staging buffers of htm_chains_step_end_host
     unsigned long long launch_seq = 0;         // k_mcmc launches of this chain set so far (the kernels' launch index)
     bool persist = true;                       // k_mcmc (master + resident full-evaluation workers) vs k_step + k_full
     ChainsDev dev_np{};                        // view for the non-persistent kernels (partial sums per k_full tile)
@@ -731,6 +732,7 @@ int htm_chains_destroy(htm_chains *hc)
     if (hc->gexec) (void)hipGraphExecDestroy(hc->gexec);
     if (hc->graph) (void)hipGraphDestroy(hc->graph);
     for (void *p : hc->pool) (void)hipFree(p);
+    if (hc->h_gath_pinned) (void)hipHostFree(hc->h_gath_pinned);
     if (hc->ev_wd) (void)hipEventDestroy(hc->ev_wd);
     if (hc->ev0) (void)hipEventDestroy(hc->ev0);
     if (hc->ev1) (void)hipEventDestroy(hc->ev1);
@@ -1052,6 +1054,32 @@ int htm_chains_step_end(htm_chains *hc, const void *d_gathered_records)
     // iteration); anything that looks at the state flushes it first (flush_pending)
     hc->pending_gathered = static_cast<const double *>(d_gathered_records);
     return HTM_OK;
+}
+
+int htm_chains_swap_record_host(htm_chains *hc, double *record)
+{
+    if (!hc || !record) return fail(HTM_EINVAL, "NULL argument");
+    HIPCHK(hipSetDevice(hc->fwd->device));
+    const size_t words = 4 + 2 * (size_t)hc->dev.n_chains;
+    HIPCHK(hipMemcpyAsync(record, hc->dev.swap_rec, words * sizeof(double), hipMemcpyDeviceToHost, hc->fwd->stream));
+    return bounded_stream_sync(hc, "waiting for the iteration's swap record");
+}
+
+int htm_chains_step_end_host(htm_chains *hc, const double *gathered_records)
+{
+    if (!hc || !gathered_records) return fail(HTM_EINVAL, "NULL argument");
+    HIPCHK(hipSetDevice(hc->fwd->device));
+    const size_t words = (4 + 2 * (size_t)hc->dev.n_chains) * (size_t)hc->dev.n_procs;
+    if (!hc->d_gath_host) {
+        int rc = dev_alloc(hc->pool, &hc->d_gath_host, words);
+        if (rc) return rc;
+        HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&hc->h_gath_pinned), words * sizeof(double), hipHostMallocDefault));
+    }
+    // the caller may reuse its array at once: stage through pinned memory (the previous copy has completed --
+    // swap_record_host of this iteration waited for the stream)
+    std::memcpy(hc->h_gath_pinned, gathered_records, words * sizeof(double));
+    HIPCHK(hipMemcpyAsync(hc->d_gath_host, hc->h_gath_pinned, words * sizeof(double), hipMemcpyHostToDevice, hc->fwd->stream));
+    return htm_chains_step_end(hc, hc->d_gath_host);
 }
 
 int htm_chains_sync(htm_chains *hc)

@@ -15,7 +15,10 @@ module cls_forward
   use htm_c_api
   implicit none
   private
-  public :: forward
+  public :: forward, htm_default_device
+
+  !> device used when HTM_DEVICE is not set; the MPI driver sets it to (local rank mod device count)
+  integer, save :: htm_default_device = -1
 
   type forward
      private
@@ -73,7 +76,7 @@ contains
     t_stdv = obs%get_t_stdv()
     a_obs = obs%get_a_obs()
     a_stdv = obs%get_a_stdv()
-    device = 0                       ! one rank per GPU: HTM_DEVICE (or the launcher's local rank) selects it
+    device = max(0, htm_default_device)   ! one rank per GPU: HTM_DEVICE, else what the MPI driver chose, else 0
     call get_environment_variable("HTM_DEVICE", env, status=ios)
     if (ios == 0) read(env, *, iostat=ios) device
     call check(htm_forward_create(int(n_sta, c_int), int(n_events, c_int), sta_x, sta_y, sta_z, &

@@ -11,6 +11,8 @@ module htm_c_api
   public :: htm_chains_create, htm_chains_destroy, htm_chains_run, htm_chains_get_state, htm_chains_get_rng
   public :: htm_chains_lik_count, htm_chains_lik_read, htm_chains_sample_count, htm_chains_sample_read
   public :: htm_chains_iterations_done
+  public :: htm_chains_step_begin, htm_chains_swap_record_host, htm_chains_step_end_host, htm_chains_drain
+  public :: htm_device_count
   public :: htm_chains_checkpoint_size, htm_chains_checkpoint_save, htm_chains_checkpoint_load
 
   !> one `type model` group stacked over the chains of the rank (include/htm_hip.h: htm_model_init)
@@ -140,6 +142,35 @@ module htm_c_api
        integer(c_int), intent(out) :: n
        integer(c_int) :: rc
      end function htm_chains_iterations_done
+
+     !> lock-step iteration of a multi-rank job, records staged through host memory (MPI programs)
+     function htm_chains_step_begin(handle) bind(C, name="htm_chains_step_begin") result(rc)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: handle
+       integer(c_int) :: rc
+     end function htm_chains_step_begin
+     function htm_chains_swap_record_host(handle, record) bind(C, name="htm_chains_swap_record_host") result(rc)
+       import :: c_int, c_double, c_ptr
+       type(c_ptr), value :: handle
+       real(c_double), intent(out) :: record(*)
+       integer(c_int) :: rc
+     end function htm_chains_swap_record_host
+     function htm_chains_step_end_host(handle, gathered) bind(C, name="htm_chains_step_end_host") result(rc)
+       import :: c_int, c_double, c_ptr
+       type(c_ptr), value :: handle
+       real(c_double), intent(in) :: gathered(*)
+       integer(c_int) :: rc
+     end function htm_chains_step_end_host
+     function htm_chains_drain(handle) bind(C, name="htm_chains_drain") result(rc)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: handle
+       integer(c_int) :: rc
+     end function htm_chains_drain
+     function htm_device_count(n) bind(C, name="htm_device_count") result(rc)
+       import :: c_int
+       integer(c_int), intent(out) :: n
+       integer(c_int) :: rc
+     end function htm_device_count
 
      !> checkpoint / resume (include/htm_hip.h); blob = c_loc of a byte buffer of htm_chains_checkpoint_size bytes
      function htm_chains_checkpoint_size(handle, bytes) bind(C, name="htm_chains_checkpoint_size") result(rc)

@@ -4,11 +4,17 @@
 !>
 !>   hypo_tremor_mcmc_hip <parameter file>
 !>
-!> One process drives one GPU (n_procs = 1 in this program; multi-GPU jobs run one rank per GPU through
-!> the Python launcher, see INTEGRATION.md).  Set-up follows the reference line by line so that the random
-!> stream is consumed in the same order: station corrections, amplitude corrections, hypocentres, then the
-!> temperature of each tempered chain.
+!> One process drives one GPU.  Built twice from this file (preprocessed): `hypo_tremor_mcmc_hip` (one rank, the
+!> whole loop in one persistent kernel) and, with -DHTM_MPI, `hypo_tremor_mcmc_hip_mpi`: an MPI program like the
+!> reference (`mpiexec -np N`, n_procs = N), rank r on GPU (r mod #GPUs) unless HTM_DEVICE says otherwise; the
+!> ranks exchange one small record per iteration with MPI_Allgather (the reference: one MPI_Bcast + two
+!> send/recv pairs, src/cls_parallel.f90:118-213) -- the RCCL form of the same exchange is the Python launcher's,
+!> see INTEGRATION.md.  Set-up follows the reference line by line so that the random stream is consumed in the
+!> same order: station corrections, amplitude corrections, hypocentres, then the temperature of each tempered chain.
 program hypo_tremor_mcmc_hip
+#ifdef HTM_MPI
+  use mpi
+#endif
   use, intrinsic :: iso_c_binding
   use, intrinsic :: iso_fortran_env, only: iostat_end
   use htm_c_api
@@ -16,7 +22,7 @@ program hypo_tremor_mcmc_hip
   use htm_param, only: param, line_max
   use cls_model, only: model
   use cls_obs_data, only: obs_data
-  use cls_forward, only: forward
+  use cls_forward, only: forward, htm_default_device
   implicit none
 
   type(param) :: para
@@ -28,7 +34,9 @@ program hypo_tremor_mcmc_hip
   character(line_max) :: param_file
   integer, allocatable :: win_id(:)
   double precision, allocatable :: x_mu(:), y_mu(:)
-  integer :: n_events, n_sta, n_chains, i, j, io, id, ierr, rank
+  integer :: n_events, n_sta, n_chains, i, j, io, id, ierr, rank, n_ranks
+  integer(c_int) :: n_dev
+  real(c_double), allocatable :: rec(:), gathered(:)
   double precision :: dummy
   double precision, parameter :: eps = epsilon(1.d0)
   ! chain-major stacks handed to htm_chains_create
@@ -38,13 +46,26 @@ program hypo_tremor_mcmc_hip
   real(c_double), allocatable, target :: vx(:), vmu(:), vsg(:), vst(:), qx(:), qmu(:), qsg(:), qst(:), temps(:)
   integer(c_int32_t), allocatable, target :: hpt(:,:), tpt(:,:), apt(:,:), vpt(:), qpt(:)
 
-  rank = 0
+  rank = 0; n_ranks = 1
+#ifdef HTM_MPI
+  call mpi_init(ierr)
+  call mpi_comm_size(MPI_COMM_WORLD, n_ranks, ierr)
+  call mpi_comm_rank(MPI_COMM_WORLD, rank, ierr)
+  if (htm_device_count(n_dev) == 0 .and. n_dev > 0) htm_default_device = mod(rank, int(n_dev))
+#endif
   if (command_argument_count() /= 1) error stop "USAGE: hypo_tremor_mcmc [parameter file]"
   call get_command_argument(1, param_file)
-  call para%load(trim(param_file), verb=.true.)
-  if (para%n_procs /= 1) then
-     write(*, *) "ERROR: n_procs in parameter file must be equal to that is given in the command line"
-     write(*, *) "       (this program drives one GPU; use the multi-rank launcher for n_procs > 1)"
+  call para%load(trim(param_file), verb=(rank == 0))
+  if (para%n_procs /= n_ranks) then
+     if (rank == 0) then
+        write(*, *) "ERROR: n_procs in parameter file must be equal to that is given in the command line"
+#ifndef HTM_MPI
+        write(*, *) "       (this program drives one GPU; hypo_tremor_mcmc_hip_mpi or the Python launcher run n_procs > 1)"
+#endif
+     end if
+#ifdef HTM_MPI
+     call mpi_abort(MPI_COMM_WORLD, MPI_ERR_OTHER, ierr)
+#endif
      stop 1
   end if
   call rng_seed([5551111, 453222, 4444431, 6765], rank)
@@ -63,7 +84,7 @@ program hypo_tremor_mcmc_hip
   n_sta = para%n_stations
   n_chains = para%n_chains
 
-  obs = obs_data(win_id=win_id, n_sta=n_sta, sta_x=para%sta_x, sta_y=para%sta_y, verb=.true.)
+  obs = obs_data(win_id=win_id, n_sta=n_sta, sta_x=para%sta_x, sta_y=para%sta_y, verb=(rank == 0))
   allocate(x_mu(n_events), y_mu(n_events))
   call obs%make_initial_guess(x_mu, y_mu)
   fwd = forward(n_sta=n_sta, n_events=n_events, sta_x=para%sta_x, sta_y=para%sta_y, sta_z=para%sta_z, &
@@ -131,7 +152,7 @@ program hypo_tremor_mcmc_hip
      end if
   end do
 
-  init%n_chains = n_chains; init%n_procs = 1; init%rank = rank
+  init%n_chains = n_chains; init%n_procs = n_ranks; init%rank = rank
   init%hypo = pack_model(hx, hmu, hsg, hst, hpt)
   init%t_corr = pack_model(tx, tmu, tsg, tst, tpt)
   init%a_corr = pack_model(ax, amu, asg, ast, apt)
@@ -146,14 +167,35 @@ program hypo_tremor_mcmc_hip
   init%n_burn = para%n_burn; init%n_interval = para%n_interval
   call check(htm_chains_create(fwd%c_handle(), init, chains), "htm_chains_create")
 
-  print *, "start MCMC"
+  if (rank == 0) print *, "start MCMC"
+#ifdef HTM_MPI
+  ! main loop of src/hypo_tremor_mcmc.f90:236-284 with swap_temperature (src/cls_parallel.f90:100-216) as ONE
+  ! all-gather of every rank's record {pair chosen by rank 0, pending judge_swap draw, (T, L) of its chains}
+  allocate(rec(4 + 2 * n_chains), gathered((4 + 2 * n_chains) * n_ranks))
+  do i = 1, para%n_iter
+     call check(htm_chains_step_begin(chains), "htm_chains_step_begin")
+     call check(htm_chains_swap_record_host(chains, rec), "htm_chains_swap_record_host")
+     call mpi_allgather(rec, size(rec), MPI_DOUBLE_PRECISION, gathered, size(rec), MPI_DOUBLE_PRECISION, &
+          & MPI_COMM_WORLD, ierr)
+     call check(htm_chains_step_end_host(chains, gathered), "htm_chains_step_end_host")
+     if (mod(i, 1000) == 0) then
+        call check(htm_chains_drain(chains), "htm_chains_drain")
+        if (rank == 0) call summary(i)
+     end if
+  end do
+  call check(htm_chains_drain(chains), "htm_chains_drain")
+#else
   do i = 0, para%n_iter - 1, 1000
      call check(htm_chains_run(chains, int(min(1000, para%n_iter - i), c_int)), "htm_chains_run")
      call summary(min(i + 1000, para%n_iter))
   end do
+#endif
 
   call write_outputs()
   call check(htm_chains_destroy(chains), "htm_chains_destroy")
+#ifdef HTM_MPI
+  call mpi_finalize(ierr)
+#endif
 
 contains
 
@@ -227,11 +269,23 @@ contains
        call check(htm_chains_get_state(chains, int(c, c_int), h, tc, v, ac, q, t, l, np, na), "htm_chains_get_state")
        np_sum = np_sum + np; na_sum = na_sum + na
     end do
-    open(newunit=io_l, file="proposal_count.txt", status="unknown")
-    do c = 1, 7
-       write(io_l, '(A,2I10)') '"' // label(c) // '"', np_sum(c), na_sum(c)
-    end do
-    close(io_l)
+#ifdef HTM_MPI
+    ! src/cls_parallel.f90:244-281: counters of all ranks summed on rank 0
+    block
+      integer(c_int32_t) :: np_all(7), na_all(7)
+      integer :: ie
+      call mpi_reduce(np_sum, np_all, 7, MPI_INTEGER4, MPI_SUM, 0, MPI_COMM_WORLD, ie)
+      call mpi_reduce(na_sum, na_all, 7, MPI_INTEGER4, MPI_SUM, 0, MPI_COMM_WORLD, ie)
+      np_sum = np_all; na_sum = na_all
+    end block
+#endif
+    if (rank == 0) then
+       open(newunit=io_l, file="proposal_count.txt", status="unknown")
+       do c = 1, 7
+          write(io_l, '(A,2I10)') '"' // label(c) // '"', np_sum(c), na_sum(c)
+       end do
+       close(io_l)
+    end if
   end subroutine write_outputs
 
 end program hypo_tremor_mcmc_hip

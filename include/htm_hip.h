@@ -168,6 +168,13 @@ typedef int (*htm_allgather_fn)(const void *sendbuff, void *recvbuff, size_t cou
                                 void *stream);
 int htm_chains_run_lockstep(htm_chains *hc, int n_iter, htm_allgather_fn allgather, void *comm,
                             void *d_gathered);
+/* Host-staged form of the same exchange for MPI programs (the Fortran driver): after step_begin,
+ * swap_record_host waits for the iteration and copies this rank's record (4 + 2*n_chains doubles) to host memory;
+ * the caller all-gathers the records of all ranks (MPI_Allgather) and hands the n_procs records back with
+ * step_end_host, which stages them in device memory.  Costs two small PCIe copies per iteration: a
+ * compatibility path -- the RCCL path above keeps everything on the device. */
+int htm_chains_swap_record_host(htm_chains *hc, double *record);
+int htm_chains_step_end_host(htm_chains *hc, const double *gathered_records);
 int htm_chains_sync(htm_chains *hc);        /* wait + raise device-side error flags */
 int htm_chains_drain(htm_chains *hc);       /* sync + move device record buffers to host memory */
 
