@@ -99,6 +99,14 @@ class ChainSet:
     def step_end(self, d_gathered: int):
         check(self._lib.htm_chains_step_end(self.handle, C.c_void_p(d_gathered)))
 
+    def swap_record_host(self, out: np.ndarray):
+        """wait for the iteration and copy this rank's record into `out` (float64[4 + 2 n_chains], host)"""
+        check(self._lib.htm_chains_swap_record_host(self.handle, out.ctypes.data_as(dp)))
+
+    def step_end_host(self, gathered: np.ndarray):
+        """all ranks' records from host memory (float64[n_procs * (4 + 2 n_chains)])"""
+        check(self._lib.htm_chains_step_end_host(self.handle, gathered.ctypes.data_as(dp)))
+
     def run_lockstep(self, n_iter: int, allgather_fn: int, comm: int, d_gathered: int):
         """n_iter lock-step iterations driven from C (see htm_chains_run_lockstep): allgather_fn is the
         address of an ncclAllGather-compatible function, comm the rank's communicator handle."""

@@ -74,6 +74,11 @@ class TorchWorld:
         if self.world != rank_obj.n_procs or dist.get_rank(group) != rank_obj.rank:
             raise ValueError("torch.distributed world/rank do not match the chain set's n_procs/rank")
         self.rec = rank_obj.record
+        # A backend without device collectives (gloo) and a rank on a GPU: stage the 160-byte records through
+        # host memory (htm_chains_swap_record_host / _step_end_host) -- the exchange an MPI program would do.
+        self.host_staged = isinstance(rank_obj, DeviceRank) and dist.get_backend(group) != "nccl"
+        if self.host_staged:
+            self.rec = torch.zeros(self.rec.numel(), dtype=torch.float64)
         self.gathered = torch.zeros(self.world * self.rec.numel(), dtype=torch.float64, device=self.rec.device)
         # records a rank may hold between drains: n_chains per iteration at most
         self.drain_every = 4096
@@ -107,6 +112,11 @@ class TorchWorld:
 
     def step(self):
         self.r.step_begin()
+        if self.host_staged:
+            self.r.cs.swap_record_host(self.rec.numpy())
+            self.dist.all_gather_into_tensor(self.gathered, self.rec, group=self.group)
+            self.r.cs.step_end_host(self.gathered.numpy())
+            return
         self.dist.all_gather_into_tensor(self.gathered, self.rec, group=self.group)
         self.r.step_end(self.gathered)
 
@@ -123,7 +133,7 @@ class TorchWorld:
 
     def reduce_counts(self):
         npr, nac = self.r.counts()
-        t = self.torch.tensor(np.concatenate([npr, nac]).astype(np.int64), device=self.rec.device)
+        t = self.torch.tensor(np.concatenate([npr, nac]).astype(np.int64), device=self.gathered.device)
         self.dist.all_reduce(t, group=self.group)
         t = t.cpu().numpy()
         return t[:7], t[7:]

@@ -4,6 +4,8 @@ reference's own output (golden fixtures) and against the oracle.
 Criterion (north_star / SURVEY §8d): log-likelihood traces within 1e-9 relative per record, identical
 accept/reject decisions (=> identical proposal_count.txt), identical RNG consumption (=> identical final
 RNG state)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -304,3 +306,54 @@ def test_random_stream_ring_wraps_around(lockstep, monkeypatch):
     assert sets[0].rng_state() == job.rng_state(0)
     a, b = sets[0].counts(); oa, ob = job.counts()
     assert np.array_equal(a, oa) and np.array_equal(b, ob)
+
+
+def _gloo_device_worker(rank, world, port, name, q):
+    import sys
+
+    sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    from hypotremormcmc_amd import driver
+    from hypotremormcmc_amd.obs_data import ObsData
+    from hypotremormcmc_amd.parallel import TorchWorld
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fx, data, params = load_case(name)
+        obs = ObsData.from_arrays(data.sta_x, data.sta_y, data.t_obs, data.t_stdv, data.a_obs, data.a_stdv)
+        fwd, cs = driver.build_rank(params, data.sta_x, data.sta_y, data.sta_z, obs, rank, n_procs=world, device=0)
+        tw = TorchWorld(cs)
+        assert tw.host_staged and tw.fast is None
+        tw.run(int(params["n_iter"]))
+        it, ch, lk = cs.likelihood_trace()
+        ok = np.array_equal(it, fx[f"lik_iter_{rank}"]) and np.allclose(lk, fx[f"lik_{rank}"], rtol=RTOL_TRACE, atol=0)
+        npr, nac = tw.reduce_counts()
+        ok = ok and np.array_equal(npr, fx["n_propose"]) and np.array_equal(nac, fx["n_accept"])
+        q.put((rank, bool(ok), len(it)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,world", [("c1", 2), ("timeonly", 3)])
+def test_torchworld_across_processes_sharing_the_gpu(name, world):
+    """TorchWorld + device-resident chains in 2-3 separate processes (one GPU, so gloo with host-staged records
+    instead of RCCL): per-rank traces and the reduced counters against the reference's MPI run."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_device_worker, args=(r, world, port, name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=400) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == list(range(world)) and all(r[1] for r in res), res
