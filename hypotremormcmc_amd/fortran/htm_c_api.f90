@@ -12,7 +12,7 @@ module htm_c_api
   public :: htm_chains_lik_count, htm_chains_lik_read, htm_chains_sample_count, htm_chains_sample_read
   public :: htm_chains_iterations_done
   public :: htm_chains_step_begin, htm_chains_swap_record_host, htm_chains_step_end_host, htm_chains_drain
-  public :: htm_device_count
+  public :: htm_device_count, htm_quantiles
   public :: htm_chains_checkpoint_size, htm_chains_checkpoint_save, htm_chains_checkpoint_load
 
   !> one `type model` group stacked over the chains of the rank (include/htm_hip.h: htm_model_init)
@@ -166,6 +166,16 @@ module htm_c_api
        type(c_ptr), value :: handle
        integer(c_int) :: rc
      end function htm_chains_drain
+     !> step-6 order statistics (include/htm_hip.h): samples [n_mod][n_par] row-major, out [n_par][3]
+     function htm_quantiles(device, samples, n_mod, n_par, ranks_1based, out) bind(C, name="htm_quantiles") result(rc)
+       import :: c_int, c_long, c_double
+       integer(c_int), value :: device
+       real(c_double), intent(in) :: samples(*)
+       integer(c_long), value :: n_mod, n_par
+       integer(c_int), intent(in) :: ranks_1based(3)
+       real(c_double), intent(out) :: out(*)
+       integer(c_int) :: rc
+     end function htm_quantiles
      function htm_device_count(n) bind(C, name="htm_device_count") result(rc)
        import :: c_int
        integer(c_int), intent(out) :: n

@@ -131,3 +131,25 @@ def test_fortran_mpi_driver_reproduces_reference_outputs(name, tmp_path):
     rows = [ln.split('"') for ln in open(tmp_path / "proposal_count.txt")]
     assert [int(r_[2].split()[0]) for r_ in rows] == fx["n_propose"].tolist()
     assert [int(r_[2].split()[1]) for r_ in rows] == fx["n_accept"].tolist()
+
+
+@pytest.mark.parametrize("name", ["c1", "timeonly", "fixedcorr"])
+def test_fortran_statistics_program_writes_the_reference_stat_files(name, tmp_path):
+    """hypo_tremor_statistics_hip on the sample files the reference's step 5 wrote (rebuilt from the fixture):
+    the four .stat files must be the reference step 6's, character for character."""
+    fx, data, params = load_case(name)
+    n_procs = int(params["n_procs"])
+    synth.write_dataset(str(tmp_path), data)
+    synth.write_param_file(str(tmp_path / "run.in"), **{k: v for k, v in params.items()})
+    E, S = data.n_events, data.n_sta
+    for r in range(n_procs):
+        for nm, nv in (("vs", 1), ("qs", 1), ("t_corr", S), ("a_corr", S), ("hypo", 3 * E)):
+            it, v = fx[f"{nm}_iter_{r}"], fx[f"{nm}_{r}"].reshape(len(fx[f"{nm}_iter_{r}"]), nv)
+            rec = np.zeros(len(it), dtype=np.dtype([("iter", "<i4"), ("val", "<f8", (nv,))]))
+            rec["iter"] = it; rec["val"] = v
+            rec.tofile(tmp_path / ("%s.%02d.out" % (nm, r)))
+    res = subprocess.run([_need("hypo_tremor_statistics_hip"), "run.in"], cwd=tmp_path, timeout=600, capture_output=True,
+                         text=True)
+    assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-1500:])
+    for fn in ("uniform_structure.stat", "station_corrections.stat", "hypo.stat", "hypo.stat.removed"):
+        assert open(tmp_path / fn).read() == str(fx["stat_" + fn.replace(".", "_")]), fn
