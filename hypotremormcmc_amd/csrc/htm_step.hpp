@@ -1065,21 +1065,26 @@ __device__ __forceinline__ void worker_body(const FwdDev &f, const ChainsDev &cs
                     st.ac[c] = valid ? ld_agent(ac + j) : 0.0;
                     if (valid && ov_idx == j) { if (ov_kind == 2) st.tc[c] = ov_val; if (ov_kind == 4) st.ac[c] = ov_val; }
                 }
+                // Events ev0, ev0 + 8W, ...: the first one's observation rows are resident (ob0); every further event's
+                // rows and coordinates are requested BEFORE the current event is evaluated (software pipeline, one
+                // event of look-ahead), so that at E >> 8W the loads of event k+1 fly under the arithmetic of k.
+                ObsRegs<NCH> ob_cur = ob0, ob_nxt = ob0;
+                double cx = 0.0, cy = 0.0, cz = 0.0, nx = 0.0, ny = 0.0, nz = 0.0;
+                if (ev0 < f.E) { cx = ld_agent(hyp + 3 * ev0); cy = ld_agent(hyp + 3 * ev0 + 1); cz = ld_agent(hyp + 3 * ev0 + 2); }
                 for (int ev = ev0; ev < f.E; ev += 8 * W) {
-                    const bool ov = ev == ov_evt;
-                    const double hx = ld_agent(hyp + 3 * ev), hy = ld_agent(hyp + 3 * ev + 1), hz = ld_agent(hyp + 3 * ev + 2);
-                    const double px[1] = {(ov && ov_cmp == 0) ? ov_val : hx};
-                    const double py[1] = {(ov && ov_cmp == 1) ? ov_val : hy};
-                    const double pz[1] = {(ov && ov_cmp == 2) ? ov_val : hz};
-                    double out[1];
-                    if (ev == ev0) {
-                        event_misfit<NCH, 1>(f, ob0, lane, st, px, py, pz, beta, q, out);
-                    } else {
-                        ObsRegs<NCH> ob;
-                        load_obs_regs<NCH>(ob, f, ev, lane);
-                        event_misfit<NCH, 1>(f, ob, lane, st, px, py, pz, beta, q, out);
+                    const int evn = ev + 8 * W;
+                    if (evn < f.E) {
+                        load_obs_regs<NCH>(ob_nxt, f, evn, lane);
+                        nx = ld_agent(hyp + 3 * evn); ny = ld_agent(hyp + 3 * evn + 1); nz = ld_agent(hyp + 3 * evn + 2);
                     }
+                    const bool ov = ev == ov_evt;
+                    const double px[1] = {(ov && ov_cmp == 0) ? ov_val : cx};
+                    const double py[1] = {(ov && ov_cmp == 1) ? ov_val : cy};
+                    const double pz[1] = {(ov && ov_cmp == 2) ? ov_val : cz};
+                    double out[1];
+                    event_misfit<NCH, 1>(f, ob_cur, lane, st, px, py, pz, beta, q, out);
                     lane_acc += out[0];
+                    ob_cur = ob_nxt; cx = nx; cy = ny; cz = nz;
                 }
             } else {
                 // generic station count: corrections are read through plain loads after an agent acquire
