@@ -7,7 +7,7 @@
  * (src/cls_mcmc.f90:7-53, src/cls_parallel.f90:7-22) driven by `program main`
  * (src/hypo_tremor_mcmc.f90:236-284).  Each entry point below names the reference interface it
  * replaces.  The Fortran ISO_C_BINDING module that re-creates `type forward` on top of these symbols is
- * hypotremormcmc_amd/fortran/htm_forward_mod.f90 (shown in INTEGRATION.md).
+ * hypotremormcmc_amd/fortran/cls_forward_hip.f90 over htm_c_api.f90 (shown in INTEGRATION.md).
  *
  * Conventions
  *   - plain C, no C++/torch types; every function returns 0 on success, a negative HTM_E* code otherwise;
