@@ -122,10 +122,6 @@ struct htm_chains {
     long long spos_lo = 0, spos_hi = 0;        // bounds on the consumed position since the last sync
     const double *pending_gathered = nullptr;  // lock-step: records whose swap the next k_step applies
     double *d_gath_host = nullptr, *h_gath_pinned = nullptr;   // staging buffers of htm_chains_step_end_host
-    bool split = false;                        // HTM_SPLIT=1: master and workers as two kernels on two streams (experimental)
-    ChainsDev dev_split{};
-    hipStream_t wstream = nullptr;
-    int split_waves = 8;
     unsigned long long launch_seq = 0;         // k_mcmc launches of this chain set so far (the kernels' launch index)
     bool persist = true;                       // k_mcmc (master + resident full-evaluation workers) vs k_step + k_full
     ChainsDev dev_np{};                        // view for the non-persistent kernels (partial sums per k_full tile)
@@ -167,23 +163,6 @@ int launch_mcmc(htm_chains *hc, int mode, int target, const double *gathered)
     case 1: hipLaunchKernelGGL(k_mcmc<1>, grid, block, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax, seq); break;
     case 2: hipLaunchKernelGGL(k_mcmc<2>, grid, block, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax, seq); break;
     default: hipLaunchKernelGGL(k_mcmc<0>, grid, block, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax, seq); break;
-    }
-    HIPCHK(hipGetLastError());
-    return HTM_OK;
-}
-
-int launch_split(htm_chains *hc, int mode, int target, const double *gathered)
-{
-    htm_forward *h = hc->fwd;
-    const unsigned long long seq = ++hc->launch_seq;
-    const dim3 wgrid(hc->dev_split.n_workers), wblock(64 * hc->split_waves);
-    switch (h->nch) {
-    case 1: hipLaunchKernelGGL(k_worker<1>, wgrid, wblock, 1024, hc->wstream, h->dev, hc->dev_split, seq);
-            hipLaunchKernelGGL(k_master<1>, dim3(1), dim3(512), hc->step_smem, h->stream, h->dev, hc->dev_split, mode, target, gathered, hc->ring_size, hc->wmax, seq); break;
-    case 2: hipLaunchKernelGGL(k_worker<2>, wgrid, wblock, 1024, hc->wstream, h->dev, hc->dev_split, seq);
-            hipLaunchKernelGGL(k_master<2>, dim3(1), dim3(512), hc->step_smem, h->stream, h->dev, hc->dev_split, mode, target, gathered, hc->ring_size, hc->wmax, seq); break;
-    default: hipLaunchKernelGGL(k_worker<0>, wgrid, wblock, 1024, hc->wstream, h->dev, hc->dev_split, seq);
-            hipLaunchKernelGGL(k_master<0>, dim3(1), dim3(512), hc->step_smem, h->stream, h->dev, hc->dev_split, mode, target, gathered, hc->ring_size, hc->wmax, seq); break;
     }
     HIPCHK(hipGetLastError());
     return HTM_OK;
@@ -730,21 +709,6 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
         return cleanup(fail(HTM_EHIP, "hipEventCreate failed"));
     hc->dev_np = hc->dev;                       // same state; partial sums laid out per k_full tile
     hc->dev.n_wg = hc->dev.n_workers;           // persistent kernel: one partial per worker block
-    {
-        const char *e = getenv("HTM_SPLIT");
-        hc->split = e && e[0] == '1';
-        if (hc->split) {
-            hc->split_waves = h->E > 8 * 240 ? 16 : 8;
-            hc->dev_split = hc->dev;
-            hc->dev_split.n_workers = std::max(1, std::min(240, (h->E + hc->split_waves - 1) / hc->split_waves));
-            hc->dev_split.n_wg = hc->dev_split.n_workers;
-            if (hipStreamCreateWithFlags(&hc->wstream, hipStreamNonBlocking) != hipSuccess) return cleanup(fail(HTM_EHIP, "worker stream"));
-            if (hc->step_smem > 48 * 1024) {
-                const void *fn = h->nch == 1 ? (const void *)k_master<1> : h->nch == 2 ? (const void *)k_master<2> : (const void *)k_master<0>;
-                HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hc->step_smem));
-            }
-        }
-    }
     if (hc->step_smem < 1024) hc->step_smem = 1024;
     if (hc->step_smem > 48 * 1024) {
         const void *fn = h->nch == 1 ? (const void *)k_mcmc<1> : h->nch == 2 ? (const void *)k_mcmc<2> : (const void *)k_mcmc<0>;
@@ -765,7 +729,6 @@ int htm_chains_destroy(htm_chains *hc)
     (void)hipStreamSynchronize(hc->fwd->stream);
     if (hc->ev_side) (void)hipEventDestroy(hc->ev_side);
     if (hc->side) (void)hipStreamDestroy(hc->side);
-    if (hc->wstream) { (void)hipStreamSynchronize(hc->wstream); (void)hipStreamDestroy(hc->wstream); }
     if (hc->gexec) (void)hipGraphExecDestroy(hc->gexec);
     if (hc->graph) (void)hipGraphDestroy(hc->graph);
     for (void *p : hc->pool) (void)hipFree(p);
@@ -901,7 +864,7 @@ static int run_persistent(htm_chains *hc, int n_iter)
         // a launch may run as far as the produced stream reaches
         const long long fed = (hc->n_hop - hc->h_ctrl.spos) / (6 * hc->dev.n_chains + 4) - 2;
         const int target = (int)std::min<long long>(hc->h_target, hc->h_ctrl.iter_done + std::max<long long>(1, fed));
-        if ((rc = hc->split ? launch_split(hc, MODE_RUN, target, nullptr) : launch_mcmc(hc, MODE_RUN, target, nullptr))) return rc;
+        if ((rc = launch_mcmc(hc, MODE_RUN, target, nullptr))) return rc;
         hc->last_graph_launches += 1;
         // keep the random stream about half a ring ahead (asynchronous, side stream), while the launch runs
         {

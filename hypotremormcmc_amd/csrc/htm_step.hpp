@@ -926,17 +926,16 @@ __global__ __launch_bounds__(512) void k_step(FwdDev f, ChainsDev cs, int mode, 
 // (the master drained its stores before publishing it).  Leaves when the master has finished (PSync::quit)
 // or after a bounded wait.
 template <int NCH>
-__device__ __forceinline__ void worker_body(const FwdDev &f, const ChainsDev &cs, unsigned long long launch, int w)
+__device__ __forceinline__ void worker_body(const FwdDev &f, const ChainsDev &cs, unsigned long long launch)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *s_red = reinterpret_cast<double *>(smem);          // [8]
     unsigned *s_tag = reinterpret_cast<unsigned *>(smem + 128);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int W = cs.n_workers;
-    const int NWV = blockDim.x >> 6;                   // waves per worker block: 8, or 16 in the split-kernel form
+    const int w = blockIdx.x - 1, W = cs.n_workers;
     const int nc = cs.n_chains;
-    const int ev0 = w * NWV + wave;
+    const int ev0 = w * 8 + wave;
 
     constexpr int N = NCH > 0 ? NCH : 1;
     StaRegs<N> st;
@@ -1072,8 +1071,8 @@ __device__ __forceinline__ void worker_body(const FwdDev &f, const ChainsDev &cs
                 ObsRegs<NCH> ob_cur = ob0, ob_nxt = ob0;
                 double cx = 0.0, cy = 0.0, cz = 0.0, nx = 0.0, ny = 0.0, nz = 0.0;
                 if (ev0 < f.E) { cx = ld_agent(hyp + 3 * ev0); cy = ld_agent(hyp + 3 * ev0 + 1); cz = ld_agent(hyp + 3 * ev0 + 2); }
-                for (int ev = ev0; ev < f.E; ev += NWV * W) {
-                    const int evn = ev + NWV * W;
+                for (int ev = ev0; ev < f.E; ev += 8 * W) {
+                    const int evn = ev + 8 * W;
                     if (evn < f.E) {
                         load_obs_regs<NCH>(ob_nxt, f, evn, lane);
                         nx = ld_agent(hyp + 3 * evn); ny = ld_agent(hyp + 3 * evn + 1); nz = ld_agent(hyp + 3 * evn + 2);
@@ -1090,7 +1089,7 @@ __device__ __forceinline__ void worker_body(const FwdDev &f, const ChainsDev &cs
             } else {
                 // generic station count: corrections are read through plain loads after an agent acquire
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                for (int ev = ev0; ev < f.E; ev += NWV * W) {
+                for (int ev = ev0; ev < f.E; ev += 8 * W) {
                     const bool ov = ev == ov_evt;
                     const double hx = ld_agent(hyp + 3 * ev), hy = ld_agent(hyp + 3 * ev + 1), hz = ld_agent(hyp + 3 * ev + 2);
                     const double px[1] = {(ov && ov_cmp == 0) ? ov_val : hx};
@@ -1113,9 +1112,7 @@ __device__ __forceinline__ void worker_body(const FwdDev &f, const ChainsDev &cs
 #endif
             if (tid == 0)
                 st_gran_f64(cs.pgran + ((size_t)m * cs.n_wg + w) * cs.pgran_stride, tag,
-                            NWV == 8 ? ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) + ((s_red[4] + s_red[5]) + (s_red[6] + s_red[7]))
-                                     : (((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) + ((s_red[4] + s_red[5]) + (s_red[6] + s_red[7]))) +
-                                       (((s_red[8] + s_red[9]) + (s_red[10] + s_red[11])) + ((s_red[12] + s_red[13]) + (s_red[14] + s_red[15]))));
+                            ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) + ((s_red[4] + s_red[5]) + (s_red[6] + s_red[7])));
             __syncthreads();
         }
     }
@@ -1135,26 +1132,8 @@ __global__ __launch_bounds__(512) void k_mcmc(FwdDev f, ChainsDev cs, int mode, 
         __syncthreads();
         if (threadIdx.x == 0) st_agent(&cs.ps->quit, launch + 1ull);
     } else {
-        worker_body<NCH>(f, cs, launch, (int)blockIdx.x - 1);
+        worker_body<NCH>(f, cs, launch);
     }
-}
-
-// The same two roles as TWO kernels on two streams (opt-in, HTM_SPLIT=1): the master keeps its 256-VGPR budget to
-// itself, the workers are compiled for their own needs (more waves per CU: 16-wave blocks at large E).  Needs
-// both kernels resident at the same time, which two streams normally give but nothing guarantees -- the
-// master's bounded wait (error -8) is the detector, the host falls back to k_mcmc.
-template <int NCH>
-__global__ __launch_bounds__(512) void k_master(FwdDev f, ChainsDev cs, int mode, int target_arg, const double *gathered,
-                                                 int ring_size, int wmax, unsigned long long launch)
-{
-    step_body<NCH, true>(f, cs, mode, target_arg, gathered, ring_size, wmax, launch);
-    __syncthreads();
-    if (threadIdx.x == 0) st_agent(&cs.ps->quit, launch + 1ull);
-}
-template <int NCH>
-__global__ __launch_bounds__(1024) void k_worker(FwdDev f, ChainsDev cs, unsigned long long launch)
-{
-    worker_body<NCH>(f, cs, launch, (int)blockIdx.x);
 }
 
 }  // namespace htm
