@@ -357,3 +357,19 @@ def test_torchworld_across_processes_sharing_the_gpu(name, world):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(r[0] for r in res) == list(range(world)) and all(r[1] for r in res), res
+
+
+def test_lockstep_on_the_two_kernel_fallback(monkeypatch):
+    """HTM_PERSIST=0 in the multi-rank code path: k_step(advance) -> k_full -> k_step(finish) per iteration"""
+    from hypotremormcmc_amd.parallel import LocalWorld
+
+    monkeypatch.setenv("HTM_PERSIST", "0")
+    fx, data, params = load_case("c1")
+    params = dict(params, n_iter="4000", n_burn="2000")
+    fwd, sets = _build_world(data, params)
+    LocalWorld(sets).run(4000)
+    for r in range(2):
+        it, ch, lk = sets[r].likelihood_trace()
+        n = len(it)
+        assert n > 0 and np.array_equal(it, fx[f"lik_iter_{r}"][:n])
+        np.testing.assert_allclose(lk, fx[f"lik_{r}"][:n], rtol=RTOL_TRACE, atol=0)
