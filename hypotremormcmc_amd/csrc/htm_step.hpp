@@ -47,6 +47,9 @@ struct StepShared {
     int redo;                     // >= 0: chains >= redo repeat their pass; -1: validated; -2: aborted
     int catchup;                  // written between the barriers: the LDS window must be extended first
     Ctrl c;
+#ifdef HTM_STAMPS
+    unsigned long long stamp_acc[96];   // diagnostic cycle accounting of this launch, flushed to ChainsDev::stamps at its end
+#endif
 };
 
 struct Ring {                     // LDS window of the stream rings, index = relative position & mask
@@ -191,7 +194,7 @@ __device__ __forceinline__ bool metropolis(double L_new, double L_cur, double T,
 }
 
 #ifdef HTM_STAMPS
-#define CSTAMP(k) do { if (stamp_me) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); cs.stamps[32 + (k)] += n_ - t_last; t_last = n_; } } while (0)
+#define CSTAMP(k) do { if (stamp_me) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); sh.stamp_acc[32 + (k)] += n_ - t_last; t_last = n_; } } while (0)
 #else
 #define CSTAMP(k) do { } while (0)
 #endif
@@ -623,7 +626,7 @@ __device__ __forceinline__ void apply_swap(const ChainsDev &cs, StepShared &sh, 
     do {                                                                                           \
         if (tid == 0 && cs.stamps) {                                                               \
             const unsigned long long now_ = __builtin_amdgcn_s_memtime();                          \
-            cs.stamps[k] += now_ - stamp_last_;                                                    \
+            sh.stamp_acc[k] += now_ - stamp_last_;   /* LDS: a global RMW here would bill ~1 k cycles to the next phase */ \
             stamp_last_ = now_;                                                                    \
         }                                                                                          \
     } while (0)
@@ -684,6 +687,9 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
     for (int j = tid; j < f.S; j += blockDim.x) { s_sx[j] = f.sx[j]; s_sy[j] = f.sy[j]; s_sz[j] = f.sz[j]; }
     for (int c = tid; c < nc; c += blockDim.x) { sh.temp[c] = cs.temp[c]; sh.L[c] = cs.L[c]; }
     for (int k = tid; k < 7 * nc; k += blockDim.x) { sh.np[k] = 0; sh.na[k] = 0; }
+#ifdef HTM_STAMPS
+    for (int k = tid; k < 96; k += blockDim.x) sh.stamp_acc[k] = 0ull;
+#endif
     for (int k = tid; k < rg.mir_n; k += blockDim.x) { rg.mx[k] = cs.xall[k]; rg.mstep[k] = cs.stall[k]; }
     // the gathered records of the previous lock-step iteration come in with the same round of loads
     const bool do_apply = (mode == MODE_APPLY || mode == MODE_ADVANCE) && gathered != nullptr;
@@ -799,8 +805,8 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
                 if (lane == 0 && cs.stamps && first) {
                     const unsigned long long ta = __builtin_amdgcn_s_memtime();
                     const bool job = nc > wave && sh.prop[wave].need_full != 0;
-                    atomicAdd(&cs.stamps[48 + wave + (job ? 8 : 0)], ta - t_top);
-                    atomicAdd(&cs.stamps[64 + wave + (job ? 8 : 0)], 1ull);
+                    atomicAdd(&sh.stamp_acc[48 + wave + (job ? 8 : 0)], ta - t_top);
+                    atomicAdd(&sh.stamp_acc[64 + wave + (job ? 8 : 0)], 1ull);
                 }
 #endif
                 __syncthreads();                                            // ---- barrier A
@@ -909,6 +915,12 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
     }
     if (tid == 0) *cs.ctrl = sh.c;
     STAMP(5);
+#ifdef HTM_STAMPS
+    __syncthreads();
+    if (cs.stamps)
+        for (int k = tid; k < 96; k += blockDim.x)
+            if (k < 20 || k >= 32) { if (sh.stamp_acc[k]) atomicAdd(&cs.stamps[k], sh.stamp_acc[k]); }
+#endif
 }
 
 template <int NCH>
