@@ -615,6 +615,8 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
         d.pgran_stride = env_int("HTM_PGRAN_STRIDE", 16, 16, 4096) / 8;
         d.npoll = env_int("HTM_NPOLL", 1, 1, 3);
     }
+    if ((rc = dev_alloc(hc->pool, &d.vused, 2 * (size_t)nc))) return cleanup(rc);
+    HIPCHK(hipMemset(d.vused, 0, 2 * (size_t)nc * sizeof(unsigned long long)));
     if ((rc = dev_alloc(hc->pool, &d.slots, (size_t)d.slot_rep * d.slot_stride))) return cleanup(rc);
     HIPCHK(hipMemset(d.slots, 0, (size_t)d.slot_rep * d.slot_stride * sizeof(unsigned long long)));
     if ((rc = dev_alloc(hc->pool, &d.pgran, (size_t)nc * d.n_workers * d.pgran_stride))) return cleanup(rc);
@@ -688,7 +690,7 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
     // stream window: a chain step draws <= 6 numbers, select_pair/judge_swap a few more (cls_parallel.f90:226-230)
     hc->wmax = ((6 * nc + 16 + 63) / 64) * 64;
     hc->ring_size = 256;
-    while (hc->ring_size < 3 * hc->wmax + 64) hc->ring_size *= 2;
+    while (hc->ring_size < 4 * hc->wmax + 64) hc->ring_size *= 2;
     // per LDS ring position: U, LOGU, pg, pr, plogr (5 doubles), dec, sw (int4), hop (kHops ints)
     hc->step_smem = ((sizeof(StepShared) + 15) & ~size_t(15)) +
                     (size_t)hc->ring_size * (5 * sizeof(double) + 2 * sizeof(int4) + kHops * sizeof(int)) +

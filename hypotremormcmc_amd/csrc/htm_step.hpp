@@ -34,8 +34,12 @@ struct StepShared {
     int cnt[kMaxChains];          // draws the step consumed (judge draw included iff prior_ok)
     int slot_l[kMaxChains], slot_s[kMaxChains];
     int redone[kMaxChains];       // the chain repeated its step in this iteration (undo + new commit: role P stays out)
-    int pre_p[kMaxChains];        // >= 0: chain's next step, starting at this position, already has its order out
-    unsigned pre_tag[kMaxChains]; // ... under this tag (k_mcmc, role P)
+    // role P (k_mcmc): [iteration & 1][chain]: the chain's step of that iteration, starting at position pre_p, already
+    // has its order out under pre_tag; pre_mode 1: sent one iteration ahead, 2: two iterations ahead (evaluated on
+    // the state before the step in between; see chain_pass)
+    int pre_p[2][kMaxChains];
+    unsigned pre_tag[2][kMaxChains];
+    int pre_mode[2][kMaxChains];
     int np[kMaxChains * 7], na[kMaxChains * 7];   // proposal / acceptance counters of this launch
     int sw_do, sw_c1, sw_c2;      // swap decided between the barriers; applied by the waves owning the chains
     double sw_T1, sw_T2;          // new temperatures of chains sw_c1 / sw_c2
@@ -46,6 +50,7 @@ struct StepShared {
     int base;                     // relative position at which the current iteration starts
     int redo;                     // >= 0: chains >= redo repeat their pass; -1: validated; -2: aborted
     int catchup;                  // written between the barriers: the LDS window must be extended first
+    int rolep_iter;               // role P has finished for this iteration (see step_body)
     Ctrl c;
 #ifdef HTM_STAMPS
     unsigned long long stamp_acc[96];   // diagnostic cycle accounting of this launch, flushed to ChainsDev::stamps at its end
@@ -212,7 +217,7 @@ __device__ __forceinline__ bool metropolis(double L_new, double L_cur, double T,
 template <int NCH, bool PERSIST>
 __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, StepShared &sh, const Ring &rg,
                                           const double *s_sx, const double *s_sy, const double *s_sz, int c,
-                                          int p, int iter, int lane, unsigned long long launch)
+                                          int p, int iter, int lane, unsigned long long launch, bool wait_rolep)
 {
     const int M = rg.mask;
 #ifdef HTM_STAMPS
@@ -271,6 +276,12 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
     const int cnt = dec_w - 1 + ok;                             // the judge draw happens only if prior_ok
     CSTAMP(1);   // proposal arithmetic (waits for the model loads)
 
+    if constexpr (PERSIST) {
+        // from here on this step reads what role P writes (orders already out) and overwrites what it reads (the
+        // previous step's record, the LDS mirror): role P of this iteration must be through -- it has been for long
+        if (wait_rolep)
+            while (__hip_atomic_load(&sh.rolep_iter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != iter) __builtin_amdgcn_s_sleep(1);
+    }
     double L_new = 0.0;
     int need_full = 0, acc = 0;
     if (ok) {
@@ -292,9 +303,17 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
             need_full = 1;
             if constexpr (PERSIST) {
                 // ---- work order: tag = ticket (unique over the life of the chain set) ------------------------------
-                const bool pre = sh.pre_p[c] == p;         // role P of the previous iteration sent it already
+                const int par = iter & 1;
+                const bool pre = sh.pre_p[par][c] == p;    // role P sent it already, one or two iterations ago
+                const int pre_mode = pre ? sh.pre_mode[par][c] : 0;
+#ifdef HTM_STAMPS
+                if (lane == 0 && cs.stamps) atomicAdd(&sh.stamp_acc[80 + (c & 7) + (pre_mode == 2 ? 8 : 0)], 1ull);
+#endif
+                const int prev_acc = sh.prop[c].accepted, prev_type = sh.prop[c].type, prev_evt = sh.prop[c].evt;
+                const int prev_idx = sh.prop[c].idx;
+                const double prev_xold = sh.prop[c].x_old, prev_xnew = sh.prop[c].x_new;
                 unsigned long long tk = 0;
-                if (lane == 0) { tk = pre ? (unsigned long long)sh.pre_tag[c] : ((atomicAdd(&sh.c.jobs_total, 1ull) + 1ull) & 0x7fffffffull); sh.pre_p[c] = -1; }
+                if (lane == 0) { tk = pre ? (unsigned long long)sh.pre_tag[par][c] : ((atomicAdd(&sh.c.jobs_total, 1ull) + 1ull) & 0x7fffffffull); sh.pre_p[par][c] = -1; }
                 const unsigned tag = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)tk);
                 // every chain-state store of this wave (earlier commits, undo) must have landed before a worker
                 // can see the order: write-through stores, drained here; the order itself is one store
@@ -305,7 +324,7 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
                     const unsigned long long xb = (unsigned long long)__double_as_longlong(x_new);
                     const unsigned pay = gi == 0 ? (unsigned)launch : gi == 1 ? ((unsigned)type | ((unsigned)idx << 3))
                                        : gi == 2 ? (unsigned)(xb >> 32) : gi == 3 ? (unsigned)xb
-                                       : gi == 4 ? 0xffffffffu : 0u;          // no commit to wait for: drained above
+                                       : gi == 4 ? 0xffffffffu : 0u;          // no commit to wait for (drained above), nothing to report
                     st_gran(cs.slots + (size_t)(lane >> 3) * cs.slot_stride + c * kGranPerSlot + gi, tag, pay);
                 }
 #ifdef HTM_STAMPS
@@ -349,6 +368,43 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
                     if (j * 64 < cs.n_wg)
                         part += (j * 64 + lane < cs.n_wg) ? (which == 0 ? gran_f64(hi[0][j], lo[0][j]) : gran_f64(hi[1][j], lo[1][j])) : 0.0;
                 L_new = -wave_sum1(part) - f.const_sum;                  // cls_forward.f90:277-300
+                if constexpr (NCH > 0) {
+                    // An order sent TWO iterations ahead was evaluated while the step in between (a hypocentre step of
+                    // this chain) may or may not have committed yet; the worker that evaluated that event says which
+                    // value it saw.  If it saw the old one and the step was accepted:
+                    //   L(state now) = L(evaluated) + misfit(event, old position) - misfit(event, new position),
+                    // both under THIS step's proposed parameters.
+                    if (pre_mode == 2 && prev_acc && prev_type >= 5) {
+                        unsigned long long vh = 0, vl = 0;
+                        const unsigned long long t0v = __builtin_amdgcn_s_memrealtime();
+                        for (;;) {
+                            vh = ld_agent(cs.vused + 2 * c); vl = ld_agent(cs.vused + 2 * c + 1);
+                            if ((unsigned)(vh >> 32) == tag && (unsigned)(vl >> 32) == tag) break;
+                            if (__builtin_amdgcn_s_memrealtime() - t0v > 500000000ull) { if (lane == 0) sh.c.err = -8; break; }
+                        }
+                        const bool saw_new = (unsigned long long)__double_as_longlong(gran_f64(vh, vl)) ==
+                                             (unsigned long long)__double_as_longlong(prev_xnew);
+                        if (!saw_new) {
+                            const int e = prev_evt - 1, pcmp = prev_idx - 3 * e;
+                            const int vzd = opaque_zero();
+                            const double *hyp = cs.hypo.x + (size_t)c * cs.hypo.nx + 3 * e;
+                            const double ex = ld_state(hyp, vzd), ey = ld_state(hyp + 1, vzd), ez = ld_state(hyp + 2, vzd);
+                            const double b_now = ld_state(cs.vs.x + c, vzd), q_now = ld_state(cs.qs.x + c, vzd);
+                            StaRegs<NCH> std_;
+                            ObsRegs<NCH> obd;
+                            load_sta_regs<NCH>(std_, f.S, lane, s_sx, s_sy, s_sz, tc, ac, (type == 2 || type == 4) ? type : 0,
+                                               (type == 2 || type == 4) ? idx : -1, x_new);
+                            load_obs_regs<NCH>(obd, f, e, lane);
+                            const double pxd[2] = {pcmp == 0 ? prev_xold : ex, ex};
+                            const double pyd[2] = {pcmp == 1 ? prev_xold : ey, ey};
+                            const double pzd[2] = {pcmp == 2 ? prev_xold : ez, ez};
+                            double outd[2];
+                            event_misfit<NCH, 2>(f, obd, lane, std_, pxd, pyd, pzd, type == 1 ? x_new : b_now,
+                                                 type == 3 ? x_new : q_now, outd);
+                            L_new = L_new + wave_sum1(outd[0] - outd[1]);
+                        }
+                    }
+                }
                 acc = metropolis(L_new, L_cur, T, lpr, r, logr) ? 1 : 0;
 #ifdef HTM_STAMPS
                 if (lane == 0 && cs.stamps) atomicAdd(&cs.stamps[25], __builtin_amdgcn_s_memrealtime());
@@ -502,49 +558,83 @@ __device__ __forceinline__ bool swap_plan(const ChainsDev &cs, const StepShared 
 // one post phase and one step front (~2 us) before its own wave would send it.  Only for chains that did not
 // commit in this iteration: their state stores have provably landed (every wave drains at the top of its pass).
 // The chain wave recognises the order by its start position and goes straight to collecting the partial sums.
-struct PreOrder {            // per lane (<-> chain): an order planned before barrier B, sent right after it
+struct PreOrder {            // per lane (<-> chain)
     bool job;
     int c;
-    unsigned tag, w1, x_hi, x_lo, co, c_hi, c_lo;
+    unsigned tag, w1, x_hi, x_lo, co, c_hi, c_lo, rep;
 };
+// For every chain (lane): the order of its step of iteration iter + 1 if that step needs the full evaluation (mode 1);
+// else -- that step being a hypocentre step -- the order of its step of iteration iter + 2 if THAT one does (mode 2):
+// sent two iterations ahead, the workers' round trip disappears behind a whole iteration.  A mode-2 order is
+// evaluated on the state that memory holds when the workers get to it, before or after the step in between commits;
+// the order names that step's element and the worker of that event reports the value it saw (ChainsDev::vused).
 __device__ __forceinline__ PreOrder role_prepublish_plan(const ChainsDev &cs, StepShared &sh, const Ring &rg, int iter,
-                                                         int pos, int wmax, int lane)
+                                                         int pos, int lane, bool allow2)
 {
     PreOrder po;
     po.job = false; po.c = 0; po.tag = 0; po.w1 = 0; po.x_hi = 0; po.x_lo = 0; po.co = 0xffffffffu; po.c_hi = 0; po.c_lo = 0;
-    const int nc = cs.n_chains, M = rg.mask;
-    if (rg.mir_n == 0 || iter + 1 > sh.c.iter_target || sh.fill < pos + wmax) return po;   // no mirror / no next iteration here / window not there yet
-    const bool in = lane < nc && lane <= kHops;
+    po.rep = 0;
+    const int nc = cs.n_chains, M = rg.mask, S_ = cs.S;
+    if (rg.mir_n == 0 || iter + 1 > sh.c.iter_target) return po;        // no mirror / no next iteration in this launch
+    const bool in = lane < nc && lane <= kHops && nc <= kHops;
     const int c = in ? lane : 0;
-    const int p = c == 0 ? pos : pos + rg.hop[(pos & M) * kHops + c - 1];
-    const int4 dec = rg.dec[p & M];
-    const Proposal pr = sh.prop[c];
-    const int type = dec.x, idx = dec.y;
-    bool job = in && type >= 1 && type <= 4 && sh.redone[c] == 0;
+    const bool clean = in && sh.redone[c] == 0;
     if (lane < nc) sh.redone[lane] = 0;
-    const int S_ = cs.S;
+    // ---- step A: this chain's step of iteration iter + 1 (positions validated up to `pos`)
+    const int pA = c == 0 ? pos : pos + rg.hop[(pos & M) * kHops + c - 1];
+    const bool winA = pA + 8 < sh.fill;
+    const int4 dA = rg.dec[pA & M];
+    const int par1 = (iter + 1) & 1, par2 = iter & 1;
+    const bool haveA = sh.pre_p[par1][c] == pA;                          // sent two iterations ahead already
+    // ---- step B: its step of iteration iter + 2, if every step of iteration iter + 1 draws its usual randoms
+    int pb0 = pos + rg.hop[(pos & M) * kHops + nc - 1];
+    bool goodB = winA;
+    if (cs.n_procs * nc > 1) {
+        const int4 sw = rg.sw[pb0 & M];
+        goodB = goodB && sw.z > 0;
+        pb0 += sw.z + 1;
+    }
+    const int pB = c == 0 ? pb0 : pb0 + rg.hop[(pb0 & M) * kHops + c - 1];
+    goodB = goodB && pb0 >= pos && pB >= pb0 && pB + 8 < sh.fill && iter + 2 <= sh.c.iter_target;
+    const int4 dB = rg.dec[pB & M];
+    const bool jobA = dA.x >= 1 && dA.x <= 4, jobB = dB.x >= 1 && dB.x <= 4;
+    int mode = 0;
+    if (clean && winA && jobA && !haveA) mode = 1;
+    else if (allow2 && clean && goodB && !jobA && jobB) mode = 2;
+    const int type = mode == 2 ? dB.x : dA.x, idx = mode == 2 ? dB.y : dA.y, pJ = mode == 2 ? pB : pA;
     const int goff = type == 1 ? 0 : type == 2 ? nc : type == 3 ? nc + nc * S_ : 2 * nc + nc * S_;
     const int gnx = (type == 1 || type == 3) ? 1 : S_;
-    const int o = job ? goff + c * gnx + idx : 0;
+    const int o = mode ? goff + c * gnx + idx : 0;
     const double x_old = rg.mx[o], step = rg.mstep[o];                  // LDS mirror: no memory round trip here
-    const double x_new = x_old + rg.pg[p & M] * step;                   // cls_model.f90:172, as chain_pass computes it
-    if (job && cs.rayleigh14) {                                         // a Rayleigh prior among vs/qs/corrections (:178-187)
-        if (cs.ptall[o] == 1 && x_new <= cs.muall[o]) job = false;      // prior rejects: no evaluation
+    const double x_new = x_old + rg.pg[pJ & M] * step;                  // cls_model.f90:172, as chain_pass computes it
+    if (mode && cs.rayleigh14) {                                        // a Rayleigh prior among vs/qs/corrections (:178-187)
+        if (cs.ptall[o] == 1 && x_new <= cs.muall[o]) mode = 0;         // prior rejects: no evaluation
     }
-    // the commit this chain made in the iteration that just ended may still be on its way to memory: the
-    // worker waits until it reads that value back
+    // the commit this chain made in the iteration that just ended may still be on its way to memory: the workers
+    // wait until they read that value back
+    const Proposal pr = sh.prop[c];
     const int ct = pr.type;
+    const int o_hy = 2 * nc + 2 * nc * S_ + c * cs.hypo.nx;
     const int cgoff = ct == 1 ? 0 : ct == 2 ? nc : ct == 3 ? nc + nc * S_ : ct == 4 ? 2 * nc + nc * S_ : 2 * nc + 2 * nc * S_;
     const int cgnx = (ct == 1 || ct == 3) ? 1 : (ct == 2 || ct == 4) ? S_ : cs.hypo.nx;
     const unsigned long long xb = (unsigned long long)__double_as_longlong(x_new);
     const unsigned long long cb = (unsigned long long)__double_as_longlong(pr.x_new);
-    po.job = job; po.c = c;
-    po.tag = 0x80000000u | (((unsigned)(iter + 1) & 0x03ffffffu) << 5) | (unsigned)c;   // own space: chain_pass tags stay below 2^31
+    // two-ahead: the workers wait for the commit of the iteration that just ended by reading its value back; the step in
+    // between must not be able to overwrite that very element before they look
+    if (mode == 2 && pr.accepted && cgoff + c * cgnx + pr.idx == o_hy + dA.y) mode = 0;
+    po.job = mode != 0; po.c = c;
+    // own tag space (chain_pass tags stay below 2^31); a step can get a two-ahead order AND, if that one turned out to
+    // be addressed to the wrong position, a one-ahead order: the two must not share a tag
+    po.tag = 0x80000000u | (mode == 2 ? 0x40000000u : 0u) | (((unsigned)(iter + mode) & 0x01ffffffu) << 5) | (unsigned)c;
     po.w1 = (unsigned)type | ((unsigned)idx << 3);
     po.x_hi = (unsigned)(xb >> 32); po.x_lo = (unsigned)xb;
     po.co = pr.accepted ? (unsigned)(cgoff + c * cgnx + pr.idx) : 0xffffffffu;
     po.c_hi = (unsigned)(cb >> 32); po.c_lo = (unsigned)cb;
-    if (lane < nc) { sh.pre_p[lane] = job ? p : -1; sh.pre_tag[lane] = po.tag; }
+    po.rep = mode == 2 ? (unsigned)(o_hy + dA.y) + 1u : 0u;            // element of the step in between (+1; 0 = none)
+    if (lane < nc && mode) {
+        const int par = mode == 2 ? par2 : par1;
+        sh.pre_p[par][lane] = pJ; sh.pre_tag[par][lane] = po.tag; sh.pre_mode[par][lane] = mode;
+    }
     return po;
 }
 __device__ __forceinline__ void role_prepublish_send(const ChainsDev &cs, const PreOrder &po, unsigned long long launch)
@@ -559,7 +649,7 @@ __device__ __forceinline__ void role_prepublish_send(const ChainsDev &cs, const 
         st_gran(sl + 4, po.tag, po.co);
         st_gran(sl + 5, po.tag, po.c_hi);
         st_gran(sl + 6, po.tag, po.c_lo);
-        st_gran(sl + 7, po.tag, 0u);
+        st_gran(sl + 7, po.tag, po.rep);
     }
 }
 
@@ -706,9 +796,9 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
         sh.origin = sh.c.spos;
         const long long av = sh.hop_end - sh.c.spos;
         sh.avail = av > (1 << 30) ? (1 << 30) : (int)av;
-        sh.fill = 0; sh.base = 0; sh.redo = -1; sh.sw_do = 0; sh.catchup = 0;
+        sh.fill = 0; sh.base = 0; sh.redo = -1; sh.sw_do = 0; sh.catchup = 0; sh.rolep_iter = -1;
     }
-    for (int c = tid; c < kMaxChains; c += blockDim.x) { sh.pre_p[c] = -1; sh.redone[c] = 0; }
+    for (int c = tid; c < kMaxChains; c += blockDim.x) { sh.pre_p[0][c] = -1; sh.pre_p[1][c] = -1; sh.redone[c] = 0; }
     {
         if (do_apply && tid == 0 && sh.c.stage == ST_WAIT_SWAP && sh.c.err == 0) {
             apply_swap(cs, sh, staged ? s_gath : gathered);
@@ -756,6 +846,7 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
     prefetch_all(cs, sh, rg, 2 * wmax);           // ends with a barrier
     STAMP(1);   // P0
 
+    bool have_prev = false;          // an iteration has completed in this launch (role P has something to look at)
     int fill_next = 0;               // wave_P: window extent staged in the last roles phase, published before the next barrier A
     for (;;) {
         const int iter = sh.c.iter_done + 1;
@@ -775,6 +866,16 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
                 break;
             }
             if (sh.catchup) prefetch_all(cs, sh, rg, sh.base + 2 * wmax);   // rare; flag is uniform (set between barriers)
+            if constexpr (PERSIST) {
+                // ---------------- role P: orders of the next two iterations' full evaluations -----------------------
+                // On wave_Q, before its own chain step (an older wave: it has the slack), from the validated base of THIS
+                // iteration (= the iteration that just ended is iter - 1).  The other waves look at what it leaves only
+                // after their step's arithmetic (chain_pass waits on sh.rolep_iter), by when it is long done.
+                if (have_prev && !lockstep && wave == wave_Q) {
+                    role_prepublish_send(cs, role_prepublish_plan(cs, sh, rg, iter - 1, sh.base, lane, NCH > 0), launch);
+                    if (lane == 0) __hip_atomic_store(&sh.rolep_iter, iter, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
             // ---------------- passes: propose -> partial update -> decide -> commit, per chain wave ----
             int redo = 0;
             bool first = true;
@@ -783,7 +884,7 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
 #endif
             for (;;) {
                 // window bounds for this iteration's extension of the LDS window (done in the roles phase below)
-                const int pf_limit = min(min(sh.base + 3 * wmax, sh.avail), sh.base + rg.mask + 1 - 8);
+                const int pf_limit = min(min(sh.base + 4 * wmax, sh.avail), sh.base + rg.mask + 1 - 8);   // two iterations + their swaps ahead (role P)
                 int p = 0;
                 bool have_p = false;
                 for (int c = wave; c < nc; c += NW) {
@@ -794,7 +895,8 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
                     } else if (!have_p) {                                   // optimistic start: c steps after base
                         p = c == 0 ? sh.base : sh.base + rg.hop[(sh.base & rg.mask) * kHops + c - 1];
                     }
-                    p = chain_pass<NCH, PERSIST>(f, cs, sh, rg, s_sx, s_sy, s_sz, c, p, iter, lane, launch);
+                    p = chain_pass<NCH, PERSIST>(f, cs, sh, rg, s_sx, s_sy, s_sz, c, p, iter, lane, launch,
+                                                 PERSIST && have_prev && !lockstep);
                     have_p = true;
                     if (NW > 1 && c + NW < nc) p += rg.hop[(p & rg.mask) * kHops + NW - 2];   // skip NW-1 steps
                 }
@@ -819,7 +921,7 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
                     pf_store(pf, rg);
                     fill_next = max(sh.fill, min(sh.fill + 64, pf_limit));
                 }
-                if (wave == 0 || wave == wave_R || wave == wave_W || (PERSIST && wave == wave_Q)) {
+                if (wave == 0 || wave == wave_R || wave == wave_W) {
                     const Valid v = validate<PERSIST>(sh, nc, lane);
                     int pos = 0, i1, i2;
                     double sr, slr;
@@ -865,8 +967,6 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
                             }
                         }
                     }
-                    if (PERSIST && wave == wave_Q && done && !lockstep)
-                        role_prepublish_send(cs, role_prepublish_plan(cs, sh, rg, iter, pos, wmax, lane), launch);
                     if (wave == wave_R && done) role_records(cs, sh, iter, lockstep, lane);
                     if (wave == wave_W && done) role_swap(cs, sh, iter, lockstep, lane, i1, i2, sr, slr);
                 }
@@ -905,6 +1005,7 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
         }
         // ---------------- after the barrier: swap + records of the chains this wave owns ---------------
         for (int c = wave; c < nc; c += NW) post_chain(cs, sh, c, iter, lane);
+        have_prev = true;
         STAMP(4);   // post
         if (lockstep) break;
     }
@@ -969,7 +1070,8 @@ __device__ __forceinline__ void worker_body(const FwdDev &f, const ChainsDev &cs
     unsigned last_tag[kGroups];
 #pragma unroll
     for (int j = 0; j < kGroups; ++j) last_tag[j] = 0;
-    // [0] type | idx << 3, [1] x_new high, [2] x_new low, [3] committed element or ~0, [4] its value high, [5] low
+    // [0] type | idx << 3, [1] x_new high, [2] x_new low, [3] committed element or ~0, [4] its value high, [5] low,
+    // [6] element (+1) whose value, as seen by this evaluation, is to be reported (two-ahead orders), 0 = none
     unsigned *s_job = reinterpret_cast<unsigned *>(smem + 160);
     const unsigned long long *slots = cs.slots + (size_t)(w % cs.slot_rep) * cs.slot_stride;
     const int npoll = cs.npoll;
@@ -1007,12 +1109,12 @@ __device__ __forceinline__ void worker_body(const FwdDev &f, const ChainsDev &cs
                         chain = 8 * j + (l0 >> 3);
                         tag = (unsigned)__builtin_amdgcn_readlane((int)t, l0);
                         if (lane == l0) last_tag[j] = tag;
-                        unsigned pv[6];
+                        unsigned pv[7];
 #pragma unroll
-                        for (int q = 0; q < 6; ++q) pv[q] = (unsigned)__builtin_amdgcn_readlane((int)pay, l0 + 1 + q);
+                        for (int q = 0; q < 7; ++q) pv[q] = (unsigned)__builtin_amdgcn_readlane((int)pay, l0 + 1 + q);
                         if (lane == 0) {
 #pragma unroll
-                            for (int q = 0; q < 6; ++q) s_job[q] = pv[q];
+                            for (int q = 0; q < 7; ++q) s_job[q] = pv[q];
                         }
                         return 1;
                     }
@@ -1063,6 +1165,8 @@ __device__ __forceinline__ void worker_body(const FwdDev &f, const ChainsDev &cs
             const double beta_c = ld_agent(cs.vs.x + m), q_c = ld_agent(cs.qs.x + m);
             const double beta = type == 1 ? ov_val : beta_c, q = type == 3 ? ov_val : q_c;
             int ov_kind = 0, ov_idx = -1, ov_evt = -1, ov_cmp = 0;
+            const int r_off = (int)s_job[6] - 1 - (2 * cs.n_chains + 2 * cs.n_chains * cs.S + m * cs.hypo.nx);
+            const int r_evt = s_job[6] ? r_off / 3 : -1, r_cmp = s_job[6] ? r_off - 3 * (r_off / 3) : 0;
             if (type == 2 || type == 4) { ov_kind = type; ov_idx = idx; }
             else if (type >= 5) { ov_evt = idx / 3; ov_cmp = idx - 3 * ov_evt; }
             const double *hyp = cs.hypo.x + (size_t)m * cs.hypo.nx;
@@ -1090,6 +1194,8 @@ __device__ __forceinline__ void worker_body(const FwdDev &f, const ChainsDev &cs
                         nx = ld_agent(hyp + 3 * evn); ny = ld_agent(hyp + 3 * evn + 1); nz = ld_agent(hyp + 3 * evn + 2);
                     }
                     const bool ov = ev == ov_evt;
+                    if (ev == r_evt && lane == 0)        // two-ahead order: which value of that coordinate went into this sum
+                        st_gran_f64(cs.vused + 2 * m, tag, r_cmp == 0 ? cx : r_cmp == 1 ? cy : cz);
                     const double px[1] = {(ov && ov_cmp == 0) ? ov_val : cx};
                     const double py[1] = {(ov && ov_cmp == 1) ? ov_val : cy};
                     const double pz[1] = {(ov && ov_cmp == 2) ? ov_val : cz};

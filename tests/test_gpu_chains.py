@@ -109,9 +109,11 @@ def test_final_state_rng_and_steps_vs_oracle():
         assert np.array_equal(s.n_propose, o["n_propose"]) and np.array_equal(s.n_accept, o["n_accept"])
 
 
-def test_lockstep_equals_single_rank_driver_bitwise():
-    """n_procs = 1: step_begin/step_end (the multi-rank code path) and htm_chains_run (graph + in-kernel
-    swap) must produce identical bits"""
+def test_lockstep_equals_single_rank_driver():
+    """n_procs = 1: step_begin/step_end (the multi-rank code path, one launch per iteration) and htm_chains_run (one
+    persistent launch, orders sent up to two iterations ahead and corrected for the step in between) take the same
+    decisions and consume the same randoms; log-likelihoods agree to rounding (the correction adds and subtracts one
+    event's misfit)"""
     from hypotremormcmc_amd.parallel import LocalWorld
 
     fx, data, params = load_case("c2")
@@ -121,10 +123,12 @@ def test_lockstep_equals_single_rank_driver_bitwise():
     _, b = _build_world(data, params)
     LocalWorld(b).run(n_iter)
     ia, ca, la = a[0].likelihood_trace(); ib, cb, lb = b[0].likelihood_trace()
-    assert np.array_equal(ia, ib) and np.array_equal(la, lb)
+    assert np.array_equal(ia, ib)
+    np.testing.assert_allclose(la, lb, rtol=1e-13, atol=0)
     assert a[0].rng_state() == b[0].rng_state()
     for c in range(2):
         assert np.array_equal(a[0].state(c).hypo, b[0].state(c).hypo)
+        assert np.array_equal(a[0].state(c).n_accept, b[0].state(c).n_accept)
 
 
 def test_run_in_pieces_and_small_record_buffers():
@@ -136,7 +140,9 @@ def test_run_in_pieces_and_small_record_buffers():
     _, b = _build_world(data, params, lik_capacity=8, sample_capacity=6)
     b[0].run(1000); b[0].run(1); b[0].run(n_iter - 1001)
     ia, _, la = a[0].likelihood_trace(); ib, _, lb = b[0].likelihood_trace()
-    assert np.array_equal(ia, ib) and np.array_equal(la, lb)
+    # same decisions; log-likelihoods to rounding (where a launch ends decides which full evaluations were sent ahead)
+    assert np.array_equal(ia, ib)
+    np.testing.assert_allclose(la, lb, rtol=1e-13, atol=0)
     sa, sb = a[0].samples(), b[0].samples()
     assert np.array_equal(sa["iter"], sb["iter"]) and np.array_equal(sa["hypo"], sb["hypo"])
     _check_against_fixture(fx, params, b)
@@ -176,7 +182,7 @@ def test_many_chains_per_rank():
     assert np.array_equal(a, oa) and np.array_equal(b, ob)
 
 
-def test_rccl_lockstep_loop_equals_single_rank_driver_bitwise():
+def test_rccl_lockstep_loop_equals_single_rank_driver():
     """The multi-GPU driver loop (htm_chains_run_lockstep: one k_mcmc launch + one ncclAllGather per iteration,
     enqueued from C) on a real RCCL communicator of one rank must produce the bits of the single-rank driver."""
     import socket
@@ -206,7 +212,8 @@ def test_rccl_lockstep_loop_equals_single_rank_driver_bitwise():
         dist.destroy_process_group()
     assert b[0].iterations_done == n_iter
     ia, ca, la = a[0].likelihood_trace(); ib, cb, lb = b[0].likelihood_trace()
-    assert np.array_equal(ia, ib) and np.array_equal(la, lb)
+    assert np.array_equal(ia, ib)
+    np.testing.assert_allclose(la, lb, rtol=1e-13, atol=0)
     assert a[0].rng_state() == b[0].rng_state()
     for c in range(2):
         assert np.array_equal(a[0].state(c).hypo, b[0].state(c).hypo)
@@ -222,7 +229,7 @@ def test_two_kernel_fallback_matches_reference_trace(monkeypatch):
     _check_against_fixture(fx, params, sets)
 
 
-def test_checkpoint_resume_is_bitwise_and_checks_shapes():
+def test_checkpoint_resume_continues_the_run_and_checks_shapes():
     """run(700) == run(300) -> checkpoint -> a NEW chain set from the same inputs -> restore -> run(400)"""
     from hypotremormcmc_amd._lib import HtmError
 
@@ -239,11 +246,12 @@ def test_checkpoint_resume_is_bitwise_and_checks_shapes():
     assert c[0].iterations_done == 700 and c[0].rng_state() == a[0].rng_state()
     ia, ca, la = a[0].likelihood_trace(); ic, cc, lc = c[0].likelihood_trace()
     keep = ia > 300
-    assert np.array_equal(ia[keep], ic) and np.array_equal(ca[keep], cc) and np.array_equal(la[keep], lc)
+    assert np.array_equal(ia[keep], ic) and np.array_equal(ca[keep], cc)
+    np.testing.assert_allclose(la[keep], lc, rtol=1e-13, atol=0)
     for k in range(2):
         sa, sc = a[0].state(k), c[0].state(k)
         assert np.array_equal(sa.hypo, sc.hypo) and np.array_equal(sa.t_corr, sc.t_corr) and sa.temp == sc.temp
-        assert sa.log_likelihood == sc.log_likelihood
+        assert abs(sa.log_likelihood - sc.log_likelihood) <= 1e-13 * abs(sa.log_likelihood)
         assert np.array_equal(sa.n_propose, sc.n_propose) and np.array_equal(sa.n_accept, sc.n_accept)
     # a blob of another shape is refused
     fx3, data3, params3 = load_case("missing")

@@ -51,6 +51,8 @@ for wv in range(8):
         if cnt:
             print("  wave %d %s: loop top -> barrier A  %7.0f ticks  (%d iterations)" %
                   (wv, "with job" if job else "partial ", (a[48 + wv + 8 * job] - base[48 + wv + 8 * job]) / cnt, cnt))
+print("  full-evaluation steps per chain: sent two ahead / other:",
+      [(a[88 + k] - base[88 + k], a[80 + k] - base[80 + k]) for k in range(8)])
 jobs = a[26] - base[26]
 if jobs:
     d = lambda k: (a[k] - base[k]) / jobs
