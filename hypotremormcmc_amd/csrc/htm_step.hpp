@@ -259,6 +259,27 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
     } else if constexpr (PERSIST) {
         __builtin_amdgcn_s_setprio(2);      // this wave's step is the long pole of the iteration: issue first
     }
+    // A full-evaluation step whose order went out two iterations ahead may need the one-event correction (below): its
+    // inputs -- that event's observation rows and coordinates, the corrections -- are requested now, into the registers
+    // a partial update would use.  Only a hint (role P of this iteration may still be writing pre_*): the decision to
+    // use them is taken after the wait on sh.rolep_iter.
+    bool dhint = false;
+    int d_e = 0;
+    double d_ex = 0.0, d_ey = 0.0, d_ez = 0.0;
+    if constexpr (PERSIST && NCH > 0) {
+        if (!partial && wait_rolep) {
+            const Proposal &pv = sh.prop[c];
+            if (sh.pre_p[iter & 1][c] == p && sh.pre_mode[iter & 1][c] == 2 && pv.accepted && pv.type >= 5) {
+                dhint = true;
+                d_e = __builtin_amdgcn_readfirstlane(pv.evt) - 1;
+                const int vzd = opaque_zero();
+                const double *hypd = cs.hypo.x + (size_t)c * cs.hypo.nx + 3 * d_e;
+                d_ex = ld_state(hypd, vzd); d_ey = ld_state(hypd + 1, vzd); d_ez = ld_state(hypd + 2, vzd);
+                load_sta_regs<NCH>(st, f.S, lane, s_sx, s_sy, s_sz, tc, ac, 0, -1, 0.0);
+                load_obs_regs<NCH>(ob, f, d_e, lane);
+            }
+        }
+    }
     const double x_old = rl_f64(gathered_v, 0);
     const double hx = rl_f64(gathered_v, 1), hy = rl_f64(gathered_v, 2), hz = rl_f64(gathered_v, 3);
     const double beta = rl_f64(gathered_v, 4), q = rl_f64(gathered_v, 5);
@@ -386,21 +407,24 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
                                              (unsigned long long)__double_as_longlong(prev_xnew);
                         if (!saw_new) {
                             const int e = prev_evt - 1, pcmp = prev_idx - 3 * e;
-                            const int vzd = opaque_zero();
-                            const double *hyp = cs.hypo.x + (size_t)c * cs.hypo.nx + 3 * e;
-                            const double ex = ld_state(hyp, vzd), ey = ld_state(hyp + 1, vzd), ez = ld_state(hyp + 2, vzd);
-                            const double b_now = ld_state(cs.vs.x + c, vzd), q_now = ld_state(cs.qs.x + c, vzd);
-                            StaRegs<NCH> std_;
-                            ObsRegs<NCH> obd;
-                            load_sta_regs<NCH>(std_, f.S, lane, s_sx, s_sy, s_sz, tc, ac, (type == 2 || type == 4) ? type : 0,
-                                               (type == 2 || type == 4) ? idx : -1, x_new);
-                            load_obs_regs<NCH>(obd, f, e, lane);
-                            const double pxd[2] = {pcmp == 0 ? prev_xold : ex, ex};
-                            const double pyd[2] = {pcmp == 1 ? prev_xold : ey, ey};
-                            const double pzd[2] = {pcmp == 2 ? prev_xold : ez, ez};
+                            if (!(dhint && d_e == e)) {        // the hint missed: request the inputs now
+                                const int vzd = opaque_zero();
+                                const double *hyp = cs.hypo.x + (size_t)c * cs.hypo.nx + 3 * e;
+                                d_ex = ld_state(hyp, vzd); d_ey = ld_state(hyp + 1, vzd); d_ez = ld_state(hyp + 2, vzd);
+                                load_sta_regs<NCH>(st, f.S, lane, s_sx, s_sy, s_sz, tc, ac, 0, -1, 0.0);
+                                load_obs_regs<NCH>(ob, f, e, lane);
+                            }
+                            if (type == 2 || type == 4) {      // this step's proposed correction, on the lane of its station
+#pragma unroll
+                                for (int k = 0; k < NCH; ++k) {
+                                    if (lane + 64 * k == idx) { if (type == 2) st.tc[k] = x_new; else st.ac[k] = x_new; }
+                                }
+                            }
+                            const double pxd[2] = {pcmp == 0 ? prev_xold : d_ex, d_ex};
+                            const double pyd[2] = {pcmp == 1 ? prev_xold : d_ey, d_ey};
+                            const double pzd[2] = {pcmp == 2 ? prev_xold : d_ez, d_ez};
                             double outd[2];
-                            event_misfit<NCH, 2>(f, obd, lane, std_, pxd, pyd, pzd, type == 1 ? x_new : b_now,
-                                                 type == 3 ? x_new : q_now, outd);
+                            event_misfit<NCH, 2>(f, ob, lane, st, pxd, pyd, pzd, type == 1 ? x_new : beta, type == 3 ? x_new : q, outd);
                             L_new = L_new + wave_sum1(outd[0] - outd[1]);
                         }
                     }
