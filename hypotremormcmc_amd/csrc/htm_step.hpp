@@ -256,8 +256,6 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
             load_sta_regs<NCH>(st, f.S, lane, s_sx, s_sy, s_sz, tc, ac, 0, -1, 0.0);
             load_obs_regs<NCH>(ob, f, ev, lane);      // in flight while the proposal is worked out
         }
-    } else if constexpr (PERSIST) {
-        __builtin_amdgcn_s_setprio(2);      // this wave's step is the long pole of the iteration: issue first
     }
     // A full-evaluation step whose order went out two iterations ahead may need the one-event correction (below): its
     // inputs -- that event's observation rows and coordinates, the corrections -- are requested now, into the registers
@@ -351,7 +349,6 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
 #ifdef HTM_STAMPS
                 if (lane == 0 && cs.stamps) { atomicAdd(&cs.stamps[20], __builtin_amdgcn_s_memrealtime()); atomicAdd(&cs.stamps[26], 1ull); if (pre) atomicAdd(&cs.stamps[28], 1ull); }
 #endif
-                __builtin_amdgcn_s_setprio(0);
                 // ---- the workers' partial sums: tagged granules, fixed summation order; two rounds of loads are
                 // ---- kept in flight so that a granule is seen at most half a round trip after it lands ----------
                 const unsigned long long *pg = cs.pgran + (size_t)c * cs.n_wg * cs.pgran_stride;
@@ -436,7 +433,6 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
             }
         }
     }
-    if constexpr (PERSIST) __builtin_amdgcn_s_setprio(0);
     if (lane == 0) {
         const int cool = (T < 1.0 + kEps) ? 1 : 0;
         Proposal &pr = sh.prop[c];
