@@ -689,8 +689,10 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
     hc->nw = std::min(nc, 8);
     // stream window: a chain step draws <= 6 numbers, select_pair/judge_swap a few more (cls_parallel.f90:226-230)
     hc->wmax = ((6 * nc + 16 + 63) / 64) * 64;
+    // look-ahead in LDS: two iterations + their swaps where role P sends orders two iterations ahead (it covers at
+    // most kHops chains), else one
     hc->ring_size = 256;
-    while (hc->ring_size < 4 * hc->wmax + 64) hc->ring_size *= 2;
+    while (hc->ring_size < (nc <= kHops ? 4 : 2) * hc->wmax + 64) hc->ring_size *= 2;
     // per LDS ring position: U, LOGU, pg, pr, plogr (5 doubles), dec, sw (int4), hop (kHops ints)
     hc->step_smem = ((sizeof(StepShared) + 15) & ~size_t(15)) +
                     (size_t)hc->ring_size * (5 * sizeof(double) + 2 * sizeof(int4) + kHops * sizeof(int)) +

@@ -164,12 +164,14 @@ def test_single_chain_job_has_no_swap():
     assert sets[0].rng_state() == job.rng_state(0)
 
 
-def test_many_chains_per_rank():
-    """more chains than k_step has waves (8): chains are processed in rounds"""
+@pytest.mark.parametrize("nc", [19, 32])
+def test_many_chains_per_rank(nc):
+    """more chains than k_step has waves (8): chains are processed in rounds (32: the LDS stream window at its
+    one-iteration look-ahead)"""
     from oracle import oracle
 
     fx, data, params = load_case("c1")
-    params = dict(params, n_procs="1", n_chains="19", n_cool="3", n_iter="1200", n_burn="100", n_interval="7")
+    params = dict(params, n_procs="1", n_chains=str(nc), n_cool="3", n_iter="1200", n_burn="100", n_interval="7")
     job = oracle.Job(params, data); job.run(1200)
     _, sets = _build_world(data, params)
     sets[0].run(1200)

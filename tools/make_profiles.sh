@@ -39,6 +39,25 @@ for sub, cname in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         v = agg[k]
         lines.append("%-34s %-11s %7d %14.3f %12.3f %14.3f" % (k[:34], cname, len(v), sum(v) / len(v), min(v), max(v)))
 open(os.path.join(out, f"{tag}_pmc_summary.txt"), "w").write("\n".join(lines) + "\n")
+# the k_mcmc rows per iteration: what bench.py reports as roofline.traffic
+import json
+tot = {}
+nl = 0
+for sub, cname in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    v = []
+    for fn in glob.glob(os.path.join(out, f"prof_{tag}_{sub}", "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(fn)):
+            if row.get("Counter_Name") == cname and "k_mcmc" in row["Kernel_Name"]:
+                v.append(float(row["Counter_Value"]))
+    tot[sub] = sum(v)
+    nl = len(v)
+iters = 4500
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace), python3 bench.py --steps 4000 --warmup 500 --no-cpu-baseline",
+           "kernel": "htm::k_mcmc<1>", "iterations": iters, "launches": nl,
+           "fetch_kb_raw_total": tot["fetch"], "write_kb_total": tot["write"],
+           "fetch_bytes_per_iteration_raw": tot["fetch"] * 1024 / iters, "write_bytes_per_iteration": tot["write"] * 1024 / iters,
+           "note": "raw counter values; gfx950 FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads (x2 at most); 8-byte-per-lane access widths are uncalibrated"},
+          open(os.path.join(out, f"{tag}_traffic.json"), "w"), indent=1)
 print("\n".join(lines))
 PY
 cat "$OUT/${TAG}_kernel_stats.csv"
