@@ -265,7 +265,7 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
     int d_e = 0;
     double d_ex = 0.0, d_ey = 0.0, d_ez = 0.0;
     if constexpr (PERSIST && NCH > 0) {
-        if (!partial && wait_rolep) {
+        if (__builtin_expect(!partial && wait_rolep, 0)) {
             const Proposal &pv = sh.prop[c];
             if (sh.pre_p[iter & 1][c] == p && sh.pre_mode[iter & 1][c] == 2 && pv.accepted && pv.type >= 5) {
                 dhint = true;
@@ -287,7 +287,7 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
     const double da = x_new - mu, db = x_old - mu;
     double lpr = -(da * da - db * db) / (2.0 * sigma * sigma);  // :175-177
     int ok = 1;
-    if (ptype == 1) {                                           // :178-187
+    if (__builtin_expect(ptype == 1, 0)) {                      // :178-187
         if (x_new <= mu) { lpr = (double)-1.0e+30f; ok = 0; }
         else lpr = lpr + log(x_new - mu) - log(x_old - mu);
     }
@@ -303,8 +303,8 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
     }
     double L_new = 0.0;
     int need_full = 0, acc = 0;
-    if (ok) {
-        if (partial) {
+    if (__builtin_expect(ok != 0, 1)) {
+        if (__builtin_expect(partial, 1)) {
             // plain selects: an if/else-if/else chain of stores into these arrays was miscompiled by
             // hipcc 7.2 at -O3 (the final else-store was dropped), see DESIGN.md §7
             const int cmp = idx - 3 * ev;        // 0 x, 1 y, 2 z of event ev
@@ -402,7 +402,7 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
                         }
                         const bool saw_new = (unsigned long long)__double_as_longlong(gran_f64(vh, vl)) ==
                                              (unsigned long long)__double_as_longlong(prev_xnew);
-                        if (!saw_new) {
+                        if (__builtin_expect(!saw_new, 0)) {
                             const int e = prev_evt - 1, pcmp = prev_idx - 3 * e;
                             if (!(dhint && d_e == e)) {        // the hint missed: request the inputs now
                                 const int vzd = opaque_zero();
@@ -843,7 +843,7 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
     STAMP(0);   // prologue
 
     // ---------------- P0: judge + commit of the chains that came back from k_full; first stream window ----
-    if (resume) {
+    if (__builtin_expect(resume, 0)) {
         if (tid == 0) cs.desc->n = 0;                          // work order consumed
         for (int c = wave; c < nc; c += NW) {
             Proposal pr = cs.prop[c];
@@ -870,7 +870,7 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
     int fill_next = 0;               // wave_P: window extent staged in the last roles phase, published before the next barrier A
     for (;;) {
         const int iter = sh.c.iter_done + 1;
-        if (!resume) {
+        if (__builtin_expect(!resume, 1)) {
             // ---------------- anything left to do? ---------------------------------------------------
             if (sh.c.iter_done >= sh.c.iter_target || sh.c.stop || sh.c.err) break;
             if (sh.c.n_lik + nc > cs.cap_lik || sh.c.n_smp + nc > cs.cap_smp) {
@@ -885,7 +885,7 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
                 __syncthreads();
                 break;
             }
-            if (sh.catchup) prefetch_all(cs, sh, rg, sh.base + 2 * wmax);   // rare; flag is uniform (set between barriers)
+            if (__builtin_expect(sh.catchup != 0, 0)) prefetch_all(cs, sh, rg, sh.base + 2 * wmax);   // rare; flag is uniform (set between barriers)
             if constexpr (PERSIST) {
                 // ---------------- role P: orders of the next two iterations' full evaluations -----------------------
                 // On wave_Q, before its own chain step (an older wave: it has the slack), from the validated base of THIS
@@ -909,7 +909,7 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
                 bool have_p = false;
                 for (int c = wave; c < nc; c += NW) {
                     if (c < redo) continue;
-                    if (!first) {
+                    if (__builtin_expect(!first, 0)) {
                         if (lane == 0) { undo_chain(cs, sh, rg, c); sh.redone[c] = 1; }
                         p = sh.start_fix[c];                                // corrected by the validation
                     } else if (!have_p) {                                   // optimistic start: c steps after base

@@ -39,6 +39,20 @@ for sub, cname in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         v = agg[k]
         lines.append("%-34s %-11s %7d %14.3f %12.3f %14.3f" % (k[:34], cname, len(v), sum(v) / len(v), min(v), max(v)))
 open(os.path.join(out, f"{tag}_pmc_summary.txt"), "w").write("\n".join(lines) + "\n")
+# k_mcmc launch by launch from the kernel trace, beside what bench.py measured with HIP events in the same run
+tr = glob.glob(os.path.join(out, f"prof_{tag}_stats", "**", "*kernel_trace.csv"), recursive=True)
+try:
+    import json as _j
+    b = _j.load(open(os.path.join(out, f"{tag}_bench_under_rocprof.json")))["roofline"]
+    dur = [(int(x["End_Timestamp"]) - int(x["Start_Timestamp"])) / 1e6 for x in csv.DictReader(open(tr[0])) if "k_mcmc" in x["Kernel_Name"]]
+    open(os.path.join(out, f"{tag}_kernel_launches.txt"), "w").write(
+        "# k_mcmc launches of `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline` (ms, in launch order)\n"
+        "# the first launches are the untimed warm-up, the last %d the timed region\n" % b["launches"] +
+        " ".join("%.3f" % x for x in dur) + "\n" +
+        "timed launches, rocprofv3 trace: %.3f ms   bench.py (HIP events on the kernels' stream, same run): %.3f ms\n"
+        % (sum(dur[-b["launches"]:]), b["avg_launch_us"] * b["launches"] / 1e3))
+except Exception as e:
+    print("kernel_launches:", e)
 # the k_mcmc rows per iteration: what bench.py reports as roofline.traffic
 import json
 tot = {}
