@@ -22,6 +22,10 @@
 #include "htm_device.hpp"
 #include "htm_stream.hpp"
 
+#ifndef HTM_ALLOW2
+#define HTM_ALLOW2 1     // diagnostics: 0 = role P sends orders one iteration ahead only
+#endif
+
 namespace htm {
 
 constexpr int kGathStage = 512;   // doubles of LDS for the gathered swap records (else they are read in place)
@@ -40,6 +44,7 @@ struct StepShared {
     int pre_p[2][kMaxChains];
     unsigned pre_tag[2][kMaxChains];
     int pre_mode[2][kMaxChains];
+    int pre_pa[2][kMaxChains];   // two-ahead orders: where the step in between was expected to start
     int np[kMaxChains * 7], na[kMaxChains * 7];   // proposal / acceptance counters of this launch
     int sw_do, sw_c1, sw_c2;      // swap decided between the barriers; applied by the waves owning the chains
     double sw_T1, sw_T2;          // new temperatures of chains sw_c1 / sw_c2
@@ -217,7 +222,7 @@ __device__ __forceinline__ bool metropolis(double L_new, double L_cur, double T,
 template <int NCH, bool PERSIST>
 __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, StepShared &sh, const Ring &rg,
                                           const double *s_sx, const double *s_sy, const double *s_sz, int c,
-                                          int p, int iter, int lane, unsigned long long launch, bool wait_rolep)
+                                          int p, int iter, int lane, unsigned long long launch, bool wait_rolep, bool first_pass)
 {
     const int M = rg.mask;
 #ifdef HTM_STAMPS
@@ -267,7 +272,7 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
     if constexpr (PERSIST && NCH > 0) {
         if (__builtin_expect(!partial && wait_rolep, 0)) {
             const Proposal &pv = sh.prop[c];
-            if (sh.pre_p[iter & 1][c] == p && sh.pre_mode[iter & 1][c] == 2 && pv.accepted && pv.type >= 5) {
+            if (first_pass && sh.pre_p[iter & 1][c] == p && sh.pre_mode[iter & 1][c] == 2 && pv.accepted && pv.type >= 5) {
                 dhint = true;
                 d_e = __builtin_amdgcn_readfirstlane(pv.evt) - 1;
                 const int vzd = opaque_zero();
@@ -323,7 +328,10 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
             if constexpr (PERSIST) {
                 // ---- work order: tag = ticket (unique over the life of the chain set) ------------------------------
                 const int par = iter & 1;
-                const bool pre = sh.pre_p[par][c] == p;    // role P sent it already, one or two iterations ago
+                // role P sent it already, one or two iterations ago.  Only in the first pass of an iteration: in a repeated
+                // pass this chain has run -- and taken back -- another step meanwhile, and workers that got to the order late
+                // may have read that step's value
+                const bool pre = first_pass && sh.pre_p[par][c] == p;
                 const int pre_mode = pre ? sh.pre_mode[par][c] : 0;
 #ifdef HTM_STAMPS
                 if (lane == 0 && cs.stamps) atomicAdd(&sh.stamp_acc[80 + (c & 7) + (pre_mode == 2 ? 8 : 0)], 1ull);
@@ -332,7 +340,13 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
                 const int prev_idx = sh.prop[c].idx;
                 const double prev_xold = sh.prop[c].x_old, prev_xnew = sh.prop[c].x_new;
                 unsigned long long tk = 0;
-                if (lane == 0) { tk = pre ? (unsigned long long)sh.pre_tag[par][c] : ((atomicAdd(&sh.c.jobs_total, 1ull) + 1ull) & 0x7fffffffull); sh.pre_p[par][c] = -1; }
+                if (lane == 0) {
+                    tk = pre ? (unsigned long long)sh.pre_tag[par][c] : ((atomicAdd(&sh.c.jobs_total, 1ull) + 1ull) & 0x7fffffffull);
+                    sh.pre_p[par][c] = -1;
+                    // an order of its own overwrites the workers' sums of any order role P has out for this chain (a repeated
+                    // pass can bring the step back to the position such an order was written for): those are void now
+                    if (!pre) { sh.pre_p[par][c] = -1; sh.pre_p[par ^ 1][c] = -1; }
+                }
                 const unsigned tag = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)tk);
                 // every chain-state store of this wave (earlier commits, undo) must have landed before a worker
                 // can see the order: write-through stores, drained here; the order itself is one store
@@ -379,7 +393,17 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
                     if (complete(0)) { which = 0; break; }
                     issue(0);
                     if (complete(1)) { which = 1; break; }
-                    if (__builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) { if (lane == 0) sh.c.err = -8; break; }
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) {
+                        if (lane == 0) sh.c.err = -8;
+#ifdef HTM_STAMPS
+                        if (lane == 0 && cs.stamps) {          // what was waited for (tools/diag_wait.py)
+                            cs.stamps[100] = 1; cs.stamps[101] = c; cs.stamps[102] = tag; cs.stamps[103] = pre; cs.stamps[104] = pre_mode;
+                            cs.stamps[105] = iter; cs.stamps[106] = p; cs.stamps[107] = type; cs.stamps[108] = idx;
+                            cs.stamps[109] = hi[0][0]; cs.stamps[110] = lo[0][0]; cs.stamps[111] = sh.start[c];
+                        }
+#endif
+                        break;
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < kSweep; ++j)            // fixed order: worker lane, lane + 64, ...
@@ -398,7 +422,13 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
                         for (;;) {
                             vh = ld_agent(cs.vused + 2 * c); vl = ld_agent(cs.vused + 2 * c + 1);
                             if ((unsigned)(vh >> 32) == tag && (unsigned)(vl >> 32) == tag) break;
-                            if (__builtin_amdgcn_s_memrealtime() - t0v > 500000000ull) { if (lane == 0) sh.c.err = -8; break; }
+                            if (__builtin_amdgcn_s_memrealtime() - t0v > 500000000ull) {
+                                if (lane == 0) sh.c.err = -8;
+#ifdef HTM_STAMPS
+                                if (lane == 0 && cs.stamps) { cs.stamps[100] = 2; cs.stamps[101] = c; cs.stamps[102] = tag; cs.stamps[105] = iter; cs.stamps[109] = vh; cs.stamps[110] = vl; }
+#endif
+                                break;
+                            }
                         }
                         const bool saw_new = (unsigned long long)__double_as_longlong(gran_f64(vh, vl)) ==
                                              (unsigned long long)__double_as_longlong(prev_xnew);
@@ -605,7 +635,12 @@ __device__ __forceinline__ PreOrder role_prepublish_plan(const ChainsDev &cs, St
     const bool winA = pA + 8 < sh.fill;
     const int4 dA = rg.dec[pA & M];
     const int par1 = (iter + 1) & 1, par2 = iter & 1;
-    const bool haveA = sh.pre_p[par1][c] == pA;                          // sent two iterations ahead already
+    // A two-ahead order for step A is out already -- unless the step in between (the one that just ended) was not the
+    // one it was written around: a repeated pass can start that step elsewhere and still leave step A where it was
+    // (the draw counts cancel).  Such an order is dropped: its report names the wrong element, and if the step in
+    // between was itself a full evaluation the workers' sums have been overwritten.
+    const bool stale2 = in && sh.pre_p[par1][c] == pA && sh.pre_mode[par1][c] == 2 && sh.pre_pa[par1][c] != sh.start[c];
+    const bool haveA = sh.pre_p[par1][c] == pA && !stale2;               // sent two iterations ahead already
     // ---- step B: its step of iteration iter + 2, if every step of iteration iter + 1 draws its usual randoms
     int pb0 = pos + rg.hop[(pos & M) * kHops + nc - 1];
     bool goodB = winA;
@@ -651,9 +686,10 @@ __device__ __forceinline__ PreOrder role_prepublish_plan(const ChainsDev &cs, St
     po.co = pr.accepted ? (unsigned)(cgoff + c * cgnx + pr.idx) : 0xffffffffu;
     po.c_hi = (unsigned)(cb >> 32); po.c_lo = (unsigned)cb;
     po.rep = mode == 2 ? (unsigned)(o_hy + dA.y) + 1u : 0u;            // element of the step in between (+1; 0 = none)
+    if (lane < nc && stale2 && mode != 1) sh.pre_p[par1][lane] = -1;   // (a one-ahead order replaces the entry)
     if (lane < nc && mode) {
         const int par = mode == 2 ? par2 : par1;
-        sh.pre_p[par][lane] = pJ; sh.pre_tag[par][lane] = po.tag; sh.pre_mode[par][lane] = mode;
+        sh.pre_p[par][lane] = pJ; sh.pre_tag[par][lane] = po.tag; sh.pre_mode[par][lane] = mode; sh.pre_pa[par][lane] = pA;
     }
     return po;
 }
@@ -892,7 +928,7 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
                 // iteration (= the iteration that just ended is iter - 1).  The other waves look at what it leaves only
                 // after their step's arithmetic (chain_pass waits on sh.rolep_iter), by when it is long done.
                 if (have_prev && !lockstep && wave == wave_Q) {
-                    role_prepublish_send(cs, role_prepublish_plan(cs, sh, rg, iter - 1, sh.base, lane, NCH > 0), launch);
+                    role_prepublish_send(cs, role_prepublish_plan(cs, sh, rg, iter - 1, sh.base, lane, HTM_ALLOW2 && NCH > 0), launch);
                     if (lane == 0) __hip_atomic_store(&sh.rolep_iter, iter, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
@@ -910,13 +946,19 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
                 for (int c = wave; c < nc; c += NW) {
                     if (c < redo) continue;
                     if (__builtin_expect(!first, 0)) {
-                        if (lane == 0) { undo_chain(cs, sh, rg, c); sh.redone[c] = 1; }
+                        if (lane == 0) {
+                            undo_chain(cs, sh, rg, c);
+                            sh.redone[c] = 1;
+                            // workers that get to an order of this chain late may have read the step just taken back: whatever
+                            // role P has out for this chain is void
+                            sh.pre_p[0][c] = -1; sh.pre_p[1][c] = -1;
+                        }
                         p = sh.start_fix[c];                                // corrected by the validation
                     } else if (!have_p) {                                   // optimistic start: c steps after base
                         p = c == 0 ? sh.base : sh.base + rg.hop[(sh.base & rg.mask) * kHops + c - 1];
                     }
                     p = chain_pass<NCH, PERSIST>(f, cs, sh, rg, s_sx, s_sy, s_sz, c, p, iter, lane, launch,
-                                                 PERSIST && have_prev && !lockstep);
+                                                 PERSIST && have_prev && !lockstep, first);
                     have_p = true;
                     if (NW > 1 && c + NW < nc) p += rg.hop[(p & rg.mask) * kHops + NW - 2];   // skip NW-1 steps
                 }
@@ -1176,7 +1218,15 @@ __device__ __forceinline__ void worker_body(const FwdDev &f, const ChainsDev &cs
                 const unsigned long long want = ((unsigned long long)s_job[4] << 32) | s_job[5];
                 const unsigned long long t0c = __builtin_amdgcn_s_memrealtime();
                 while ((unsigned long long)__double_as_longlong(ld_agent(cs.xall + s_job[3])) != want) {
-                    if (__builtin_amdgcn_s_memrealtime() - t0c > 500000000ull) return;
+                    if (__builtin_amdgcn_s_memrealtime() - t0c > 500000000ull) {
+#ifdef HTM_STAMPS
+                        if (tid == 0 && w == 0 && cs.stamps) {
+                            cs.stamps[112] = 1; cs.stamps[113] = m; cs.stamps[114] = tag; cs.stamps[115] = s_job[3]; cs.stamps[116] = want;
+                            cs.stamps[117] = (unsigned long long)__double_as_longlong(ld_agent(cs.xall + s_job[3])); cs.stamps[118] = s_job[0]; cs.stamps[119] = s_job[6];
+                        }
+#endif
+                        return;
+                    }
                     __builtin_amdgcn_s_sleep(1);
                 }
             }

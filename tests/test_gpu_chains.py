@@ -291,6 +291,76 @@ def test_c5_size_16_chains_against_oracle():
         assert s.temp == o["temp"]
 
 
+_SHAPES = [
+    # events, stations, chains, cool chains, seed, iterations, parameter overrides
+    (7, 5, 3, 1, 11, 900, {}),                                             # fewer events than waves of one worker block
+    (64, 64, 8, 2, 12, 900, {"step_size_z": 6.0}),                          # Rayleigh-prior rejections every few steps
+    (130, 70, 5, 1, 13, 700, {}),                                          # two stations per lane, odd counts
+    (33, 200, 4, 2, 14, 500, {"solve_qs": "F"}),                           # generic (strided) station path
+    (500, 64, 8, 8, 15, 600, {"n_interval": 2}),                           # every chain cool: all of them record
+    (100, 16, 2, 1, 16, 900, {"use_amp": "F", "step_size_z": 6.0}),
+    (1000, 64, 8, 1, 17, 700, {"step_size_z": 8.0, "n_interval": 2}),      # the bench shape with many rejections
+    (40, 64, 6, 1, 18, 900, {"solve_t_corr": "F", "solve_a_corr": "F"}),   # only vs / qs steps need the full evaluation
+]
+
+
+@pytest.mark.parametrize("shape", _SHAPES, ids=lambda s: "%dx%d_%dch_seed%d" % (s[:3] + (s[4],)))
+def test_assorted_shapes_against_oracle(shape):
+    """Shapes and settings the fixtures do not hold -- ragged sizes, rejection-heavy step sizes (orders sent ahead
+    then miss their step and the validation repeats passes), switched-off parameter groups -- every recorded
+    log-likelihood, the counters, the final states and the RNG consumption against the oracle."""
+    from hypotremormcmc_amd import synth
+    from oracle import oracle
+
+    E, S, nc, n_cool, seed, n_iter, over = shape
+    data = synth.make_synthetic(E, S, seed)
+    params = dict(synth.DEFAULT_PARAMS, n_procs=1, n_chains=nc, n_cool=n_cool, n_iter=n_iter, n_burn=n_iter // 3,
+                  n_interval=5)
+    params.update(over)
+    job = oracle.Job(params, data); job.run(n_iter)
+    _, sets = _build_world(data, params)
+    sets[0].run(n_iter)
+    it, lk = job.likelihood_trace(0)
+    gi, _, gl = sets[0].likelihood_trace()
+    assert len(gi) > 20 and np.array_equal(gi, it)
+    np.testing.assert_allclose(gl, lk, rtol=RTOL_TRACE)
+    assert sets[0].rng_state() == job.rng_state(0)
+    a, b = sets[0].counts(); oa, ob = job.counts()
+    assert np.array_equal(a, oa) and np.array_equal(b, ob)
+    for c in range(nc):
+        s, o = sets[0].state(c), job.chain(0, c)
+        np.testing.assert_allclose(s.hypo, o["hypo"], rtol=1e-11, atol=1e-12)
+        assert s.temp == o["temp"]
+
+
+@pytest.mark.parametrize("E,S,nc,seed,sz", [(64, 64, 8, 1, 4.0), (64, 64, 8, 3, 12.0), (1000, 64, 8, 2, 8.0),
+                                           (1000, 64, 8, 4, 20.0), (30, 20, 7, 3, 12.0)])
+def test_rejection_heavy_runs_against_oracle(E, S, nc, seed, sz):
+    """Depth steps several times the prior width: the Rayleigh prior rejects every few steps, each rejection shifts the
+    stream positions of the chains behind it, passes are repeated, and the orders role P sent one and two iterations
+    ahead miss their steps, are voided or come back into position.  (Each of these configurations exposed a fault of
+    the two-ahead orders once: sums overwritten by the chain's own order, a step coming back to the position an order
+    was written for after a repeated pass, workers reading a step that was taken back.  tools/stress_rejections.py
+    runs the longer version.)"""
+    from hypotremormcmc_amd import synth
+    from oracle import oracle
+
+    n_iter = 3000
+    data = synth.make_synthetic(E, S, 100 + seed)
+    params = dict(synth.DEFAULT_PARAMS, n_procs=1, n_chains=nc, n_cool=2, n_iter=n_iter, n_burn=n_iter // 2,
+                  n_interval=3, step_size_z=sz, step_size_vs=0.4)
+    job = oracle.Job(params, data); job.run(n_iter)
+    _, sets = _build_world(data, params)
+    sets[0].run(n_iter)
+    it, lk = job.likelihood_trace(0)
+    gi, _, gl = sets[0].likelihood_trace()
+    assert len(gi) == 2000 and np.array_equal(gi, it)
+    np.testing.assert_allclose(gl, lk, rtol=RTOL_TRACE)
+    assert sets[0].rng_state() == job.rng_state(0)
+    a, b = sets[0].counts(); oa, ob = job.counts()
+    assert np.array_equal(a, oa) and np.array_equal(b, ob)
+
+
 @pytest.mark.parametrize("lockstep", [False, True])
 def test_random_stream_ring_wraps_around(lockstep, monkeypatch):
     """The rank's random stream lives in rings over the absolute position (2^20 by default, i.e. one wrap every
