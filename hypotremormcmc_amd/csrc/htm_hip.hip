@@ -1360,9 +1360,53 @@ int htm_quantiles_dev(int device, const double *d_samples, long n_mod, long n_pa
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(HTM_ENODEVICE, "no HIP device");
     HIPCHK(hipSetDevice(device));
     const dim3 grid((unsigned)((n_par + 63) / 64)), block(64 * kSelRG);
-    hipLaunchKernelGGL(k_select, grid, block, 0, static_cast<hipStream_t>(hip_stream), d_samples, n_mod, n_par, ld,
-                       ranks_1based[0] - 1, ranks_1based[1] - 1, ranks_1based[2] - 1, d_out);
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    const char *force = getenv("HTM_SELECT_SLABS");
+    // small sets: one launch, a column group per workgroup; large sets: row slabs over the whole chip, a launch per digit
+    long slabs = 1;
+    if ((double)n_mod * (double)n_par >= (double)(1 << 22)) {
+        slabs = std::max(1L, std::min((n_mod + 255) / 256, (long)(2048 / grid.x)));
+        slabs = std::min(slabs, 1024L);
+    }
+    if (force) slabs = std::max(1L, std::min(atol(force), std::min(n_mod, 65535L)));
+    if (slabs <= 1 && !force) {
+        hipLaunchKernelGGL(k_select, grid, block, 0, st, d_samples, n_mod, n_par, ld,
+                           ranks_1based[0] - 1, ranks_1based[1] - 1, ranks_1based[2] - 1, d_out);
+        HIPCHK(hipGetLastError());
+        return HTM_OK;
+    }
+    // workspace: three histograms, two prefix/remaining states (stream-ordered allocation keeps the call asynchronous)
+    const size_t hist_b = (size_t)grid.x * kSelHistPerGroup * sizeof(int);
+    const size_t st_b = (size_t)n_par * kSelRanks * sizeof(unsigned long long);
+    const size_t total = 3 * hist_b + 4 * st_b;
+    char *ws = nullptr;
+    bool async_alloc = hipMallocAsync(reinterpret_cast<void **>(&ws), total, st) == hipSuccess;
+    if (!async_alloc) {
+        (void)hipGetLastError();
+        if (hipMalloc(reinterpret_cast<void **>(&ws), total) != hipSuccess) return fail(HTM_EHIP, "hipMalloc of %zu bytes failed", total);
+    }
+    HIPCHK(hipMemsetAsync(ws, 0, total, st));
+    SelWork w;
+    for (int k = 0; k < 3; ++k) w.hist[k] = reinterpret_cast<int *>(ws + k * hist_b);
+    for (int k = 0; k < 2; ++k) {
+        w.prefix[k] = reinterpret_cast<unsigned long long *>(ws + 3 * hist_b + (2 * k) * st_b);
+        w.remaining[k] = reinterpret_cast<long *>(ws + 3 * hist_b + (2 * k + 1) * st_b);
+    }
+    const long slab_rows = (n_mod + slabs - 1) / slabs;
+    const dim3 grid2(grid.x, (unsigned)slabs);
+    int pass = 0;
+    for (int shift = 60; shift >= 0; shift -= 4, ++pass)
+        hipLaunchKernelGGL(k_select_pass, grid2, block, 0, st, d_samples, n_mod, n_par, ld, ranks_1based[0] - 1,
+                           ranks_1based[1] - 1, ranks_1based[2] - 1, shift, pass, slab_rows, w, (double *)nullptr);
+    hipLaunchKernelGGL(k_select_pass, grid, block, 0, st, d_samples, n_mod, n_par, ld, ranks_1based[0] - 1,
+                       ranks_1based[1] - 1, ranks_1based[2] - 1, -4, pass, slab_rows, w, d_out);
     HIPCHK(hipGetLastError());
+    if (async_alloc) {
+        HIPCHK(hipFreeAsync(ws, st));
+    } else {
+        HIPCHK(hipStreamSynchronize(st));
+        (void)hipFree(ws);
+    }
     return HTM_OK;
 }
 

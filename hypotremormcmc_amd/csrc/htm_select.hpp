@@ -97,4 +97,109 @@ __global__ __launch_bounds__(64 * kSelRG) void k_select(const double *x, long n_
     }
 }
 
+// ---- the same select for large sample sets: row slabs over many workgroups, one launch per digit --------------------
+// k_select keeps a column group on one workgroup (49 workgroups for 3 130 parameters: a fifth of the CUs, four waves
+// each).  Here the rows are cut into slabs as well, grid = (column groups, slabs); a pass counts its slab into private
+// LDS counters as above and adds the 48 totals per column to a global histogram (integer atomics: exact, order-free);
+// the NEXT launch starts by resolving the previous digit from that histogram -- every workgroup of a column group does
+// the same small walk, slab 0 writes the new prefix/remaining state and clears the histogram after next.  Three
+// histogram buffers and two state buffers go round; a last, count-free launch writes the values.
+struct SelWork {
+    int *hist[3];                       // [column group][rank][digit][lane]
+    unsigned long long *prefix[2];      // [n_par][rank]
+    long *remaining[2];
+};
+constexpr size_t kSelHistPerGroup = (size_t)kSelRanks * 16 * 64;
+
+__global__ __launch_bounds__(64 * kSelRG) void k_select_pass(const double *x, long n_mod, long n_par, long ld, int r0, int r1,
+                                                             int r2, int shift, int pass, long slab_rows, SelWork w,
+                                                             double *out)
+{
+    __shared__ int cnt[kSelRanks][16][kSelRG][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const long p = (long)blockIdx.x * 64 + lane;
+    const bool live = p < n_par;
+    const int *h_prev = w.hist[(pass + 2) % 3] + (size_t)blockIdx.x * kSelHistPerGroup;
+    int *h_cur = w.hist[pass % 3] + (size_t)blockIdx.x * kSelHistPerGroup;
+    int *h_next = w.hist[(pass + 1) % 3] + (size_t)blockIdx.x * kSelHistPerGroup;
+    const unsigned long long *pre_old = w.prefix[(pass + 1) & 1];
+    const long *rem_old = w.remaining[(pass + 1) & 1];
+    unsigned long long prefix[kSelRanks] = {0ull, 0ull, 0ull};
+    long remaining[kSelRanks] = {r0, r1, r2};
+    if (pass > 0 && live) {             // resolve the digit the previous launch counted (at shift + 4)
+#pragma unroll
+        for (int r = 0; r < kSelRanks; ++r) {
+            const long rem = rem_old[p * kSelRanks + r];
+            long c = 0;
+            int pick = 15;
+            bool found = false;
+            for (int d = 0; d < 16; ++d) {
+                const long tot = h_prev[((size_t)r * 16 + d) * 64 + lane];
+                if (!found && rem < c + tot) { pick = d; found = true; }
+                if (!found) c += tot;
+            }
+            prefix[r] = pre_old[p * kSelRanks + r] | ((unsigned long long)pick << (shift + 4));
+            remaining[r] = rem - c;
+        }
+    }
+    if (blockIdx.y == 0 && g == 0 && live) {
+#pragma unroll
+        for (int r = 0; r < kSelRanks; ++r) {
+            w.prefix[pass & 1][p * kSelRanks + r] = prefix[r];
+            w.remaining[pass & 1][p * kSelRanks + r] = remaining[r];
+            if (out) out[p * kSelRanks + r] = sel_val(prefix[r]);
+        }
+    }
+    if (out) return;                    // the last launch only resolves
+    if (blockIdx.y == 0)
+        for (int k = threadIdx.x; k < (int)kSelHistPerGroup; k += blockDim.x) h_next[k] = 0;
+#pragma unroll
+    for (int r = 0; r < kSelRanks; ++r)
+#pragma unroll
+        for (int d = 0; d < 16; ++d) cnt[r][d][g][lane] = 0;
+    const long row0 = (long)blockIdx.y * slab_rows, row1 = min(n_mod, row0 + slab_rows);
+    if (live) {
+        long k = row0 + g;
+        for (; k + (kSelUnroll - 1) * kSelRG < row1; k += kSelUnroll * kSelRG) {
+            unsigned long long key[kSelUnroll];
+#pragma unroll
+            for (int u = 0; u < kSelUnroll; ++u) key[u] = sel_key(x[(k + u * kSelRG) * ld + p]);
+#pragma unroll
+            for (int u = 0; u < kSelUnroll; ++u) {
+                const int dig = (int)((key[u] >> shift) & 15ull);
+                const unsigned long long hi = shift == 60 ? 0ull : key[u] >> (shift + 4);
+#pragma unroll
+                for (int r = 0; r < kSelRanks; ++r) {
+                    const unsigned long long want = shift == 60 ? 0ull : prefix[r] >> (shift + 4);
+                    if (hi == want) cnt[r][dig][g][lane] += 1;
+                }
+            }
+        }
+        for (; k < row1; k += kSelRG) {
+            const unsigned long long key = sel_key(x[k * ld + p]);
+            const int dig = (int)((key >> shift) & 15ull);
+            const unsigned long long hi = shift == 60 ? 0ull : key >> (shift + 4);
+#pragma unroll
+            for (int r = 0; r < kSelRanks; ++r) {
+                const unsigned long long want = shift == 60 ? 0ull : prefix[r] >> (shift + 4);
+                if (hi == want) cnt[r][dig][g][lane] += 1;
+            }
+        }
+    }
+    __syncthreads();
+    if (live) {
+        // wave g adds the totals of digits 4g .. 4g+3 (all ranks) to the column group's histogram
+#pragma unroll
+        for (int r = 0; r < kSelRanks; ++r)
+#pragma unroll
+            for (int dd = 0; dd < 16 / kSelRG; ++dd) {
+                const int d = g * (16 / kSelRG) + dd;
+                int tot = 0;
+#pragma unroll
+                for (int gg = 0; gg < kSelRG; ++gg) tot += cnt[r][d][gg][lane];
+                if (tot) atomicAdd(&h_cur[((size_t)r * 16 + d) * 64 + lane], tot);
+            }
+    }
+}
+
 }  // namespace htm

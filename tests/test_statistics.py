@@ -59,10 +59,16 @@ def test_remove_double_counts_rule():
 
 
 @pytest.mark.gpu
-def test_device_select_equals_sorted_column():
+@pytest.mark.parametrize("slabs", [None, "1", "7", "64"])
+def test_device_select_equals_sorted_column(slabs, monkeypatch):
+    """None: the library's own choice (one launch per column group for these sizes, row slabs + one launch per digit for
+    the last, 4 M-sample one); 1 / 7 / 64: the slab path forced with that many slabs (ragged last slab, slabs of a
+    few rows, more slabs than 256-row pieces)"""
     from hypotremormcmc_amd import statistics as st
     from oracle import stats_oracle as so
 
+    if slabs is not None:
+        monkeypatch.setenv("HTM_SELECT_SLABS", slabs)
     rng = np.random.default_rng(11)
     for n_mod, n_par in ((40, 1), (200, 3), (1000, 130), (4097, 67), (20000, 257)):
         x = rng.normal(size=(n_mod, n_par)) * rng.choice([1e-3, 1.0, 1e6], size=n_par)
