@@ -689,20 +689,20 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
     hc->nw = std::min(nc, 8);
     // stream window: a chain step draws <= 6 numbers, select_pair/judge_swap a few more (cls_parallel.f90:226-230)
     hc->wmax = ((6 * nc + 16 + 63) / 64) * 64;
-    // look-ahead in LDS: two iterations + their swaps where role P sends orders two iterations ahead (it covers at
-    // most kHops chains), else one
-    hc->ring_size = 256;
-    while (hc->ring_size < (nc <= kHops ? 4 : 2) * hc->wmax + 64) hc->ring_size *= 2;
-    // per LDS ring position: U, LOGU, pg, pr, plogr (5 doubles), dec, sw (int4), hop (kHops ints)
-    hc->step_smem = ((sizeof(StepShared) + 15) & ~size_t(15)) +
-                    (size_t)hc->ring_size * (5 * sizeof(double) + 2 * sizeof(int4) + kHops * sizeof(int)) +
-                    3 * (size_t)h->S * sizeof(double) + kGathStage * sizeof(double);
-    {
-        // LDS mirror of (vs, t_corr, qs, a_corr) x all chains + their step sizes, if it fits beside the rest
-        const size_t mir = 2 * (size_t)nc + 2 * (size_t)nc * h->S;
-        hc->dev.mirror_n = 0;
-        if (hc->step_smem + 2 * mir * sizeof(double) <= 96 * 1024) { hc->dev.mirror_n = (int)mir; hc->step_smem += 2 * mir * sizeof(double); }
-    }
+    // LDS of the master: the stream window -- two iterations + their swaps ahead where it fits (role P sends orders two
+    // iterations ahead), else one -- and the mirror of (vs, t_corr, qs, a_corr) x all chains + their step sizes that
+    // role P reads (without it no orders are sent ahead).  Per ring position: U, LOGU, pg, pr, plogr (5 doubles), dec,
+    // sw (int4), hop (kHops ints).
+    const size_t lds_fixed = ((sizeof(StepShared) + 15) & ~size_t(15)) + 3 * (size_t)h->S * sizeof(double) + kGathStage * sizeof(double);
+    const size_t lds_pos = 5 * sizeof(double) + 2 * sizeof(int4) + kHops * sizeof(int);
+    const size_t mir = 2 * (size_t)nc + 2 * (size_t)nc * h->S;
+    const size_t lds_cap = 150 * 1024;
+    auto ring_for = [&](int look) { int r = 256; while (r < look * hc->wmax + 64) r *= 2; return r; };
+    hc->dev.mirror_n = 0;
+    if (lds_fixed + (size_t)ring_for(4) * lds_pos + 2 * mir * sizeof(double) <= lds_cap) { hc->ring_size = ring_for(4); hc->dev.mirror_n = (int)mir; }
+    else if (lds_fixed + (size_t)ring_for(2) * lds_pos + 2 * mir * sizeof(double) <= lds_cap) { hc->ring_size = ring_for(2); hc->dev.mirror_n = (int)mir; }
+    else hc->ring_size = ring_for(2);
+    hc->step_smem = lds_fixed + (size_t)hc->ring_size * lds_pos + 2 * (size_t)hc->dev.mirror_n * sizeof(double);
     if (hc->step_smem > 150 * 1024) return cleanup(fail(HTM_EINVAL, "n_chains / n_sta too large for k_step's LDS budget"));
     if (hc->step_smem > 48 * 1024) {
         const void *fn = h->nch == 1 ? (const void *)k_step<1> : h->nch == 2 ? (const void *)k_step<2> : (const void *)k_step<0>;

@@ -608,6 +608,15 @@ __device__ __forceinline__ bool swap_plan(const ChainsDev &cs, const StepShared 
 // one post phase and one step front (~2 us) before its own wave would send it.  Only for chains that did not
 // commit in this iteration: their state stores have provably landed (every wave drains at the top of its pass).
 // The chain wave recognises the order by its start position and goes straight to collecting the partial sums.
+// start of the chain step n steps after the one that starts at pos (hop tables cover kHops steps at a time)
+__device__ __forceinline__ int hop_ahead(const Ring &rg, int pos, int n)
+{
+    int p = pos;
+    while (n > kHops) { p += rg.hop[(p & rg.mask) * kHops + kHops - 1]; n -= kHops; }
+    if (n > 0) p += rg.hop[(p & rg.mask) * kHops + n - 1];
+    return p;
+}
+
 struct PreOrder {            // per lane (<-> chain)
     bool job;
     int c;
@@ -626,12 +635,12 @@ __device__ __forceinline__ PreOrder role_prepublish_plan(const ChainsDev &cs, St
     po.rep = 0;
     const int nc = cs.n_chains, M = rg.mask, S_ = cs.S;
     if (rg.mir_n == 0 || iter + 1 > sh.c.iter_target) return po;        // no mirror / no next iteration in this launch
-    const bool in = lane < nc && lane <= kHops && nc <= kHops;
+    const bool in = lane < nc;
     const int c = in ? lane : 0;
     const bool clean = in && sh.redone[c] == 0;
     if (lane < nc) sh.redone[lane] = 0;
     // ---- step A: this chain's step of iteration iter + 1 (positions validated up to `pos`)
-    const int pA = c == 0 ? pos : pos + rg.hop[(pos & M) * kHops + c - 1];
+    const int pA = hop_ahead(rg, pos, c);
     const bool winA = pA + 8 < sh.fill;
     const int4 dA = rg.dec[pA & M];
     const int par1 = (iter + 1) & 1, par2 = iter & 1;
@@ -642,14 +651,14 @@ __device__ __forceinline__ PreOrder role_prepublish_plan(const ChainsDev &cs, St
     const bool stale2 = in && sh.pre_p[par1][c] == pA && sh.pre_mode[par1][c] == 2 && sh.pre_pa[par1][c] != sh.start[c];
     const bool haveA = sh.pre_p[par1][c] == pA && !stale2;               // sent two iterations ahead already
     // ---- step B: its step of iteration iter + 2, if every step of iteration iter + 1 draws its usual randoms
-    int pb0 = pos + rg.hop[(pos & M) * kHops + nc - 1];
+    int pb0 = hop_ahead(rg, pos, nc);
     bool goodB = winA;
     if (cs.n_procs * nc > 1) {
         const int4 sw = rg.sw[pb0 & M];
         goodB = goodB && sw.z > 0;
         pb0 += sw.z + 1;
     }
-    const int pB = c == 0 ? pb0 : pb0 + rg.hop[(pb0 & M) * kHops + c - 1];
+    const int pB = hop_ahead(rg, pb0, c);
     goodB = goodB && pb0 >= pos && pB >= pb0 && pB + 8 < sh.fill && iter + 2 <= sh.c.iter_target;
     const int4 dB = rg.dec[pB & M];
     const bool jobA = dA.x >= 1 && dA.x <= 4, jobB = dB.x >= 1 && dB.x <= 4;

@@ -14,7 +14,7 @@ from oracle import oracle
 
 n_iter = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 bad = 0
-for (E, S, nc) in ((64, 64, 8), (1000, 64, 8), (200, 64, 3), (30, 20, 7)):
+for (E, S, nc) in ((64, 64, 8), (1000, 64, 8), (200, 64, 3), (30, 20, 7), (100, 64, 16), (64, 32, 27)):
     for seed, sz in ((1, 4.0), (2, 8.0), (3, 12.0), (4, 20.0)):
         data = synth.make_synthetic(E, S, 100 + seed)
         params = dict(synth.DEFAULT_PARAMS, n_procs=1, n_chains=nc, n_cool=2 if nc > 2 else 1, n_iter=n_iter, n_burn=n_iter // 2,
