@@ -696,14 +696,21 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
     const size_t lds_fixed = ((sizeof(StepShared) + 15) & ~size_t(15)) + 3 * (size_t)h->S * sizeof(double) + kGathStage * sizeof(double);
     const size_t lds_pos = 5 * sizeof(double) + 2 * sizeof(int4) + kHops * sizeof(int);
     const size_t mir = 2 * (size_t)nc + 2 * (size_t)nc * h->S;
-    const size_t lds_cap = 150 * 1024;
+    const size_t lds_cap = 156 * 1024;
     auto ring_for = [&](int look) { int r = 256; while (r < look * hc->wmax + 64) r *= 2; return r; };
-    hc->dev.mirror_n = 0;
-    if (lds_fixed + (size_t)ring_for(4) * lds_pos + 2 * mir * sizeof(double) <= lds_cap) { hc->ring_size = ring_for(4); hc->dev.mirror_n = (int)mir; }
-    else if (lds_fixed + (size_t)ring_for(2) * lds_pos + 2 * mir * sizeof(double) <= lds_cap) { hc->ring_size = ring_for(2); hc->dev.mirror_n = (int)mir; }
-    else hc->ring_size = ring_for(2);
-    hc->step_smem = lds_fixed + (size_t)hc->ring_size * lds_pos + 2 * (size_t)hc->dev.mirror_n * sizeof(double);
-    if (hc->step_smem > 150 * 1024) return cleanup(fail(HTM_EINVAL, "n_chains / n_sta too large for k_step's LDS budget"));
+    hc->dev.mirror_n = 0; hc->dev.mirror_steps = 0;
+    hc->ring_size = ring_for(2);
+    {
+        // preference: long window + values + step sizes, long window + values, short window + both, short + values, nothing
+        const int looks[4] = {4, 4, 2, 2}, steps[4] = {1, 0, 1, 0};
+        for (int k = 0; k < 4; ++k)
+            if (lds_fixed + (size_t)ring_for(looks[k]) * lds_pos + (1 + steps[k]) * mir * sizeof(double) <= lds_cap) {
+                hc->ring_size = ring_for(looks[k]); hc->dev.mirror_n = (int)mir; hc->dev.mirror_steps = steps[k];
+                break;
+            }
+    }
+    hc->step_smem = lds_fixed + (size_t)hc->ring_size * lds_pos + (1 + hc->dev.mirror_steps) * (size_t)hc->dev.mirror_n * sizeof(double);
+    if (hc->step_smem > lds_cap) return cleanup(fail(HTM_EINVAL, "n_chains / n_sta too large for k_step's LDS budget"));
     if (hc->step_smem > 48 * 1024) {
         const void *fn = h->nch == 1 ? (const void *)k_step<1> : h->nch == 2 ? (const void *)k_step<2> : (const void *)k_step<0>;
         HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hc->step_smem));

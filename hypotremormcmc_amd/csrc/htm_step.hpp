@@ -72,6 +72,7 @@ struct Ring {                     // LDS window of the stream rings, index = rel
     // that role P needs no memory round trip.  mir_n = 0: no mirror (too large, or not the persistent kernel)
     double *mx, *mstep;
     int mir_n;
+    bool mir_steps;
 };
 
 // one stream position in flight from the global rings to the LDS window
@@ -669,7 +670,10 @@ __device__ __forceinline__ PreOrder role_prepublish_plan(const ChainsDev &cs, St
     const int goff = type == 1 ? 0 : type == 2 ? nc : type == 3 ? nc + nc * S_ : 2 * nc + nc * S_;
     const int gnx = (type == 1 || type == 3) ? 1 : S_;
     const int o = mode ? goff + c * gnx + idx : 0;
-    const double x_old = rg.mx[o], step = rg.mstep[o];                  // LDS mirror: no memory round trip here
+    const double x_old = rg.mx[o];                                      // LDS mirror: no memory round trip here
+    double step;
+    if (rg.mir_steps) step = rg.mstep[o];
+    else step = mode ? cs.stall[o] : 0.0;                               // immutable; only where the mirror of x took the room
     const double x_new = x_old + rg.pg[pJ & M] * step;                  // cls_model.f90:172, as chain_pass computes it
     if (mode && cs.rayleigh14) {                                        // a Rayleigh prior among vs/qs/corrections (:178-187)
         if (cs.ptall[o] == 1 && x_new <= cs.muall[o]) mode = 0;         // prior rejects: no evaluation
@@ -816,6 +820,7 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
     rg.mir_n = (PERSIST && mode == MODE_RUN) ? cs.mirror_n : 0;
     rg.mx = s_gath + kGathStage;
     rg.mstep = rg.mx + rg.mir_n;
+    rg.mir_steps = cs.mirror_steps != 0;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -845,7 +850,7 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
 #ifdef HTM_STAMPS
     for (int k = tid; k < 96; k += blockDim.x) sh.stamp_acc[k] = 0ull;
 #endif
-    for (int k = tid; k < rg.mir_n; k += blockDim.x) { rg.mx[k] = cs.xall[k]; rg.mstep[k] = cs.stall[k]; }
+    for (int k = tid; k < rg.mir_n; k += blockDim.x) { rg.mx[k] = cs.xall[k]; if (rg.mir_steps) rg.mstep[k] = cs.stall[k]; }
     // the gathered records of the previous lock-step iteration come in with the same round of loads
     const bool do_apply = (mode == MODE_APPLY || mode == MODE_ADVANCE) && gathered != nullptr;
     const int n_gath = cs.n_procs * (4 + 2 * nc);
