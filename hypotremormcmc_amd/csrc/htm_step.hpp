@@ -830,7 +830,9 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
     // helper roles between the barriers: validation+bookkeeping on wave 0, records and swap on other waves
     const int wave_R = NW > 1 ? 1 : 0, wave_W = NW > 2 ? 2 : 0;
     const int wave_P = NW > 4 ? 4 : NW - 1;        // extends the LDS window during the roles phase (no role of its own if NW > 4)
-    const int wave_Q = NW > 3 ? 3 : 0;             // role P: orders of the NEXT iteration's full evaluations
+    // role P (orders of the coming iterations' full evaluations): a wave without a chain if there is one, else an older
+    // wave (it has the slack before its own step)
+    const int wave_Q = nc < NW ? NW - 1 : NW > 3 ? 3 : 0;
 #ifdef HTM_STAMPS
     unsigned long long stamp_last_ = __builtin_amdgcn_s_memtime();
 #endif
