@@ -52,6 +52,11 @@ CASES = {
     "fixedcorr": dict(n_events=7, n_sta=9, seed=4, n_missing=0,
                       params=dict(n_procs=2, n_chains=3, n_cool=2, n_iter=5000, n_burn=0, n_interval=20,
                                   solve_t_corr="F", solve_vs="F", temp_high="50.0")),
+    # depth steps several times the prior width: the Rayleigh prior rejects every few steps (a rejection consumes no
+    # judge draw, which shifts everything behind it in the random stream)
+    "rejects": dict(n_events=40, n_sta=12, seed=9, n_missing=0,
+                    params=dict(n_procs=2, n_chains=4, n_cool=1, n_iter=3000, n_burn=1000, n_interval=10,
+                                step_size_z=6.0, step_size_vs=0.4)),
     "c3": dict(n_events=1000, n_sta=64, seed=1, n_missing=0, store_inputs=False,
                params=dict(n_procs=1, n_chains=8, n_cool=1, n_iter=600, n_burn=300, n_interval=10)),
 }

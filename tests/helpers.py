@@ -6,7 +6,7 @@ import numpy as np
 from hypotremormcmc_amd import synth
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = ["c1", "c2", "missing", "timeonly", "fixedcorr", "c3"]
+CASES = ["c1", "c2", "missing", "timeonly", "fixedcorr", "rejects", "c3"]
 
 
 def load_case(name):

@@ -75,7 +75,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("name,world", [("c1", 2), ("timeonly", 3)])
+@pytest.mark.parametrize("name,world", [("c1", 2), ("timeonly", 3), ("rejects", 2)])
 def test_lockstep_allgather_protocol_reproduces_mpi_reference(name, world):
     import torch.multiprocessing as mp
 

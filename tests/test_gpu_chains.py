@@ -65,7 +65,7 @@ def test_single_rank_run_matches_reference_trace(name):
     _check_against_fixture(fx, params, sets)
 
 
-@pytest.mark.parametrize("name", ["c1", "timeonly", "fixedcorr"])
+@pytest.mark.parametrize("name", ["c1", "timeonly", "fixedcorr", "rejects"])
 def test_multi_rank_lockstep_matches_reference_trace(name):
     """2-3 simulated ranks on one GPU; the record exchange is a device copy instead of the RCCL all-gather"""
     from hypotremormcmc_amd.parallel import LocalWorld

@@ -103,7 +103,7 @@ def test_unmodified_reference_driver_on_hip_forward_shim(tmp_path):
         np.testing.assert_allclose(v[:, 0], fx[f"lik_{rank}"][:n], rtol=1e-9, atol=0)
 
 
-@pytest.mark.parametrize("name", ["c1", "timeonly", "fixedcorr"])
+@pytest.mark.parametrize("name", ["c1", "timeonly", "fixedcorr", "rejects"])
 def test_fortran_mpi_driver_reproduces_reference_outputs(name, tmp_path):
     """hypo_tremor_mcmc_hip_mpi under real MPI (2-3 processes sharing the GPU): an MPI program like the reference,
     every rank's chains device-resident, one MPI_Allgather of the swap records per iteration.  All output
