@@ -13,7 +13,9 @@ from hypotremormcmc_amd import driver, synth
 from hypotremormcmc_amd.obs_data import ObsData
 
 nc = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-data = synth.make_synthetic(1000, 64, 1)
+E_ = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
+S_ = int(sys.argv[4]) if len(sys.argv) > 4 else 64
+data = synth.make_synthetic(E_, S_, 1)
 params = dict(synth.DEFAULT_PARAMS, n_procs=1, n_chains=nc, n_cool=1, n_iter=10**7, n_burn=10**9, n_interval=1000)
 obs = ObsData.from_arrays(data.sta_x, data.sta_y, data.t_obs, data.t_stdv, data.a_obs, data.a_stdv)
 fwd, cs = driver.build_rank(params, data.sta_x, data.sta_y, data.sta_z, obs, 0, n_procs=1)
@@ -24,13 +26,13 @@ if LOCK:
     run = world.run
 else:
     run = cs.run
-run(2000)
+run(2000 if E_ <= 1000 else 300)
 lib = _lib.load()
 lib.htm_chains_read_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
 a = (C.c_uint64 * 128)()
 lib.htm_chains_read_stamps(cs.handle, a)
 base = list(a)
-n = 10000
+n = 10000 if E_ <= 1000 else 2000
 import time
 t0 = time.perf_counter()
 run(n)
