@@ -940,7 +940,7 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
             if (__builtin_expect(sh.catchup != 0, 0)) prefetch_all(cs, sh, rg, sh.base + 2 * wmax);   // rare; flag is uniform (set between barriers)
             if constexpr (PERSIST) {
                 // ---------------- role P: orders of the next two iterations' full evaluations -----------------------
-                // On wave_Q, before its own chain step (an older wave: it has the slack), from the validated base of THIS
+                // On wave_Q, before its own chain step (an older wave: it has the slack; or a wave without a chain), from the validated base of THIS
                 // iteration (= the iteration that just ended is iter - 1).  The other waves look at what it leaves only
                 // after their step's arithmetic (chain_pass waits on sh.rolep_iter), by when it is long done.
                 if (have_prev && !lockstep && wave == wave_Q) {
