@@ -1210,7 +1210,31 @@ __device__ __forceinline__ void worker_body(const FwdDev &f, const ChainsDev &cs
 #ifdef HTM_STAMPS
                     if (cs.stamps && w == 0 && lane == 0) cs.stamps[27] += 1;      // polls of worker 0
 #endif
-                    const int r = spin ? check(b) : 0;
+                    int r = spin ? check(b) : 0;
+                    if (r == 1 && s_job[3] != 0xffffffffu) {
+                        // The order was sent ahead of the chain's latest commit: wait until that store is what memory returns
+                        // (the other waves read the chain's state only after this wave has seen it).  An order can be void by
+                        // the time it is looked at -- the chain repeated a pass and wrote the element again -- and then the
+                        // value never shows: the wait ends as soon as the slot holds a newer order, or after 200 us, and the
+                        // order is dropped (had it been a live one, the master's own bounded wait reports it).
+                        const unsigned long long want = ((unsigned long long)s_job[4] << 32) | s_job[5];
+                        const unsigned long long t0c = __builtin_amdgcn_s_memrealtime();
+                        for (;;) {
+                            if ((unsigned long long)__double_as_longlong(ld_agent(cs.xall + s_job[3])) == want) break;
+                            const unsigned now_tag = (unsigned)(ld_agent(slots + (size_t)chain * kGranPerSlot) >> 32);
+                            if (now_tag != tag || __builtin_amdgcn_s_memrealtime() - t0c > 20000ull) {
+#ifdef HTM_STAMPS
+                                if (lane == 0 && w == 0 && cs.stamps) {
+                                    cs.stamps[112] += 1; cs.stamps[113] = chain; cs.stamps[114] = tag; cs.stamps[115] = s_job[3]; cs.stamps[116] = want;
+                                    cs.stamps[117] = (unsigned long long)__double_as_longlong(ld_agent(cs.xall + s_job[3])); cs.stamps[118] = s_job[0]; cs.stamps[119] = now_tag;
+                                }
+#endif
+                                r = 0; tag = 0; chain = -1;      // dropped: keep polling
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                    }
                     if (r != 0) spin = false;
                     if (spin) issue(b);
                 }
@@ -1229,23 +1253,6 @@ __device__ __forceinline__ void worker_body(const FwdDev &f, const ChainsDev &cs
         {
             const int type = (int)(s_job[0] & 7u), idx = (int)(s_job[0] >> 3);
             const double ov_val = __longlong_as_double((long long)(((unsigned long long)s_job[1] << 32) | s_job[2]));
-            if (s_job[3] != 0xffffffffu) {
-                // sent ahead of the chain's latest commit: wait until that store is what memory returns
-                const unsigned long long want = ((unsigned long long)s_job[4] << 32) | s_job[5];
-                const unsigned long long t0c = __builtin_amdgcn_s_memrealtime();
-                while ((unsigned long long)__double_as_longlong(ld_agent(cs.xall + s_job[3])) != want) {
-                    if (__builtin_amdgcn_s_memrealtime() - t0c > 500000000ull) {
-#ifdef HTM_STAMPS
-                        if (tid == 0 && w == 0 && cs.stamps) {
-                            cs.stamps[112] = 1; cs.stamps[113] = m; cs.stamps[114] = tag; cs.stamps[115] = s_job[3]; cs.stamps[116] = want;
-                            cs.stamps[117] = (unsigned long long)__double_as_longlong(ld_agent(cs.xall + s_job[3])); cs.stamps[118] = s_job[0]; cs.stamps[119] = s_job[6];
-                        }
-#endif
-                        return;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            }
             // vs and qs of the evaluated model: chain state unless they are the proposal (same round of loads as
             // the corrections and the event coordinates below)
             const double beta_c = ld_agent(cs.vs.x + m), q_c = ld_agent(cs.qs.x + m);

@@ -1,21 +1,31 @@
-import sys, ctypes as C
-sys.path.insert(0, '.')
-import numpy as np
-from hypotremormcmc_amd import synth, driver, _lib
+"""Run ON THE GPU BOX with the -DHTM_STAMPS build: what a timed-out wait of the master was waiting for.
+HTM_LIB=hypotremormcmc_amd/lib/libhtm_hip_stamps.so python tools/diag_wait.py E S chains seed step_size_z n_iter
+(the run of tools/stress_rejections.py with the same numbers)"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+from hypotremormcmc_amd import _lib, driver, synth
 from hypotremormcmc_amd.obs_data import ObsData
-E,S,nc,ncool,seed,n_iter,over = (1000, 64, 8, 1, 17, 700, {"step_size_z": 8.0, "n_interval": 2})
-data = synth.make_synthetic(E,S,seed)
-params = dict(synth.DEFAULT_PARAMS, n_procs=1, n_chains=nc, n_cool=ncool, n_iter=n_iter, n_burn=n_iter//3, n_interval=5); params.update(over)
+
+E, S, nc, seed = (int(x) for x in sys.argv[1:5])
+sz = float(sys.argv[5]); n_iter = int(sys.argv[6])
+data = synth.make_synthetic(E, S, 100 + seed)
+params = dict(synth.DEFAULT_PARAMS, n_procs=1, n_chains=nc, n_cool=2 if nc > 2 else 1, n_iter=n_iter, n_burn=n_iter // 2,
+              n_interval=3, step_size_z=sz, step_size_vs=0.4)
 obs = ObsData.from_arrays(data.sta_x, data.sta_y, data.t_obs, data.t_stdv, data.a_obs, data.a_stdv)
 fwd, cs = driver.build_rank(params, data.sta_x, data.sta_y, data.sta_z, obs, 0, n_procs=1)
 try:
     cs.run(n_iter)
     print("ran fine")
-except Exception as e:
+except Exception as e:      # noqa: BLE001
     print("ERR", e)
 lib = _lib.load()
 lib.htm_chains_read_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
 a = (C.c_uint64 * 128)()
 lib.htm_chains_read_stamps(cs.handle, a)
-print("master:", [hex(x) for x in a[100:111]])
-print("worker:", [hex(x) for x in a[112:120]])
+names = ["wait (1 sums, 2 seen value)", "chain", "tag", "pre", "pre_mode", "iter", "p", "type", "idx", "granule hi", "granule lo", "start[c]"]
+print("master:", {n: hex(v) for n, v in zip(names, a[100:112])})
+print("worker 0 (commit wait timed out):", [hex(x) for x in a[112:120]])
