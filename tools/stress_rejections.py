@@ -1,5 +1,5 @@
 """Run ON THE GPU BOX: rejection-heavy runs against the oracle (Rayleigh-prior rejections shift stream positions, the
-validation repeats passes, orders sent ahead by role P miss their step).  python tools/stress_rejections.py [n_iter]"""
+validation repeats passes, orders sent ahead by role P miss their step).  python tools/stress_rejections.py [n_iter] [a:b]"""
 import os
 import sys
 import time
@@ -14,7 +14,11 @@ from oracle import oracle
 
 n_iter = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 bad = 0
-for (E, S, nc) in ((64, 64, 8), (1000, 64, 8), (200, 64, 3), (30, 20, 7), (100, 64, 16), (64, 32, 27)):
+SHAPES = ((64, 64, 8), (1000, 64, 8), (200, 64, 3), (30, 20, 7), (100, 64, 16), (64, 32, 27))
+if len(sys.argv) > 2:        # "a:b": a slice of the shapes
+    a_, b_ = (int(x) for x in sys.argv[2].split(":"))
+    SHAPES = SHAPES[a_:b_]
+for (E, S, nc) in SHAPES:
     for seed, sz in ((1, 4.0), (2, 8.0), (3, 12.0), (4, 20.0)):
         data = synth.make_synthetic(E, S, 100 + seed)
         params = dict(synth.DEFAULT_PARAMS, n_procs=1, n_chains=nc, n_cool=2 if nc > 2 else 1, n_iter=n_iter, n_burn=n_iter // 2,
