@@ -50,6 +50,8 @@ cases = [
     ("pieces + tiny record buffers", dict(E=64, S=64, nc=8, n_procs=1, sz=12.0), "pieces"),
     ("checkpoint / restore", dict(E=64, S=64, nc=8, n_procs=1, sz=12.0), "ckpt"),
     ("single rank driven in lock-step", dict(E=64, S=64, nc=8, n_procs=1, sz=12.0), "lockstep"),
+    ("small random-stream ring", dict(E=64, S=64, nc=8, n_procs=1, sz=12.0), "smallring"),
+    ("small ring, two ranks in lock-step", dict(E=64, S=64, nc=4, n_procs=2, sz=8.0), "smallring-lockstep"),
 ]
 for name, c, how in cases:
     data = synth.make_synthetic(c["E"], c["S"], 300 + len(name))
@@ -83,6 +85,16 @@ for name, c, how in cases:
         elif how == "lockstep":
             sets = build(data, params)
             LocalWorld(sets).run(n_iter)
+        elif how.startswith("smallring"):
+            os.environ["HTM_STREAM_CAP"] = "131072"      # the ring wraps every ~2 600 iterations; launches end at its edge
+            try:
+                sets = build(data, params)
+            finally:
+                del os.environ["HTM_STREAM_CAP"]
+            if how.endswith("lockstep"):
+                LocalWorld(sets).run(n_iter)
+            else:
+                sets[0].run(n_iter)
         else:
             sets = build(data, params)
             sets[0].run(n_iter)
