@@ -1,5 +1,5 @@
 """Run ON THE GPU BOX: rejection-heavy runs against the oracle (Rayleigh-prior rejections shift stream positions, the
-validation repeats passes, orders sent ahead by role P miss their step).  python tools/stress_rejections.py [n_iter] [a:b]"""
+validation repeats passes, orders sent ahead by role P miss their step).  python tools/stress_rejections.py [n_iter] [a:b] [sz,sz,...]"""
 import os
 import sys
 import time
@@ -19,7 +19,10 @@ if len(sys.argv) > 2:        # "a:b": a slice of the shapes
     a_, b_ = (int(x) for x in sys.argv[2].split(":"))
     SHAPES = SHAPES[a_:b_]
 for (E, S, nc) in SHAPES:
-    for seed, sz in ((1, 4.0), (2, 8.0), (3, 12.0), (4, 20.0)):
+    SZS = ((1, 4.0), (2, 8.0), (3, 12.0), (4, 20.0))
+    if len(sys.argv) > 3:    # "0.4,1.0": depth step sizes to run instead
+        SZS = tuple((10 + k, float(x)) for k, x in enumerate(sys.argv[3].split(",")))
+    for seed, sz in SZS:
         data = synth.make_synthetic(E, S, 100 + seed)
         params = dict(synth.DEFAULT_PARAMS, n_procs=1, n_chains=nc, n_cool=2 if nc > 2 else 1, n_iter=n_iter, n_burn=n_iter // 2,
                       n_interval=3, step_size_z=sz, step_size_vs=0.4)
