@@ -1220,9 +1220,12 @@ __device__ __forceinline__ void worker_body(const FwdDev &f, const ChainsDev &cs
                         const unsigned long long want = ((unsigned long long)s_job[4] << 32) | s_job[5];
                         const unsigned long long t0c = __builtin_amdgcn_s_memrealtime();
                         for (;;) {
+                            // the clock is read BEFORE the value: a wave that was switched out in between (processes sharing
+                            // the GPU) finds the value when it comes back instead of an expired clock
+                            const unsigned long long t_now = __builtin_amdgcn_s_memrealtime();
                             if ((unsigned long long)__double_as_longlong(ld_agent(cs.xall + s_job[3])) == want) break;
                             const unsigned now_tag = (unsigned)(ld_agent(slots + (size_t)chain * kGranPerSlot) >> 32);
-                            if (now_tag != tag || __builtin_amdgcn_s_memrealtime() - t0c > 20000ull) {
+                            if (now_tag != tag || t_now - t0c > 20000ull) {
 #ifdef HTM_STAMPS
                                 if (lane == 0 && w == 0 && cs.stamps) {
                                     cs.stamps[112] += 1; cs.stamps[113] = chain; cs.stamps[114] = tag; cs.stamps[115] = s_job[3]; cs.stamps[116] = want;
