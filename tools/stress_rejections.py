@@ -1,5 +1,5 @@
 """Run ON THE GPU BOX: rejection-heavy runs against the oracle (Rayleigh-prior rejections shift stream positions, the
-validation repeats passes, orders sent ahead by role P miss their step).  python tools/stress_rejections.py [n_iter] [a:b] [sz,sz,...]"""
+validation repeats passes, orders sent ahead by role P miss their step).  python tools/stress_rejections.py [n_iter] [a:b] [sz,sz,...] [seed offset]"""
 import os
 import sys
 import time
@@ -14,6 +14,7 @@ from oracle import oracle
 
 n_iter = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 bad = 0
+SEED0 = int(sys.argv[4]) if len(sys.argv) > 4 else 0      # another set of data sets and random streams
 SHAPES = ((64, 64, 8), (1000, 64, 8), (200, 64, 3), (30, 20, 7), (100, 64, 16), (64, 32, 27))
 if len(sys.argv) > 2:        # "a:b": a slice of the shapes
     a_, b_ = (int(x) for x in sys.argv[2].split(":"))
@@ -23,7 +24,7 @@ for (E, S, nc) in SHAPES:
     if len(sys.argv) > 3:    # "0.4,1.0": depth step sizes to run instead
         SZS = tuple((10 + k, float(x)) for k, x in enumerate(sys.argv[3].split(",")))
     for seed, sz in SZS:
-        data = synth.make_synthetic(E, S, 100 + seed)
+        data = synth.make_synthetic(E, S, 100 + seed + SEED0)
         params = dict(synth.DEFAULT_PARAMS, n_procs=1, n_chains=nc, n_cool=2 if nc > 2 else 1, n_iter=n_iter, n_burn=n_iter // 2,
                       n_interval=3, step_size_z=sz, step_size_vs=0.4)
         t0 = time.time()
