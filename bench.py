@@ -1,29 +1,36 @@
 #!/usr/bin/env python3
 """bench.py -- MCMC proposal steps/s of the HIP likelihood inner loop on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          # N > 1: spawns its own N ranks (one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 Workload (BASELINE.json configs[2], the one the metric is quoted on): 1 000 synthetic events x 64 stations
 (seed 1), 8 chains per GPU, n_cool = 1, temp_high = 200, all solve_* / use_* = T, priors and step sizes of
 sample/hypo_tremor.in.  N > 1: one rank per GPU, 8 chains each (weak scaling, BASELINE configs[3] at N = 8),
-temperature swap between ANY two chains of the job every iteration, exchanged with one RCCL all-gather.
+temperature swap between ANY two chains of the job every iteration (reference src/cls_parallel.f90:100-216).
 
-A "step" for --steps/--warmup is one MCMC iteration of a rank = n_chains proposal steps (propose ->
-forward -> judge for every chain, then swap_temperature).  `value` = proposal steps per second over all
-ranks; inputs are resident in HBM before the timed region starts.
+A bench "step" (--steps / --warmup) is a fixed BLOCK of main-loop iterations of every rank (reference
+src/hypo_tremor_mcmc.f90:236-284), ITERS_PER_STEP = 8 192 by default: one iteration = n_chains proposal steps
+(propose -> forward -> judge for every chain, then swap_temperature).  So the driver's `--steps 20 --warmup 5`
+times 163 840 iterations = 1.3 M proposal steps per GPU: a region of about a second of the persistent kernel,
+not a launch prologue.  `value` = proposal steps per second over all ranks; inputs are resident in HBM before
+the timed region starts; the region is bracketed by a barrier + device synchronisation on both sides.
 
 Besides the driver contract the JSON line carries
   roofline          the dominant kernel of the timed region (k_mcmc), HIP events on its stream; peak = 8 TB/s
-  roofline_batch64  the full-evaluation kernel on its own (64 stacked models per launch)
-  stages            the two stages of an iteration timed separately on the two-kernel path
-  cpu_baseline  the CPU restatement (oracle/) timed on one host core on a bounded sample of the same workload
+  roofline_batch64  the full-evaluation kernel on its own (64 stacked models per launch)            [N = 1]
+  stages            the two stages of an iteration timed separately on the two-kernel path           [N = 1]
+  cpu_baseline      the compiled reference (oracle/_ref; else the C restatement) timed on the host cores of
+                    this box on a bounded sample of the same workload: all chains of the job spread over
+                    min(chains, cores) MPI ranks, plus the one-core figure
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,6 +38,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 N_EVENTS, N_STA, N_CHAINS, SEED = 1000, 64, 8, 1
+ITERS_PER_STEP = 8192
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -41,95 +49,154 @@ def algorithmic_bytes(E, S, w=8):
     return b_full, b_part
 
 
+# ---------------------------------------------------------------------------------------------------
+# CPU baseline (the only part of this file that touches oracle/)
+# ---------------------------------------------------------------------------------------------------
 def _port_baseline(params, data, seconds_target):
     from oracle import oracle
 
     job = oracle.Job(params, data)
     job.run(200)                                  # includes the all-full first iteration; not timed
-    t0 = time.perf_counter(); job.run(500); dt = time.perf_counter() - t0
-    n_it = max(500, int(500 * seconds_target / max(dt, 1e-3)))
+    t0 = time.perf_counter(); job.run(300); dt = time.perf_counter() - t0
+    n_it = max(300, int(300 * seconds_target / max(dt, 1e-3)))
     t0 = time.perf_counter(); job.run(n_it); dt = time.perf_counter() - t0
     return n_it * int(params["n_chains"]) / dt, n_it, dt
 
 
-def _reference_baseline(params, data, n_iter_long, n_iter_short):
-    """The compiled reference itself (oracle/_ref, built in the build container from the unmodified Fortran
-    sources with AMD flang -O2 + MPICH), 1 MPI rank: two runs of different length, so that set-up and file
-    input cancel and only the main loop is priced."""
+def _host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return os.cpu_count() or 1
+
+
+def _reference_run(work, exe, params, ranks, n_it):
+    from hypotremormcmc_amd import synth
+
+    synth.write_param_file(os.path.join(work, "run.in"), **dict(params, n_iter=n_it, n_burn=n_it, n_interval=1000))
+    t0 = time.perf_counter()
+    subprocess.run(["/opt/conda/bin/mpiexec", "-np", str(ranks), exe, "run.in"], cwd=work, check=True, timeout=900,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return time.perf_counter() - t0
+
+
+def _reference_baseline(params, data, ranks, chains_per_rank, seconds_target):
+    """The compiled reference itself (oracle/_ref: the unmodified Fortran sources, AMD flang -O2 + MPICH) on
+    `ranks` MPI ranks x `chains_per_rank` chains: runs of different length, so that set-up and file input
+    cancel and only the main loop (src/hypo_tremor_mcmc.f90:236-284) is priced.
+    Returns (proposal steps/s, iterations, seconds) or None."""
     import shutil
-    import subprocess
     import tempfile
 
     from hypotremormcmc_amd import synth
 
     exe = os.path.join(ROOT, "oracle", "_ref", "hypo_tremor_mcmc_ref")
-    mpiexec = "/opt/conda/bin/mpiexec"
-    if not (os.path.exists(exe) and os.path.exists(mpiexec)):
+    if not (os.path.exists(exe) and os.path.exists("/opt/conda/bin/mpiexec")):
         return None
     work = tempfile.mkdtemp(prefix="htm_refbase_")
     try:
         synth.write_dataset(work, data)
-        times = []
-        for n_it in (n_iter_short, n_iter_long):
-            synth.write_param_file(os.path.join(work, "run.in"),
-                                   **dict(params, n_iter=n_it, n_burn=n_it, n_interval=1000))
-            t0 = time.perf_counter()
-            subprocess.run([mpiexec, "-np", "1", exe, "run.in"], cwd=work, check=True, timeout=600,
-                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-            times.append(time.perf_counter() - t0)
-        dt = times[1] - times[0]
+        p = dict(params, n_procs=ranks, n_chains=chains_per_rank)
+        n0, n1 = 200, 1200
+        t_short = _reference_run(work, exe, p, ranks, n0)
+        t_mid = _reference_run(work, exe, p, ranks, n1)
+        rate = (n1 - n0) / max(t_mid - t_short, 1e-3)                 # iterations / s
+        n2 = n0 + int(min(max(rate * seconds_target, 2000), 2_000_000))
+        t_long = _reference_run(work, exe, p, ranks, n2)
+        dt = t_long - t_short
         if dt <= 0:
             return None
-        return (n_iter_long - n_iter_short) * int(params["n_chains"]) / dt, dt
-    except Exception:
+        return (n2 - n0) * ranks * chains_per_rank / dt, n2 - n0, dt
+    except Exception as exc:                                          # report the port instead
+        sys.stderr.write(f"[bench] reference baseline failed: {exc}\n")
         return None
     finally:
         shutil.rmtree(work, ignore_errors=True)
 
 
-def cpu_baseline(params, data, seconds_target=10.0):
-    """CPU baseline on ONE host core, same workload, bounded sample: the compiled reference when its
-    binary travelled with the snapshot (kind = reference), else the C restatement (kind = port)."""
-    n_chains = int(params["n_chains"])
-    port, n_it, dt = _port_baseline(params, data, seconds_target)
+def cpu_baseline(params, data, total_chains, seconds_target=10.0):
+    """CPU baseline of the same job on this box's host cores (bounded samples).  `value` = the reference on
+    min(total_chains, cores) MPI ranks (the reference's own parallelism: chains over ranks,
+    README.md:62-66), `one_core` = the same chains of ONE GPU's share on one rank."""
+    nc = int(params["n_chains"])
+    cores = _host_cores()
+    ranks = 1
+    for r in range(min(total_chains, cores), 0, -1):
+        if total_chains % r == 0:
+            ranks = r
+            break
+    port, n_it, dt = _port_baseline(dict(params, n_procs=1), data, min(5.0, seconds_target))
     out = {"value": port, "unit": "proposal steps/s", "cores": 1, "kind": "port",
-           "sample": f"{n_it} iterations x {n_chains} chains of the same {data.n_events}x{data.n_sta} workload "
+           "sample": f"{n_it} iterations x {nc} chains of the same {data.n_events}x{data.n_sta} workload "
                      f"on 1 core ({dt:.1f} s), oracle/htm_oracle.c (gcc -O2, no fast-math)"}
-    ref = _reference_baseline(params, data, 36300, 300)
-    if ref is not None:
-        out = {"value": ref[0], "unit": "proposal steps/s", "cores": 1, "kind": "reference",
-               "sample": f"36000 iterations x {n_chains} chains of the same workload, 1 MPI rank, main loop only "
-                         f"({ref[1]:.1f} s; difference of a 36300- and a 300-iteration run), reference Fortran "
-                         f"compiled unmodified with AMD flang -O2",
+    one = _reference_baseline(params, data, 1, nc, seconds_target)
+    multi = _reference_baseline(params, data, ranks, total_chains // ranks, seconds_target) if ranks > 1 else one
+    if multi is not None:
+        out = {"value": multi[0], "unit": "proposal steps/s", "cores": ranks, "kind": "reference",
+               "host_cores_available": cores,
+               "sample": f"{multi[1]} iterations x {total_chains} chains ({ranks} MPI ranks x {total_chains // ranks} "
+                         f"chain(s), swap every iteration) of the same workload, main loop only ({multi[2]:.1f} s; "
+                         f"difference of two run lengths), reference Fortran compiled unmodified with AMD flang -O2 + MPICH",
                "port_value": port, "port_sample": out["sample"]}
+        if one is not None:
+            out["one_core"] = {"value": one[0], "cores": 1,
+                               "sample": f"{one[1]} iterations x {nc} chains, 1 MPI rank ({one[2]:.1f} s)"}
     return out
 
 
-def main():
-    # Native libraries (RCCL prints a version banner) write to fd 1; the contract is ONE JSON line on stdout.
-    # Everything else goes to stderr; the JSON is written to the saved stdout at the end.
-    real_stdout = os.dup(1)
-    sys.stdout.flush()
-    os.dup2(2, 1)
+# ---------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` (N > 1) starts its own ranks -- the reference is launched as
+# `mpirun -np N` (README.md:62-66); here one rank per GPU under torch.distributed.run
+# ---------------------------------------------------------------------------------------------------
+def free_port():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """Runs before anything in this process has touched the GPU (no torch import, no HIP call): the ranks are
+    child processes, this process only forwards their output and exit code."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20000)
-    ap.add_argument("--warmup", type=int, default=2000)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--iters-per-step", type=int, default=ITERS_PER_STEP,
+                    help="main-loop iterations per bench step (default %(default)s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chains", type=int, default=N_CHAINS)
     ap.add_argument("--events", type=int, default=N_EVENTS)
     ap.add_argument("--stations", type=int, default=N_STA)
     ap.add_argument("--force-lockstep", action="store_true",
-                    help="N = 1 only: drive the multi-rank code path (RCCL all-gather per iteration) with one rank")
-    args = ap.parse_args()
+                    help="N = 1 only: drive the multi-rank code path (swap records exchanged every iteration) with one rank")
+    return ap.parse_args(argv)
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, argv))
+
+    # Native libraries (RCCL prints a version banner) write to fd 1; the contract is ONE JSON line on stdout.
+    # Everything else goes to stderr; the JSON is written to the saved stdout at the end.
+    real_stdout = os.dup(1)
+    sys.stdout.flush()
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N > 1 with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
 
     # a cold `import torch` on a fresh box can take minutes: a sign of life on stderr meanwhile (rank 0)
     if rank == 0:
@@ -146,60 +213,78 @@ def main():
         threading.Thread(target=_beat, daemon=True).start()
     import torch  # device plumbing + torch.distributed only
 
-    from hypotremormcmc_amd import driver, synth
-    from hypotremormcmc_amd.obs_data import ObsData
-
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1 or args.force_lockstep:
-        import torch.distributed as dist
-
-        if world == 1:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            import socket
-
-            with socket.socket() as sk:
-                sk.bind(("127.0.0.1", 0))
-                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
-            dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    from hypotremormcmc_amd import synth
 
     E, S, nc = args.events, args.stations, args.chains
+    ips = max(1, args.iters_per_step)
+    n_warm, n_timed = args.warmup * ips, args.steps * ips
     data = synth.make_synthetic(E, S, SEED)
     params = dict(synth.DEFAULT_PARAMS, n_procs=world, n_chains=nc, n_cool=1,
-                  n_iter=args.steps + args.warmup + 10 ** 6, n_burn=10 ** 9, n_interval=1000)
-    obs = ObsData.from_arrays(data.sta_x, data.sta_y, data.t_obs, data.t_stdv, data.a_obs, data.a_stdv)
-    fwd, cs = driver.build_rank(params, data.sta_x, data.sta_y, data.sta_z, obs, rank, n_procs=world,
-                                device=local_rank)
+                  n_iter=n_warm + n_timed + 10 ** 6, n_burn=2 * 10 ** 9, n_interval=1000)
 
-    def sync_all():
+    # Test hook (tests/test_bench_launcher.py): "module:function" supplying the per-rank engine, so that launcher,
+    # rendezvous, timing protocol and the JSON contract run on a box without a GPU (gloo).  Never a measurement:
+    # the line is marked.  The product engine below has no fallback -- without the HIP library it raises.
+    test_engine = os.environ.get("HTM_BENCH_TEST_ENGINE")
+    dist = None
+    lockstep = world > 1 or args.force_lockstep
+    if test_engine:
+        import importlib
+
+        mod, fn = test_engine.split(":")
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        eng =getattr(importlib.import_module(mod), fn)(params, data, rank, world)
+        run, sync, device_sync = eng.run, eng.sync, (lambda: None)
+        fwd = cs = None
+    else:
+        from hypotremormcmc_amd import driver
+        from hypotremormcmc_amd.obs_data import ObsData
+
+        torch.cuda.set_device(local_rank)
+        if lockstep:
+            import torch.distributed as dist
+
+            if world == 1:
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", str(free_port()))
+                dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        obs = ObsData.from_arrays(data.sta_x, data.sta_y, data.t_obs, data.t_stdv, data.a_obs, data.a_stdv)
+        fwd, cs = driver.build_rank(params, data.sta_x, data.sta_y, data.sta_z, obs, rank, n_procs=world,
+                                    device=local_rank)
+        if not lockstep:
+            run = cs.run
+        else:
+            from hypotremormcmc_amd.parallel import TorchWorld
+
+            tw = TorchWorld(cs)
+            run = tw.run
+        sync, device_sync = cs.sync, torch.cuda.synchronize
+
+    def fence():
+        sync()                  # the chains' own stream: every iteration asked for has completed
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        device_sync()
 
-    if world == 1 and not args.force_lockstep:
-        run = cs.run
-    else:
-        from hypotremormcmc_amd.parallel import TorchWorld
-
-        tw = TorchWorld(cs)
-        run = tw.run
-
-    run(args.warmup)
-    sync_all()
+    run(n_warm)
+    fence()
     t0 = time.perf_counter()
-    run(args.steps)
-    cs.sync()
-    sync_all()
+    run(n_timed)
+    fence()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if test_engine else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    assert cs.iterations_done == args.warmup + args.steps
+    done = eng.iterations_done if test_engine else cs.iterations_done
+    assert done == n_warm + n_timed, (done, n_warm + n_timed)
 
-    value = world * nc * args.steps / dt
+    value = world * nc * n_timed / dt
     b_full, b_part = algorithmic_bytes(E, S)
     out = {
         "metric": "MCMC proposal steps/sec (whole node), 1k events x 64 stn",
@@ -209,53 +294,66 @@ def main():
         "config": {"workload": f"{E} events x {S} stations, {nc} chains/GPU x {world} GPU(s), swap every "
                                f"iteration, all solve_*/use_* = T (BASELINE configs[{2 if world == 1 else 3}])",
                    "chains_per_gpu": nc, "n_events": E, "n_sta": S, "seed": SEED,
-                   "step_definition": "one MCMC iteration of a rank = n_chains proposal steps",
-                   "parallelism": f"chains sharded over {world} rank(s); one all-gather of "
-                                  f"{8 * (4 + 2 * nc)} B per rank per iteration" if world > 1 else "single rank"},
+                   "step_definition": f"one bench step = {ips} main-loop iterations of every rank = {ips * nc} proposal "
+                                      f"steps per GPU (one iteration = n_chains x [propose -> forward -> judge] + swap_temperature)",
+                   "iterations_per_step": ips, "iterations_timed": n_timed, "us_per_iteration": 1e6 * dt / n_timed,
+                   "parallelism": f"chains sharded over {world} rank(s), one per GPU; swap records of "
+                                  f"{8 * (4 + 2 * nc)} B per rank exchanged every iteration" if world > 1 else "single rank"},
     }
-
     if args.force_lockstep:
-        out["config"]["parallelism"] = "lock-step path (one RCCL all-gather per iteration), 1 rank"
-    if rank == 0 and world == 1 and not args.force_lockstep:
+        out["config"]["parallelism"] = "lock-step path (swap records exchanged every iteration), 1 rank"
+    if test_engine:
+        out["engine"] = f"{test_engine} (test double on CPU: launcher/protocol check, NOT a measurement)"
+        out["data"] = "synthetic (test double)"
+
+    if rank == 0 and not test_engine:
         # ---- dominant kernel of the timed region: k_mcmc (chain master + resident full-evaluation workers).
-        # Its launches ARE the timed region; duration from the HIP events htm_chains_run records on the
-        # kernels' stream around them, algorithmic bytes from the evaluations they performed.
+        # Its launches ARE the timed region; duration from the HIP events the library records on the kernels'
+        # stream around them, algorithmic bytes from the evaluations they performed.
         st = cs.last_run_stats()
         persistent = os.environ.get("HTM_PERSIST", "1") != "0"
         n_launch = max(1, st["graph_launches"])
         bytes_region = st["full_evals"] * b_full + st["partial_evals"] * b_part
-        achieved = bytes_region / (st["device_us"] * 1e-6) / 1e9
-        # HBM-side bytes per launch from the committed PMC passes (profiles/*_traffic.json: FETCH_SIZE doubled as
-        # MI355X_MICROARCH.md prescribes for gfx950 + WRITE_SIZE, per iteration) x the iterations of a launch
+        achieved = bytes_region / max(st["device_us"] * 1e-6, 1e-9) / 1e9
+        # HBM-side bytes per launch: PMC passes are separate rocprofv3 runs of this same command (tools/
+        # make_profiles.sh), so the figure comes from the newest committed profiles/*_traffic.json -- FETCH_SIZE
+        # doubled as MI355X_MICROARCH.md prescribes for gfx950 + WRITE_SIZE, per iteration -- x the iterations of a
+        # launch; `traffic_source` says which file (null when the shape differs from the profiled one)
         traffic, traffic_src = None, None
         try:
             import glob
 
             tf_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
-            if tf_files and persistent and (E, S, nc) == (N_EVENTS, N_STA, N_CHAINS):
+            if tf_files and persistent and not lockstep and (E, S, nc) == (N_EVENTS, N_STA, N_CHAINS):
                 with open(tf_files[-1]) as fh:
                     tj = json.load(fh)
                 per_it = 2.0 * tj["fetch_bytes_per_iteration_raw"] + tj["write_bytes_per_iteration"]
-                traffic = per_it * args.steps / n_launch
-                traffic_src = os.path.relpath(tf_files[-1], ROOT)
+                traffic = per_it * n_timed / n_launch
+                traffic_src = os.path.relpath(tf_files[-1], ROOT) + " (separate PMC passes of this command, not this run)"
         except Exception:
             traffic = None
+        if lockstep:
+            kname = "k_mcmc<1> (lock-step: one iteration per hand-shake with the swap-record exchange)"
+        elif persistent:
+            kname = "k_mcmc<1> (propose + partial/full log-likelihood + judge + swap, persistent)"
+        else:
+            kname = "k_step<1> + k_full<1,false> (graph of the two-kernel path)"
         out["roofline"] = {
-            "bound": "hbm",
-            "kernel": "k_mcmc<1> (propose + partial/full log-likelihood + judge + swap, persistent)" if persistent
-                      else "k_step<1> + k_full<1,false> (graph of the two-kernel path)",
+            "bound": "hbm", "kernel": kname,
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": traffic_src,
             "bytes_per_launch": bytes_region / n_launch, "avg_launch_us": st["device_us"] / n_launch,
             "launches": n_launch, "full_evals": st["full_evals"], "partial_evals": st["partial_evals"],
+            "device_us_region": st["device_us"],
             "note": "algorithmic bytes = 2 074 568 B per full evaluation + 4 672 B per single-event partial update "
-                    "(SURVEY 8d); at 8 chains/GPU an iteration is a dependent chain of ~8 us that touches ~1.7 MB, "
-                    "all of it L2/Infinity-Cache resident (traffic = HBM-side bytes per launch from the committed PMC "
-                    "passes, ~1 % of the algorithmic bytes): the workload is latency-bound, not HBM-bound (DESIGN.md 5); "
-                    "see roofline_batch64 for the full-evaluation kernel on its own",
+                    "(SURVEY 8d) x the evaluations counted on the device in the timed region (rank 0's GPU), / the HIP-event "
+                    "time of that region on the kernels' stream.  At 8 chains/GPU an iteration is a dependent chain "
+                    "of a few us that touches ~1.7 MB, all of it L2/Infinity-Cache resident: the workload is "
+                    "latency-bound, not HBM-bound (DESIGN.md 5); see roofline_batch64 for the full-evaluation kernel on its own",
         }
+    if rank == 0 and world == 1 and not args.force_lockstep and not test_engine:
         # ---- the two stages timed separately (fallback two-kernel path, same arithmetic), HIP events per launch
-        n_prof = min(4000, max(500, args.steps // 5))
+        n_prof = 2000
         prof = cs.profile(n_prof)
         full_avg_us = prof["full_us"] / max(1, prof["full_launches"])
         step_avg_us = prof["step_us"] / max(1, prof["step_launches"])
@@ -290,15 +388,9 @@ def main():
                                    "avg_launch_us": us, "evals_per_s": nb / (us * 1e-6),
                                    "note": "200 back-to-back launches of k_full<1,true> + k_sum_partials bracketed by "
                                            "HIP events; inputs resident in HBM"}
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(dict(params, n_procs=1), data)
-    elif rank == 0:
-        b_step = 0.1 * b_full + 0.9 * b_part
-        ach = value * b_step / 1e9 / world
-        out["roofline"] = {"bound": "hbm", "kernel": "whole loop (per GPU)", "achieved": ach, "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                           "note": "N > 1: steps/s x 211 662 B expected algorithmic bytes per step / n_gpus; "
-                                   "per-kernel figures are reported by the N = 1 run"}
+    if rank == 0 and not args.no_cpu_baseline and not test_engine:
+        # the other ranks wait at the barrier below; their GPUs are idle by now
+        out["cpu_baseline"] = cpu_baseline(params, data, world * nc)
     if rank == 0:
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:

@@ -6,7 +6,7 @@ import numpy as np
 from hypotremormcmc_amd import synth
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = ["c1", "c2", "missing", "timeonly", "fixedcorr", "rejects", "c3"]
+CASES = ["c1", "c2", "missing", "timeonly", "fixedcorr", "rejects", "c3", "c4"]
 
 
 def load_case(name):
@@ -30,3 +30,32 @@ def load_case(name):
 
 def tf(v):
     return str(v).strip().upper().lstrip(".").startswith("T")
+
+
+class OracleRank:
+    """A rank of the job computed by the CPU oracle, in the shape TorchWorld drives."""
+
+    def __init__(self, job, rank, n_procs):
+        import torch
+
+        self.job, self.rank, self.n_procs = job, rank, n_procs
+        self._rec = np.zeros(job.record_words())
+        self.record = torch.from_numpy(self._rec)   # shares memory
+
+    def step_begin(self):
+        self.job.rank_begin(self.rank, self._rec)
+
+    def step_end(self, gathered):
+        g = gathered.numpy()
+        rc = self.job.rank_end(self.rank, np.ascontiguousarray(g))
+        assert rc == 0, f"rank_end returned {rc}"
+
+    def drain(self):
+        pass
+
+    def counts(self):
+        npr = np.zeros(7, np.int64); nac = np.zeros(7, np.int64)
+        for c in range(int(self.job.p.n_chains)):
+            st = self.job.chain(self.rank, c)
+            npr += st["n_propose"]; nac += st["n_accept"]
+        return npr, nac

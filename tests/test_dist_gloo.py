@@ -13,35 +13,6 @@ import pytest
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
-class OracleRank:
-    """A rank of the job computed by the CPU oracle, in the shape TorchWorld drives."""
-
-    def __init__(self, job, rank, n_procs):
-        import torch
-
-        self.job, self.rank, self.n_procs = job, rank, n_procs
-        self._rec = np.zeros(job.record_words())
-        self.record = torch.from_numpy(self._rec)   # shares memory
-
-    def step_begin(self):
-        self.job.rank_begin(self.rank, self._rec)
-
-    def step_end(self, gathered):
-        g = gathered.numpy()
-        rc = self.job.rank_end(self.rank, np.ascontiguousarray(g))
-        assert rc == 0, f"rank_end returned {rc}"
-
-    def drain(self):
-        pass
-
-    def counts(self):
-        npr = np.zeros(7, np.int64); nac = np.zeros(7, np.int64)
-        for c in range(int(self.job.p.n_chains)):
-            st = self.job.chain(self.rank, c)
-            npr += st["n_propose"]; nac += st["n_accept"]
-        return npr, nac
-
-
 def _worker(rank, world, port, name, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -49,7 +20,7 @@ def _worker(rank, world, port, name, q):
 
     from hypotremormcmc_amd.parallel import TorchWorld
     from oracle import oracle
-    from tests.helpers import load_case
+    from tests.helpers import OracleRank, load_case
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -75,7 +46,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("name,world", [("c1", 2), ("timeonly", 3), ("rejects", 2)])
+@pytest.mark.parametrize("name,world", [("c1", 2), ("timeonly", 3), ("rejects", 2), ("c4", 8)])   # c4 = BASELINE configs[3]
 def test_lockstep_allgather_protocol_reproduces_mpi_reference(name, world):
     import torch.multiprocessing as mp
 
