@@ -16,6 +16,8 @@ Cases
   fixedcorr 7 ev x  9 stn, seed 4, solve_t_corr = solve_vs = F, 2 ranks x 3 chains, n_cool = 2
   c3     1000 ev x 64 stn, seed 1, 1 rank x 8 chains, 600 it: inputs are NOT stored (2 MB) -- the seeded
          generator reproduces them; a checksum of the inputs is stored instead.
+  c4     1000 ev x 64 stn, seed 1, 8 ranks x 8 chains = 64 tempered chains, temp_high = 200, 400 it (BASELINE
+         configs[3], run under mpiexec -np 8); inputs as for c3.
 """
 from __future__ import annotations
 
@@ -59,6 +61,9 @@ CASES = {
                                 step_size_z=6.0, step_size_vs=0.4)),
     "c3": dict(n_events=1000, n_sta=64, seed=1, n_missing=0, store_inputs=False,
                params=dict(n_procs=1, n_chains=8, n_cool=1, n_iter=600, n_burn=300, n_interval=10)),
+    # BASELINE configs[3]: 64 chains with parallel tempering over 8 ranks (mpiexec -np 8), temp_high = 200
+    "c4": dict(n_events=1000, n_sta=64, seed=1, n_missing=0, store_inputs=False,
+               params=dict(n_procs=8, n_chains=8, n_cool=1, n_iter=400, n_burn=100, n_interval=10, temp_high="200.0")),
 }
 
 
@@ -159,9 +164,10 @@ def run_case(name, spec):
             fx[f"lik_{r}"] = v[:, 0]
             for nm, nv in (("vs", 1), ("qs", 1), ("t_corr", S), ("a_corr", S), ("hypo", 3 * E)):
                 it, v = read_records(os.path.join(work, "%s.%02d.out" % (nm, r)), nv)
-                if name == "c3" and nm == "hypo":
-                    v = v[-2:]  # keep the fixture small: last two hypocentre samples only
-                    it = it[-2:]
+                if not spec.get("store_inputs", True) and nm == "hypo":
+                    keep = 2 if n_procs == 1 else (1 if r in (0, n_procs - 1) else 0)
+                    v = v[len(v) - keep:]  # keep the fixture small: the last hypocentre sample(s) only, of the outer ranks
+                    it = it[len(it) - keep:]
                 fx[f"{nm}_iter_{r}"] = it
                 fx[f"{nm}_{r}"] = v
         # step 6 of the reference on the files step 5 just wrote: the four .stat files, as text.

@@ -65,9 +65,10 @@ def test_single_rank_run_matches_reference_trace(name):
     _check_against_fixture(fx, params, sets)
 
 
-@pytest.mark.parametrize("name", ["c1", "timeonly", "fixedcorr", "rejects"])
+@pytest.mark.parametrize("name", ["c1", "timeonly", "fixedcorr", "rejects", "c4"])
 def test_multi_rank_lockstep_matches_reference_trace(name):
-    """2-3 simulated ranks on one GPU; the record exchange is a device copy instead of the RCCL all-gather"""
+    """2-8 simulated ranks on one GPU; the record exchange is a device copy instead of the RCCL all-gather.
+    c4 = BASELINE configs[3]: 1000 x 64, 8 ranks x 8 chains, temp_high 200, against the reference under mpiexec -np 8"""
     from hypotremormcmc_amd.parallel import LocalWorld
 
     fx, data, params = load_case(name)
