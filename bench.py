@@ -70,20 +70,22 @@ def _host_cores():
         return os.cpu_count() or 1
 
 
-def _reference_run(work, exe, params, ranks, n_it):
+def _reference_run(work, exe, params, ranks, n_it, timeout):
     from hypotremormcmc_amd import synth
 
     synth.write_param_file(os.path.join(work, "run.in"), **dict(params, n_iter=n_it, n_burn=n_it, n_interval=1000))
     t0 = time.perf_counter()
-    subprocess.run(["/opt/conda/bin/mpiexec", "-np", str(ranks), exe, "run.in"], cwd=work, check=True, timeout=900,
+    subprocess.run(["/opt/conda/bin/mpiexec", "-np", str(ranks), exe, "run.in"], cwd=work, check=True, timeout=timeout,
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return time.perf_counter() - t0
 
 
-def _reference_baseline(params, data, ranks, chains_per_rank, seconds_target):
+def _reference_baseline(params, data, ranks, chains_per_rank, seconds_target, port_steps_per_s):
     """The compiled reference itself (oracle/_ref: the unmodified Fortran sources, AMD flang -O2 + MPICH) on
     `ranks` MPI ranks x `chains_per_rank` chains: runs of different length, so that set-up and file input
-    cancel and only the main loop (src/hypo_tremor_mcmc.f90:236-284) is priced.
+    cancel and only the main loop (src/hypo_tremor_mcmc.f90:236-284) is priced.  The long run's length comes from
+    a calibration pair, capped by what the C port's one-core rate allows (a noisy calibration must not turn a
+    bounded sample into minutes of CPU work); every run has its own timeout.
     Returns (proposal steps/s, iterations, seconds) or None."""
     import shutil
     import tempfile
@@ -97,12 +99,14 @@ def _reference_baseline(params, data, ranks, chains_per_rank, seconds_target):
     try:
         synth.write_dataset(work, data)
         p = dict(params, n_procs=ranks, n_chains=chains_per_rank)
-        n0, n1 = 200, 1200
-        t_short = _reference_run(work, exe, p, ranks, n0)
-        t_mid = _reference_run(work, exe, p, ranks, n1)
-        rate = (n1 - n0) / max(t_mid - t_short, 1e-3)                 # iterations / s
-        n2 = n0 + int(min(max(rate * seconds_target, 2000), 2_000_000))
-        t_long = _reference_run(work, exe, p, ranks, n2)
+        n0, n1 = 200, 2200
+        _reference_run(work, exe, p, ranks, n0, 120)                   # warms the file cache; not timed
+        t_short = _reference_run(work, exe, p, ranks, n0, 120)
+        t_mid = _reference_run(work, exe, p, ranks, n1, 240)
+        rate_cap = 3.0 * port_steps_per_s / chains_per_rank           # iterations / s a rank can plausibly reach
+        rate = min((n1 - n0) / max(t_mid - t_short, 1e-3), rate_cap)
+        n2 = n0 + int(max(rate * seconds_target, 2000))
+        t_long = _reference_run(work, exe, p, ranks, n2, 60 + 6 * seconds_target)
         dt = t_long - t_short
         if dt <= 0:
             return None
@@ -129,8 +133,8 @@ def cpu_baseline(params, data, total_chains, seconds_target=10.0):
     out = {"value": port, "unit": "proposal steps/s", "cores": 1, "kind": "port",
            "sample": f"{n_it} iterations x {nc} chains of the same {data.n_events}x{data.n_sta} workload "
                      f"on 1 core ({dt:.1f} s), oracle/htm_oracle.c (gcc -O2, no fast-math)"}
-    one = _reference_baseline(params, data, 1, nc, seconds_target)
-    multi = _reference_baseline(params, data, ranks, total_chains // ranks, seconds_target) if ranks > 1 else one
+    one = _reference_baseline(params, data, 1, nc, seconds_target, port)
+    multi = _reference_baseline(params, data, ranks, total_chains // ranks, seconds_target, port) if ranks > 1 else one
     if multi is not None:
         out = {"value": multi[0], "unit": "proposal steps/s", "cores": ranks, "kind": "reference",
                "host_cores_available": cores,
@@ -263,6 +267,9 @@ def main(argv=None):
 
             tw = TorchWorld(cs)
             run = tw.run
+            transport = ("persistent lock-step: swap records written into the peers' inboxes from inside the kernel (xGMI peer memory)"
+                         if tw.direct else "one k_mcmc launch + one RCCL all-gather per iteration, enqueued from C" if tw.fast
+                         else "torch.distributed all-gather per iteration")
         sync, device_sync = cs.sync, torch.cuda.synchronize
 
     def fence():
@@ -302,6 +309,8 @@ def main(argv=None):
     }
     if args.force_lockstep:
         out["config"]["parallelism"] = "lock-step path (swap records exchanged every iteration), 1 rank"
+    if lockstep and not test_engine:
+        out["config"]["swap_transport"] = transport
     if test_engine:
         out["engine"] = f"{test_engine} (test double on CPU: launcher/protocol check, NOT a measurement)"
         out["data"] = "synthetic (test double)"

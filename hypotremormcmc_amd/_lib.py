@@ -72,6 +72,9 @@ SIGNATURES = {
     "htm_quantiles_dev": (C.c_int, [C.c_int, vp, C.c_long, C.c_long, C.c_long, C.POINTER(C.c_int), vp, vp]),
     "htm_chains_swap_record_host": (C.c_int, [vp, dp]),
     "htm_chains_step_end_host": (C.c_int, [vp, dp]),
+    "htm_chains_xchg_handle": (C.c_int, [vp, vp, C.c_size_t]),
+    "htm_chains_xchg_connect": (C.c_int, [vp, vp, C.c_size_t]),
+    "htm_chains_run_lockstep_direct": (C.c_int, [vp, C.c_int]),
     "htm_chains_checkpoint_size": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
     "htm_chains_checkpoint_save": (C.c_int, [vp, vp, C.c_size_t]),
     "htm_chains_checkpoint_load": (C.c_int, [vp, vp, C.c_size_t]),
@@ -86,6 +89,7 @@ SIGNATURES = {
     "htm_chains_profile": (C.c_int, [vp, C.c_int, dp, C.POINTER(C.c_int), dp, C.POINTER(C.c_int),
                                      C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "htm_selftest": (C.c_int, [C.c_int]),
+    "htm_rng_jump": (C.c_int, [up, C.c_ulonglong, up]),
 }
 
 _LIB = None

@@ -113,6 +113,26 @@ class ChainSet:
         check(self._lib.htm_chains_run_lockstep(self.handle, int(n_iter), C.c_void_p(allgather_fn),
                                                 C.c_void_p(comm), C.c_void_p(d_gathered)))
 
+    # ---- persistent lock-step: swap records exchanged inside the kernel (peer-mapped inboxes) -------------
+    XCHG_HANDLE_BYTES = 64
+
+    def xchg_handle(self) -> bytes:
+        """IPC handle of this rank's inbox (to be all-gathered over the ranks)."""
+        buf = C.create_string_buffer(self.XCHG_HANDLE_BYTES)
+        check(self._lib.htm_chains_xchg_handle(self.handle, buf, self.XCHG_HANDLE_BYTES))
+        return buf.raw
+
+    def xchg_connect(self, handles: bytes | None):
+        """handles = the n_procs handles in rank order, concatenated (None for a single-rank job)."""
+        if handles is None:
+            check(self._lib.htm_chains_xchg_connect(self.handle, None, 0))
+        else:
+            buf = C.create_string_buffer(handles, len(handles))
+            check(self._lib.htm_chains_xchg_connect(self.handle, buf, self.XCHG_HANDLE_BYTES))
+
+    def run_lockstep_direct(self, n_iter: int):
+        check(self._lib.htm_chains_run_lockstep_direct(self.handle, int(n_iter)))
+
     def sync(self):
         check(self._lib.htm_chains_sync(self.handle))
 

@@ -286,7 +286,7 @@ struct ModelDev {            // one reference `type model` group for all chains 
 };
 
 enum Stage : int { ST_IDLE = 0, ST_WAIT_FULL = 1, ST_WAIT_SWAP = 2 };
-enum Mode : int { MODE_RUN = 0, MODE_ADVANCE = 1, MODE_FINISH = 2, MODE_APPLY = 3 };
+enum Mode : int { MODE_RUN = 0, MODE_ADVANCE = 1, MODE_FINISH = 2, MODE_APPLY = 3, MODE_LOCKRUN = 4 };
 
 struct Proposal {            // everything random about one chain step, resolved at the start of the iteration
     int    type;             // 1 vs, 2 t_corr, 3 qs, 4 a_corr, 5..7 hypo (5 + icmp), cls_mcmc.f90:139-165
@@ -355,7 +355,7 @@ struct StreamDev {
     int *hop;                  // [p][k-1] = position after k optimistic chain steps, k = 1..8
     int4 *sw;                  // select_pair starting at p (rank 0): {i1, i2, draws used or -1, 0}
     long long mask;            // capacity - 1
-    uint32_t *gen;             // [4] generator state after the last produced raw
+    uint32_t *gen;             // [2][4] generator state after the last produced raw (the host alternates the two)
     long long *hop_end;        // every array is complete for positions < *hop_end
 };
 
@@ -395,6 +395,10 @@ struct ChainsDev {
     int mirror_steps;                // the step sizes of those elements are mirrored too (else role P reads them from memory)
     int rayleigh14;                  // some element of those four groups has a Rayleigh prior (prior_type 1)
     int n_workers;                   // worker blocks of a k_mcmc launch
+    // in-kernel exchange of the swap records (MODE_LOCKRUN, htm_step.hpp exchange_records)
+    unsigned long long *inbox;       // [2][n_procs][xg] tagged granules, this rank's own (fine-grained memory: peers write it)
+    unsigned long long *const *outbox;   // [n_procs] where rank q's inbox is mapped in this process (q = rank: inbox itself)
+    int xg;                          // granules per record = 2 * (4 + 2 n_chains) + 2
     StreamDev stream;
     unsigned long long *stamps;      // diagnostic builds (-DHTM_STAMPS) only, else nullptr
 };

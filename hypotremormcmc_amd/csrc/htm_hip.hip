@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -78,6 +79,46 @@ int dev_upload(std::vector<void *> &pool, T **p, const T *src, size_t n)
 
 int nch_for(int S) { return S <= 64 ? 1 : S <= 128 ? 2 : S <= 256 ? 4 : 0; }
 
+// ---- GF(2) algebra of mod_random's xorshift128 (reference src/mod_random.f90:63-71) ----------------------------
+// One step is linear in the 128 state bits (x | y << 32 | z << 64 | w << 96): state' = T * state.  Powers of T let
+// the device start any 64-draw segment of the stream directly (htm_stream.hpp, k_rawgen) and the host jump over any
+// number of draws (htm_rng_jump).  A matrix is stored as its 128 columns.
+struct Bits128 { uint32_t w[4]; };
+using Mat128 = std::array<Bits128, 128>;
+
+Bits128 xs_step(Bits128 s)
+{
+    const uint32_t t = s.w[0] ^ (s.w[0] << 11);
+    Bits128 r;
+    r.w[0] = s.w[1]; r.w[1] = s.w[2]; r.w[2] = s.w[3];
+    r.w[3] = (s.w[3] ^ (s.w[3] >> 19)) ^ (t ^ (t >> 8));
+    return r;
+}
+Bits128 gf2_matvec(const Mat128 &M, const Bits128 &v)
+{
+    Bits128 a{{0, 0, 0, 0}};
+    for (int j = 0; j < 128; ++j)
+        if ((v.w[j >> 5] >> (j & 31)) & 1u)
+            for (int k = 0; k < 4; ++k) a.w[k] ^= M[j].w[k];
+    return a;
+}
+// P[k] = T^(2^k), k = 0..63
+const std::vector<Mat128> &xs_powers()
+{
+    static const std::vector<Mat128> P = [] {
+        std::vector<Mat128> p(64);
+        for (int j = 0; j < 128; ++j) {
+            Bits128 e{{0, 0, 0, 0}};
+            e.w[j >> 5] = 1u << (j & 31);
+            p[0][j] = xs_step(e);
+        }
+        for (int k = 1; k < 64; ++k)
+            for (int j = 0; j < 128; ++j) p[k][j] = gf2_matvec(p[k - 1], p[k - 1][j]);
+        return p;
+    }();
+    return P;
+}
+
 }  // namespace
 
 struct htm_forward {
@@ -126,6 +167,14 @@ struct htm_chains {
     bool persist = true;                       // k_mcmc (master + resident full-evaluation workers) vs k_step + k_full
     ChainsDev dev_np{};                        // view for the non-persistent kernels (partial sums per k_full tile)
     uint32_t init_state[4] = {0, 0, 0, 0};     // mod_random state at stream position 0
+    // in-kernel exchange of the swap records (persistent lock-step): this rank's inbox, the peers' inboxes as mapped here
+    unsigned long long *d_inbox = nullptr;
+    size_t inbox_bytes = 0;
+    std::vector<void *> peer_maps;             // hipIpcOpenMemHandle mappings to close
+    unsigned long long **d_outbox = nullptr;
+    bool xchg_ready = false;
+    u32x4 *d_jump = nullptr;                   // [kJumpLevels][128] columns of T^(64 * 2^b) (k_rawgen)
+    int gen_par = 0;                           // which half of StreamDev::gen holds the current generator state
     double th[4] = {0, 0, 0, 0};
 };
 
@@ -193,7 +242,9 @@ int stream_produce(htm_chains *hc, long long n)
     if (n > room) n = room / 64 * 64;
     if (n <= 0) return HTM_OK;
     hipStream_t st = hc->side;
-    hipLaunchKernelGGL(k_rawgen, dim3(1), dim3(64), 0, st, sd, hc->n_raw, (int)n);
+    hipLaunchKernelGGL(k_rawgen, dim3((unsigned)((n + 4095) / 4096)), dim3(64), 0, st, sd, hc->n_raw, (int)n, hc->d_jump,
+                       sd.gen + 4 * hc->gen_par, sd.gen + 4 * (hc->gen_par ^ 1));
+    hc->gen_par ^= 1;
     hc->n_raw += n;
     auto blocks = [](long long cnt) { return dim3((unsigned)((cnt + 255) / 256)); };
     long long e = hc->n_raw - 1;
@@ -600,6 +651,7 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
     if ((rc = dev_alloc(hc->pool, &d.desc, 1))) return cleanup(rc);
     HIPCHK(hipMemset(d.desc, 0, sizeof(FullDesc)));
     d.n_workers = std::max(1, std::min(240, (h->E + 7) / 8));
+    if (const char *e = getenv("HTM_MAX_WORKERS")) d.n_workers = std::max(1, std::min(d.n_workers, atoi(e)));   // GPUs shared between ranks
     if ((rc = dev_alloc(hc->pool, &d.partial, (size_t)nc * std::max(h->n_wg, d.n_workers)))) return cleanup(rc);
     if ((rc = dev_alloc(hc->pool, &d.ps, 1))) return cleanup(rc);
     HIPCHK(hipMemset(d.ps, 0, sizeof(PSync)));
@@ -670,7 +722,19 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
         if ((rc = dev_alloc(hc->pool, &sd.dec, n))) return cleanup(rc);
         if ((rc = dev_alloc(hc->pool, &sd.hop, n * kHops))) return cleanup(rc);
         if ((rc = dev_alloc(hc->pool, &sd.sw, n))) return cleanup(rc);
-        if ((rc = dev_upload(hc->pool, &sd.gen, hc->init_state, 4))) return cleanup(rc);
+        {
+            uint32_t g8[8] = {hc->init_state[0], hc->init_state[1], hc->init_state[2], hc->init_state[3], 0, 0, 0, 0};
+            if ((rc = dev_upload(hc->pool, &sd.gen, g8, 8))) return cleanup(rc);
+            hc->gen_par = 0;
+            const std::vector<Mat128> &P = xs_powers();
+            std::vector<u32x4> jt((size_t)kJumpLevels * 128);
+            for (int b = 0; b < kJumpLevels; ++b)
+                for (int j = 0; j < 128; ++j) {
+                    const Bits128 &c = P[6 + b][j];
+                    jt[(size_t)b * 128 + j] = u32x4{c.w[0], c.w[1], c.w[2], c.w[3]};
+                }
+            if ((rc = dev_upload(hc->pool, &hc->d_jump, jt.data(), jt.size()))) return cleanup(rc);
+        }
         const long long zero = 0;
         if ((rc = dev_upload(hc->pool, &sd.hop_end, &zero, 1))) return cleanup(rc);
     }
@@ -719,12 +783,21 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
     if (hipEventCreate(&hc->ev0) != hipSuccess || hipEventCreate(&hc->ev1) != hipSuccess)
         return cleanup(fail(HTM_EHIP, "hipEventCreate failed"));
     hc->dev_np = hc->dev;                       // same state; partial sums laid out per k_full tile
-    hc->dev.n_wg = hc->dev.n_workers;           // persistent kernel: one partial per worker block
     if (hc->step_smem < 1024) hc->step_smem = 1024;
-    if (hc->step_smem > 48 * 1024) {
+    if (hc->persist) {
+        // Master and workers of a k_mcmc launch wait for each other, so every block must be RESIDENT: never ask for more
+        // worker blocks than the device can hold next to the master (a partitioned or CU-masked GPU has fewer CUs; every
+        // block carries the master's LDS size).  Workers take events round-robin, so fewer of them only take longer.
         const void *fn = h->nch == 1 ? (const void *)k_mcmc<1> : h->nch == 2 ? (const void *)k_mcmc<2> : (const void *)k_mcmc<0>;
-        HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hc->step_smem));
+        if (hc->step_smem > 48 * 1024) HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hc->step_smem));
+        int per_cu = 0, n_cu = 0;
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 512, hc->step_smem));
+        HIPCHK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
+        const long room = (long)per_cu * n_cu - 1;
+        if (room < 1) hc->persist = false;      // not even one worker fits next to the master: two-kernel path
+        else hc->dev.n_workers = (int)std::min<long>(hc->dev.n_workers, room);
     }
+    hc->dev.n_wg = hc->dev.n_workers;           // persistent kernel: one partial per worker block
     // first stretch of the random stream (synchronous)
     if ((rc = stream_produce(hc, 1 << 16))) return cleanup(rc);
     HIPCHK(hipStreamSynchronize(hc->side));
@@ -742,6 +815,8 @@ int htm_chains_destroy(htm_chains *hc)
     if (hc->side) (void)hipStreamDestroy(hc->side);
     if (hc->gexec) (void)hipGraphExecDestroy(hc->gexec);
     if (hc->graph) (void)hipGraphDestroy(hc->graph);
+    for (void *p : hc->peer_maps) (void)hipIpcCloseMemHandle(p);
+    if (hc->d_inbox) (void)hipFree(hc->d_inbox);
     for (void *p : hc->pool) (void)hipFree(p);
     if (hc->h_gath_pinned) (void)hipHostFree(hc->h_gath_pinned);
     if (hc->ev_wd) (void)hipEventDestroy(hc->ev_wd);
@@ -800,6 +875,8 @@ static int ctrl_error(const htm_chains *hc)
     case -6: return fail(HTM_EDESYNC, "swap records of the ranks carry different iteration numbers");
     case -8: return fail(HTM_ESTATE, "persistent workers did not answer within 5 s (iteration %d)", hc->h_ctrl.iter_done + 1);
     case -7: return fail(HTM_ESTATE, "random stream underrun in lock-step mode (iteration %d)", hc->h_ctrl.iter_done + 1);
+    case -10: return fail(HTM_ESTATE, "swap records of the other ranks did not arrive within 20 s (iteration %d)", hc->h_ctrl.iter_done + 1);
+    case -11: return fail(HTM_ESTATE, "another rank reported a failure (iteration %d)", hc->h_ctrl.iter_done + 1);
     default: return fail(HTM_ESTATE, "device error flag %d", hc->h_ctrl.err);
     }
 }
@@ -963,7 +1040,12 @@ int htm_chains_profile(htm_chains *hc, int n_iter, double *step_us, int *step_la
     HIPCHK(hipMemcpyAsync(&hc->dev.ctrl->iter_target, &hc->h_target, sizeof(int), hipMemcpyHostToDevice, h->stream));
     const long long f0 = hc->h_ctrl.n_full_evals, p0 = hc->h_ctrl.n_partial_evals;
     constexpr int B = 64;                       // launch pairs between host checks
-    std::vector<hipEvent_t> ev(3 * B);
+    struct Events {             // destroyed on every return path
+        std::vector<hipEvent_t> v;
+        ~Events() { for (hipEvent_t e : v) if (e) (void)hipEventDestroy(e); }
+    } evs;
+    evs.v.assign(3 * B, nullptr);
+    std::vector<hipEvent_t> &ev = evs.v;
     for (auto &e : ev) HIPCHK(hipEventCreate(&e));
     const FullJob jb = chain_full_job(hc);
     double s_us = 0.0, f_us = 0.0;
@@ -989,7 +1071,6 @@ int htm_chains_profile(htm_chains *hc, int n_iter, double *step_us, int *step_la
         }
         if (hc->h_ctrl.stop && (rc = drain_records(hc))) return rc;
     }
-    for (auto &e : ev) (void)hipEventDestroy(e);
     if (step_us) *step_us = s_us;
     if (step_launches) *step_launches = s_n;
     if (full_us) *full_us = f_us;
@@ -1036,6 +1117,11 @@ int htm_chains_run_lockstep(htm_chains *hc, int n_iter, htm_allgather_fn allgath
     // records a rank may hold on the device between drains: n_chains per iteration at most
     const int drain_every = std::max(1, std::min(hc->dev.cap_lik, hc->dev.cap_smp) / (2 * hc->dev.n_chains) - 2);
     int k = 0, since_drain = 0, rc;
+    // stats of this call (htm_chains_last_run_stats): evaluations counted on the device, HIP events on the kernels' stream
+    if ((rc = read_ctrl(hc))) return rc;
+    hc->run_full0 = hc->h_ctrl.n_full_evals; hc->run_part0 = hc->h_ctrl.n_partial_evals;
+    hc->last_graph_launches = 0;
+    HIPCHK(hipEventRecord(hc->ev0, h->stream));
     for (; k < n_iter; ++k) {
         rc = htm_chains_step_begin(hc);
         if (rc) return rc;
@@ -1045,7 +1131,129 @@ int htm_chains_run_lockstep(htm_chains *hc, int n_iter, htm_allgather_fn allgath
         if (++since_drain >= drain_every) { if ((rc = htm_chains_drain(hc))) return rc; since_drain = 0; }
         else if ((k & 511) == 511 && (rc = bounded_stream_sync(hc, "lock-step loop"))) return rc;
     }
+    hc->last_graph_launches = n_iter;
+    HIPCHK(hipEventRecord(hc->ev1, h->stream));
+    if ((rc = read_ctrl(hc))) return rc;          // flushes the last swap, waits for the stream
+    if ((rc = ctrl_error(hc))) return rc;
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, hc->ev0, hc->ev1));
+    hc->last_device_us = 1000.0 * ms;
+    hc->last_full = hc->h_ctrl.n_full_evals - hc->run_full0;
+    hc->last_part = hc->h_ctrl.n_partial_evals - hc->run_part0;
     return HTM_OK;
+}
+
+// ---- persistent lock-step: swap records exchanged inside the launch (exchange_records in htm_step.hpp) --------
+static int xchg_alloc(htm_chains *hc)
+{
+    if (hc->d_inbox) return HTM_OK;
+    ChainsDev &d = hc->dev;
+    d.xg = 2 * (4 + 2 * d.n_chains) + 2;
+    hc->inbox_bytes = 2 * (size_t)d.n_procs * d.xg * sizeof(unsigned long long);
+    void *p = nullptr;
+    // fine-grained: peers write it over xGMI while this rank's kernel polls it (system-scope accesses, no L2 copy)
+    hipError_t e = hipExtMallocWithFlags(&p, hc->inbox_bytes, hipDeviceMallocFinegrained);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        e = hipExtMallocWithFlags(&p, hc->inbox_bytes, hipDeviceMallocUncached);
+    }
+    if (e != hipSuccess) { (void)hipGetLastError(); HIPCHK(hipMalloc(&p, hc->inbox_bytes)); }
+    HIPCHK(hipMemset(p, 0, hc->inbox_bytes));
+    hc->d_inbox = static_cast<unsigned long long *>(p);
+    d.inbox = hc->d_inbox;
+    return HTM_OK;
+}
+
+int htm_chains_xchg_handle(htm_chains *hc, void *handle, size_t handle_bytes)
+{
+    if (!hc || !handle) return fail(HTM_EINVAL, "NULL argument");
+    if (handle_bytes < sizeof(hipIpcMemHandle_t)) return fail(HTM_EINVAL, "handle buffer too small (%zu < %zu)", handle_bytes, sizeof(hipIpcMemHandle_t));
+    HIPCHK(hipSetDevice(hc->fwd->device));
+    int rc = xchg_alloc(hc);
+    if (rc) return rc;
+    hipIpcMemHandle_t h;
+    HIPCHK(hipIpcGetMemHandle(&h, hc->d_inbox));
+    std::memset(handle, 0, handle_bytes);
+    std::memcpy(handle, &h, sizeof(h));
+    return HTM_OK;
+}
+
+int htm_chains_xchg_connect(htm_chains *hc, const void *handles, size_t handle_bytes)
+{
+    if (!hc) return fail(HTM_EINVAL, "NULL handle");
+    const ChainsDev &d0 = hc->dev;
+    if (d0.n_procs > 1 && (!handles || handle_bytes < sizeof(hipIpcMemHandle_t)))
+        return fail(HTM_EINVAL, "handles of all %d ranks are needed", d0.n_procs);
+    if (!hc->persist) return fail(HTM_ESTATE, "the in-kernel exchange needs the persistent kernel (HTM_PERSIST=0 is set)");
+    if ((size_t)d0.n_procs * (4 + 2 * d0.n_chains) > (size_t)kGathStage)
+        return fail(HTM_EINVAL, "%d ranks x %d chains: the gathered records do not fit the kernel's staging area", d0.n_procs, d0.n_chains);
+    HIPCHK(hipSetDevice(hc->fwd->device));
+    int rc = xchg_alloc(hc);
+    if (rc) return rc;
+    if (hc->xchg_ready) return HTM_OK;
+    std::vector<unsigned long long *> ptr(d0.n_procs, nullptr);
+    for (int q = 0; q < d0.n_procs; ++q) {
+        if (q == d0.rank) { ptr[q] = hc->d_inbox; continue; }
+        hipIpcMemHandle_t h;
+        std::memcpy(&h, static_cast<const char *>(handles) + (size_t)q * handle_bytes, sizeof(h));
+        void *p = nullptr;
+        const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            for (void *m : hc->peer_maps) (void)hipIpcCloseMemHandle(m);
+            hc->peer_maps.clear();
+            return fail(HTM_EHIP, "hipIpcOpenMemHandle of rank %d's inbox failed: %s", q, hipGetErrorString(e));
+        }
+        hc->peer_maps.push_back(p);
+        ptr[q] = static_cast<unsigned long long *>(p);
+    }
+    if ((rc = dev_upload(hc->pool, &hc->d_outbox, ptr.data(), ptr.size()))) return rc;
+    hc->dev.outbox = hc->d_outbox;
+    hc->xchg_ready = true;
+    return HTM_OK;
+}
+
+// n_iter lock-step iterations with the exchange inside the kernel: one k_mcmc launch runs until the target, or until
+// some rank asks everybody to stop (its record buffers or its produced random stream are nearly used up); then every
+// rank drains / refills and launches again.  All ranks leave a launch after the same iteration.
+int htm_chains_run_lockstep_direct(htm_chains *hc, int n_iter)
+{
+    if (!hc || n_iter < 0) return fail(HTM_EINVAL, "bad argument");
+    if (!hc->xchg_ready) return fail(HTM_ESTATE, "htm_chains_xchg_connect has not been called");
+    htm_forward *h = hc->fwd;
+    HIPCHK(hipSetDevice(h->device));
+    int rc = read_ctrl(hc);
+    if (rc) return rc;
+    if ((rc = ctrl_error(hc))) return rc;
+    if (hc->h_ctrl.stage != ST_IDLE) return fail(HTM_ESTATE, "an iteration is in flight");
+    hc->h_target = hc->h_ctrl.iter_done + n_iter;
+    hc->run_full0 = hc->h_ctrl.n_full_evals; hc->run_part0 = hc->h_ctrl.n_partial_evals;
+    hc->last_graph_launches = 0;
+    HIPCHK(hipEventRecord(hc->ev0, h->stream));
+    while (hc->h_ctrl.iter_done < hc->h_target) {
+        // the launch reads the produced stream's extent once, at its start: have a good stretch ready
+        long long ahead = hc->n_hop - hc->h_ctrl.spos;
+        if (ahead < hc->cap / 2 && (rc = stream_produce(hc, std::min<long long>(hc->cap / 2 - ahead + 4096, 1 << 18)))) return rc;
+        HIPCHK(hipStreamWaitEvent(h->stream, hc->ev_side, 0));      // (the producer takes ~0.1 ms per 2^18 positions)
+        const int before = hc->h_ctrl.iter_done;
+        if ((rc = launch_mcmc(hc, MODE_LOCKRUN, hc->h_target, nullptr))) return rc;
+        hc->last_graph_launches += 1;
+        ahead = hc->n_hop - hc->h_ctrl.spos;        // top up while the launch runs (for the next one)
+        if (ahead < hc->cap / 2 && (rc = stream_produce(hc, std::min<long long>(hc->cap / 2 - ahead + 4096, 1 << 18)))) return rc;
+        if ((rc = read_ctrl(hc))) return rc;
+        if ((rc = ctrl_error(hc))) return rc;
+        if (hc->h_ctrl.stop) { if ((rc = drain_records(hc))) return rc; }
+        else if (hc->h_ctrl.iter_done == before && hc->h_ctrl.iter_done < hc->h_target)
+            return fail(HTM_ESTATE, "lock-step launch made no progress at iteration %d", before);
+    }
+    HIPCHK(hipEventRecord(hc->ev1, h->stream));
+    HIPCHK(hipEventSynchronize(hc->ev1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, hc->ev0, hc->ev1));
+    hc->last_device_us = 1000.0 * ms;
+    hc->last_full = hc->h_ctrl.n_full_evals - hc->run_full0;
+    hc->last_part = hc->h_ctrl.n_partial_evals - hc->run_part0;
+    return drain_records(hc);
 }
 
 int htm_chains_swap_record(htm_chains *hc, void **d_record, size_t *record_bytes)
@@ -1200,6 +1408,7 @@ int htm_chains_checkpoint_load(htm_chains *hc, const void *blob, size_t bytes)
     // the random stream restarts at the saved generator state: position 0 of a fresh stream
     for (int k = 0; k < 4; ++k) hc->init_state[k] = h.rng_state[k];
     HIPCHK(hipMemcpy(hc->dev.stream.gen, hc->init_state, 4 * sizeof(uint32_t), hipMemcpyHostToDevice));
+    hc->gen_par = 0;
     const long long zero = 0;
     HIPCHK(hipMemcpy(hc->dev.stream.hop_end, &zero, sizeof(zero), hipMemcpyHostToDevice));
     hc->n_raw = hc->n_tr = hc->n_rec = hc->n_hop = 0;
@@ -1212,6 +1421,14 @@ int htm_chains_checkpoint_load(htm_chains *hc, const void *blob, size_t bytes)
     hc->h_target = h.iter_done;
     hc->pending_gathered = nullptr;
     HIPCHK(hipMemcpy(hc->dev.ctrl, &c, sizeof(Ctrl), hipMemcpyHostToDevice));
+    // hand-off buffers of the persistent kernel: tags are functions of the job counter and of iteration | chain, which
+    // a roll-back repeats -- nothing an earlier run left there may match
+    {
+        const ChainsDev &d = hc->dev;
+        HIPCHK(hipMemset(d.slots, 0, (size_t)d.slot_rep * d.slot_stride * sizeof(unsigned long long)));
+        HIPCHK(hipMemset(d.pgran, 0, (size_t)d.n_chains * d.n_workers * d.pgran_stride * sizeof(unsigned long long)));
+        HIPCHK(hipMemset(d.vused, 0, 2 * (size_t)d.n_chains * sizeof(unsigned long long)));
+    }
     hc->lik_iter.clear(); hc->lik_chain.clear(); hc->lik_val.clear();
     hc->smp_iter.clear(); hc->smp_chain.clear(); hc->smp_data.clear();
     if ((rc = stream_produce(hc, 1 << 16))) return rc;
@@ -1436,6 +1653,54 @@ int htm_quantiles(int device, const double *samples, long n_mod, long n_par, con
     return rc;
 }
 
+int htm_rng_jump(const uint32_t state_in[4], unsigned long long n_draws, uint32_t state_out[4])
+{
+    if (!state_in || !state_out) return fail(HTM_EINVAL, "NULL argument");
+    const std::vector<Mat128> &P = xs_powers();
+    Bits128 s{{state_in[0], state_in[1], state_in[2], state_in[3]}};
+    for (int k = 0; k < 64; ++k)
+        if ((n_draws >> k) & 1ull) s = gf2_matvec(P[k], s);
+    for (int k = 0; k < 4; ++k) state_out[k] = s.w[k];
+    return HTM_OK;
+}
+
+// the parallel generator against a serial loop on the device: n draws from `seed`, ring of `cap` positions starting at `start`
+static int selftest_rawgen(const uint32_t seed[4], int n, long long start, long long cap)
+{
+    std::vector<void *> pool;
+    auto done = [&](int code) { for (void *p : pool) (void)hipFree(p); return code; };
+    StreamDev sd{};
+    sd.mask = cap - 1;
+    uint32_t *d_ser = nullptr, *d_gen = nullptr;
+    u32x4 *d_jump = nullptr;
+    int rc;
+    if ((rc = dev_alloc(pool, &sd.raw, (size_t)cap)) || (rc = dev_alloc(pool, &d_ser, (size_t)n))) return done(rc);
+    uint32_t g16[16] = {seed[0], seed[1], seed[2], seed[3]};
+    if ((rc = dev_upload(pool, &d_gen, g16, 16))) return done(rc);
+    const std::vector<Mat128> &P = xs_powers();
+    std::vector<u32x4> jt((size_t)kJumpLevels * 128);
+    for (int b = 0; b < kJumpLevels; ++b)
+        for (int j = 0; j < 128; ++j) jt[(size_t)b * 128 + j] = u32x4{P[6 + b][j].w[0], P[6 + b][j].w[1], P[6 + b][j].w[2], P[6 + b][j].w[3]};
+    if ((rc = dev_upload(pool, &d_jump, jt.data(), jt.size()))) return done(rc);
+    hipLaunchKernelGGL(k_rawgen, dim3((unsigned)((n + 4095) / 4096)), dim3(64), 0, 0, sd, start, n, d_jump, d_gen, d_gen + 4);
+    hipLaunchKernelGGL(k_rawgen_serial, dim3(1), dim3(1), 0, 0, d_ser, n, d_gen, d_gen + 8);
+    if (hipDeviceSynchronize() != hipSuccess) return done(fail(HTM_EHIP, "rawgen selftest kernels failed"));
+    std::vector<uint32_t> ring((size_t)cap), ser((size_t)n);
+    uint32_t g[16];
+    if (hipMemcpy(ring.data(), sd.raw, cap * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(ser.data(), d_ser, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(g, d_gen, sizeof(g), hipMemcpyDeviceToHost) != hipSuccess) return done(fail(HTM_EHIP, "download failed"));
+    for (int k = 0; k < n; ++k)
+        if (ring[(size_t)((start + k) & (cap - 1))] != ser[k])
+            return done(fail(HTM_ESTATE, "parallel xorshift128 differs from the serial stream at draw %d of %d", k, n));
+    uint32_t hj[4];
+    htm_rng_jump(seed, (unsigned long long)n, hj);
+    for (int k = 0; k < 4; ++k)
+        if (g[4 + k] != g[8 + k] || g[4 + k] != hj[k])
+            return done(fail(HTM_ESTATE, "generator state after %d draws: parallel %08x serial %08x host jump %08x", n, g[4 + k], g[8 + k], hj[k]));
+    return done(HTM_OK);
+}
+
 int htm_selftest(int device)
 {
     int rc = use_device(device);
@@ -1466,6 +1731,13 @@ int htm_selftest(int device)
     if (o[13] != 0.0) return fail(HTM_ESTATE, "DPP wave_incl_scan disagrees with the serial prefix sum");
     if (std::fabs(o[12] - 0.78381228502204603) > 1e-15)
         return fail(HTM_ESTATE, "device rand_g = %.17g, want 0.78381228502204603", o[12]);
+    // jump-ahead generator == serial generator: one wave, several waves with a ragged tail, a ring wrap-around
+    const uint32_t seed0[4] = {0x4b88a366u, 0x1b11733cu, 0x097044b6u, 0x00676ea2u};   // rank-0 state
+    const uint32_t seed1[4] = {0x311ce1d7u, 0x6c840a86u, 0x28236c5fu, 0x019ea85du};   // rank 1
+    if ((rc = selftest_rawgen(seed0, 64, 0, 1 << 12))) return rc;
+    if ((rc = selftest_rawgen(seed0, 4096 * 3 + 64 * 5, 0, 1 << 14))) return rc;
+    if ((rc = selftest_rawgen(seed1, 1 << 16, (1 << 16) - 4096 - 192, 1 << 16))) return rc;
+    if ((rc = selftest_rawgen(seed1, 1 << 18, 12345 * 64, 1 << 18))) return rc;
     return HTM_OK;
 }
 

@@ -56,6 +56,7 @@ struct StepShared {
     int redo;                     // >= 0: chains >= redo repeat their pass; -1: validated; -2: aborted
     int catchup;                  // written between the barriers: the LDS window must be extended first
     int rolep_iter;               // role P has finished for this iteration (see step_body)
+    double xrec[4 + 2 * kMaxChains];   // MODE_LOCKRUN: this rank's swap record of the iteration (what goes to every rank's inbox)
     Ctrl c;
 #ifdef HTM_STAMPS
     unsigned long long stamp_acc[96];   // diagnostic cycle accounting of this launch, flushed to ChainsDev::stamps at its end
@@ -195,6 +196,19 @@ __device__ __forceinline__ double gran_f64(unsigned long long hi, unsigned long 
     return __longlong_as_double((long long)(((hi & 0xffffffffull) << 32) | (lo & 0xffffffffull)));
 }
 __device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// system-scope relaxed accesses: what another GPU (or another process on this one) writes into / reads from this
+// rank's memory over xGMI while the kernel runs (swap-record inboxes, fine-grained allocations)
+__device__ __forceinline__ void st_sys(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ unsigned long long ld_sys(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+// The master takes back whatever order chain c's slot holds (k_mcmc): granule 0 loses its tag, so the slot is no longer
+// a complete order -- a worker that has not looked yet never takes it, a worker waiting for the order's named commit
+// sees the slot change and drops it.  This is how a void order is SIGNALLED (the chain repeated a pass, or the order
+// was written for a stream position the step does not start at); nothing on the hand-off path is decided by a clock.
+__device__ __forceinline__ void void_slot(const ChainsDev &cs, int c)
+{
+    for (int r = 0; r < cs.slot_rep; ++r) st_gran(cs.slots + (size_t)r * cs.slot_stride + c * kGranPerSlot, 0u, 0u);
+}
 
 __device__ __forceinline__ bool metropolis(double L_new, double L_cur, double T, double lpr, double r,
                                            double logr)
@@ -342,7 +356,7 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
                 const double prev_xold = sh.prop[c].x_old, prev_xnew = sh.prop[c].x_new;
                 unsigned long long tk = 0;
                 if (lane == 0) {
-                    tk = pre ? (unsigned long long)sh.pre_tag[par][c] : ((atomicAdd(&sh.c.jobs_total, 1ull) + 1ull) & 0x7fffffffull);
+                    tk = pre ? (unsigned long long)sh.pre_tag[par][c] : (atomicAdd(&sh.c.jobs_total, 1ull) % 0x7ffffffeull + 1ull);   // 1 .. 2^31 - 2: never 0 (= empty slot)
                     sh.pre_p[par][c] = -1;
                     // an order of its own overwrites the workers' sums of any order role P has out for this chain (a repeated
                     // pass can bring the step back to the position such an order was written for): those are void now
@@ -524,7 +538,7 @@ __device__ __forceinline__ Valid validate(const StepShared &sh, int nc, int lane
 }
 
 // role R: record slots (hypo_tremor_mcmc.f90:270-280), step log, per-chain part of the swap record
-__device__ __forceinline__ void role_records(const ChainsDev &cs, StepShared &sh, int iter, bool lockstep, int lane)
+__device__ __forceinline__ void role_records(const ChainsDev &cs, StepShared &sh, int iter, bool lockstep, int lane, double *rec)
 {
     const int nc = cs.n_chains;
     const bool in = lane < nc;
@@ -546,7 +560,7 @@ __device__ __forceinline__ void role_records(const ChainsDev &cs, StepShared &sh
             ir[5] = pr.accepted; ir[6] = pr.need_full; ir[7] = 0;
             dr[0] = pr.x_new; dr[1] = pr.L_new; dr[2] = L_post; dr[3] = T;
         }
-        if (lockstep) { cs.swap_rec[4 + 2 * c] = T; cs.swap_rec[5 + 2 * c] = L_post; }
+        if (lockstep) { rec[4 + 2 * c] = T; rec[5 + 2 * c] = L_post; }
     }
     if (lane == 0) {
         sh.c.n_lik += __popcll(ml); sh.c.n_smp += __popcll(ms);
@@ -557,12 +571,12 @@ __device__ __forceinline__ void role_records(const ChainsDev &cs, StepShared &sh
 // role W: the temperature swap of cls_parallel.f90:121-136 + :285-302 (single rank) or the header of this
 // rank's record (lock-step).  Uniform over the wave; lane 0 writes.
 __device__ __forceinline__ void role_swap(const ChainsDev &cs, StepShared &sh, int iter, bool lockstep, int lane,
-                                          int i1, int i2, double sr, double slr)
+                                          int i1, int i2, double sr, double slr, double *rec)
 {
     if (lane != 0) return;
     sh.sw_do = 0;
     if (lockstep) {
-        cs.swap_rec[0] = (double)i1; cs.swap_rec[1] = (double)i2; cs.swap_rec[2] = sr; cs.swap_rec[3] = (double)iter;
+        rec[0] = (double)i1; rec[1] = (double)i2; rec[2] = sr; rec[3] = (double)iter;
     } else if (cs.n_procs * cs.n_chains > 1) {
         const double T1 = sh.temp[i1], T2 = sh.temp[i2];
         const double del_s = (sh.L[i2] - sh.L[i1]) * (1.0 / T1 - 1.0 / T2);
@@ -629,7 +643,7 @@ struct PreOrder {            // per lane (<-> chain)
 // evaluated on the state that memory holds when the workers get to it, before or after the step in between commits;
 // the order names that step's element and the worker of that event reports the value it saw (ChainsDev::vused).
 __device__ __forceinline__ PreOrder role_prepublish_plan(const ChainsDev &cs, StepShared &sh, const Ring &rg, int iter,
-                                                         int pos, int lane, bool allow2)
+                                                         int pos, int lane, bool allow2, bool lockstep)
 {
     PreOrder po;
     po.job = false; po.c = 0; po.tag = 0; po.w1 = 0; po.x_hi = 0; po.x_lo = 0; po.co = 0xffffffffu; po.c_hi = 0; po.c_lo = 0;
@@ -656,8 +670,15 @@ __device__ __forceinline__ PreOrder role_prepublish_plan(const ChainsDev &cs, St
     bool goodB = winA;
     if (cs.n_procs * nc > 1) {
         const int4 sw = rg.sw[pb0 & M];
-        goodB = goodB && sw.z > 0;
-        pb0 += sw.z + 1;
+        if (!lockstep) {                                  // single rank: select_pair + judge_swap both draw here
+            goodB = goodB && sw.z > 0;
+            pb0 += sw.z + 1;
+        } else if (cs.rank == 0) {                        // rank 0 draws the pair; the judge draw is rank1's (cls_parallel.f90:163)
+            goodB = goodB && sw.z > 0;
+            pb0 += sw.z + ((sw.x / nc) == 0 ? 1 : 0);
+        }
+        // other ranks draw nothing for the pair, and the judge draw only if they own chain 1 of it (1 time in n_procs):
+        // the bet is "not"; a lost bet shows as an order written for the wrong position, which is taken back (void_slot)
     }
     const int pB = hop_ahead(rg, pb0, c);
     goodB = goodB && pb0 >= pos && pB >= pb0 && pB + 8 < sh.fill && iter + 2 <= sh.c.iter_target;
@@ -699,7 +720,15 @@ __device__ __forceinline__ PreOrder role_prepublish_plan(const ChainsDev &cs, St
     po.co = pr.accepted ? (unsigned)(cgoff + c * cgnx + pr.idx) : 0xffffffffu;
     po.c_hi = (unsigned)(cb >> 32); po.c_lo = (unsigned)cb;
     po.rep = mode == 2 ? (unsigned)(o_hy + dA.y) + 1u : 0u;            // element of the step in between (+1; 0 = none)
-    if (lane < nc && stale2 && mode != 1) sh.pre_p[par1][lane] = -1;   // (a one-ahead order replaces the entry)
+    // Orders still on the books that no step will use: (a) addressed to iteration iter + 1 but written for another start
+    // position (a Rayleigh rejection shifted the stream) or around another step in between (stale2); (b) addressed to the
+    // iteration that just ended and never taken (its step started elsewhere and was a partial update).  The workers are
+    // told (void_slot) unless a new order of this chain overwrites the slot right now.
+    const bool staleA = in && sh.pre_p[par1][c] != -1 && (sh.pre_p[par1][c] != pA || stale2);
+    const bool deadB = in && sh.pre_p[par2][c] != -1;
+    if (staleA && mode != 1) sh.pre_p[par1][lane] = -1;               // (a one-ahead order replaces the entry)
+    if (deadB && mode != 2) sh.pre_p[par2][lane] = -1;
+    if ((staleA || deadB) && mode == 0 && !(haveA && in)) void_slot(cs, c);   // haveA: the slot holds a live order (written after the dead one)
     if (lane < nc && mode) {
         const int par = mode == 2 ? par2 : par1;
         sh.pre_p[par][lane] = pJ; sh.pre_tag[par][lane] = po.tag; sh.pre_mode[par][lane] = mode; sh.pre_pa[par][lane] = pA;
@@ -780,6 +809,85 @@ __device__ __forceinline__ void apply_swap(const ChainsDev &cs, StepShared &sh, 
     sh.c.stage = ST_IDLE;
 }
 
+// MODE_LOCKRUN, wave 0, after the roles of iteration `iter`: this rank's swap record goes into EVERY rank's inbox
+// (its own included) as tagged 8-byte granules {iteration : 32, payload : 32} written with system-scope stores -- over
+// xGMI into the peers' memory, no collective, no kernel boundary --, then the wave polls its own inbox until all
+// n_procs records of this iteration are complete, stages them in LDS as the doubles apply_swap reads, and lane 0
+// decides the swap exactly as every other rank does (cls_parallel.f90:118-213).  Record = the (4 + 2 n_chains) words
+// of the all-gather protocol + one control word: bit 0 = this rank asks everybody to stop after this iteration
+// (record buffers or produced random stream nearly used up: the host drains / refills and launches again), bit 1 = it
+// has failed.  Inbox parity = iter & 1: a rank can be at most one iteration ahead of the slowest one.
+constexpr int kXLoads = 8;        // granule loads per lane in flight while polling
+
+__device__ __forceinline__ void exchange_records(const ChainsDev &cs, StepShared &sh, double *s_gath, int iter, int lane,
+                                                 int wmax)
+{
+    const int nc = cs.n_chains, RW = 4 + 2 * nc, G = cs.xg, np = cs.n_procs, par = iter & 1;
+    const unsigned tag = (unsigned)iter;
+    const bool want_stop = sh.c.n_lik + 2 * nc > cs.cap_lik || sh.c.n_smp + 2 * nc > cs.cap_smp || sh.avail < sh.base + 3 * wmax;
+    const unsigned ctl = (want_stop ? 1u : 0u) | (sh.c.err ? 2u : 0u);
+    // ---- post
+    for (int g0 = 0; g0 < G; g0 += 64) {
+        const int g = g0 + lane;
+        if (g < G) {
+            const int w = g >> 1;
+            unsigned pay;
+            if (w < RW) {
+                const unsigned long long b = (unsigned long long)__double_as_longlong(sh.xrec[w]);
+                pay = (g & 1) ? (unsigned)b : (unsigned)(b >> 32);
+            } else pay = (g & 1) ? 0u : ctl;
+            const unsigned long long v = ((unsigned long long)tag << 32) | pay;
+            for (int q = 0; q < np; ++q) st_sys(ld_const(cs.outbox + q) + (size_t)(par * np + cs.rank) * G + g, v);
+        }
+    }
+    // ---- collect: rows of 64 granules, row = (rank r, chunk k of its record); kXLoads rows in flight
+    const unsigned long long *in = cs.inbox + (size_t)par * np * G;
+    unsigned *gu = reinterpret_cast<unsigned *>(s_gath);
+    const int chunks = (G + 63) >> 6, rows = np * chunks;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();       // 100 MHz
+    unsigned anyctl = 0;
+    bool dead = false;
+    for (int row0 = 0; row0 < rows && !dead; row0 += kXLoads) {
+        unsigned long long v[kXLoads];
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < kXLoads; ++j) {
+                const int row = row0 + j, r = row / chunks, k = (row - r * chunks) * 64 + lane;
+                v[j] = (unsigned long long)tag << 32;
+                if (row < rows && k < G) v[j] = ld_sys(in + (size_t)r * G + k);
+            }
+#pragma unroll
+            for (int j = 0; j < kXLoads; ++j) ok = ok && (unsigned)(v[j] >> 32) == tag;
+            if (__all(ok)) break;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000000ull) {       // 20 s: a peer is gone
+                if (lane == 0) sh.c.err = -10;
+                dead = true;
+                break;
+            }
+        }
+        if (dead) break;
+#pragma unroll
+        for (int j = 0; j < kXLoads; ++j) {
+            const int row = row0 + j, r = row / chunks, k = (row - r * chunks) * 64 + lane;
+            if (row < rows && k < G) {
+                const int w = k >> 1;
+                if (w < RW) gu[2 * (r * RW + w) + ((k & 1) ? 0 : 1)] = (unsigned)v[j];      // little-endian halves of the double
+                else if (!(k & 1)) anyctl |= (unsigned)v[j];
+            }
+        }
+    }
+    const bool stop_any = __ballot((anyctl & 1u) != 0) != 0ull, err_any = __ballot((anyctl & 2u) != 0) != 0ull;
+    if (lane == 0 && !dead) {
+        if (sh.c.err == 0 && sh.c.stage == ST_WAIT_SWAP) {
+            apply_swap(cs, sh, s_gath);                         // iteration done; rank1 consumed its judge_swap draw
+            sh.base = (int)(sh.c.spos - sh.origin);
+        }
+        if (stop_any && sh.c.stop == 0) sh.c.stop = 3;          // everybody leaves after this iteration
+        if (err_any && sh.c.err == 0) sh.c.err = -11;           // a peer reported a failure
+    }
+}
+
 #ifdef HTM_STAMPS
 #define STAMP(k)                                                                                   \
     do {                                                                                           \
@@ -817,7 +925,7 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
     double *s_sy = s_sx + f.S;
     double *s_sz = s_sy + f.S;
     double *s_gath = s_sz + f.S;                   // [kGathStage] the all-gathered swap records, staged
-    rg.mir_n = (PERSIST && mode == MODE_RUN) ? cs.mirror_n : 0;
+    rg.mir_n = (PERSIST && (mode == MODE_RUN || mode == MODE_LOCKRUN)) ? cs.mirror_n : 0;
     rg.mx = s_gath + kGathStage;
     rg.mstep = rg.mx + rg.mir_n;
     rg.mir_steps = cs.mirror_steps != 0;
@@ -827,6 +935,11 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
     const int NW = blockDim.x >> 6;                // every wave is a chain wave
     const int nc = cs.n_chains;
     const bool lockstep = (mode != MODE_RUN);
+    // MODE_LOCKRUN: lock-step with the swap records exchanged inside the launch (exchange_records) -- the kernel stays
+    // resident over the iterations, so the orders of role P and the LDS state carry over as in the single-rank loop
+    const bool lockrun = PERSIST && mode == MODE_LOCKRUN;
+    const bool rolep_on = PERSIST && (!lockstep || lockrun);
+    double *rec = lockrun ? sh.xrec : cs.swap_rec;
     // helper roles between the barriers: validation+bookkeeping on wave 0, records and swap on other waves
     const int wave_R = NW > 1 ? 1 : 0, wave_W = NW > 2 ? 2 : 0;
     const int wave_P = NW > 4 ? 4 : NW - 1;        // extends the LDS window during the roles phase (no role of its own if NW > 4)
@@ -943,8 +1056,8 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
                 // On wave_Q, before its own chain step (an older wave: it has the slack; or a wave without a chain), from the validated base of THIS
                 // iteration (= the iteration that just ended is iter - 1).  The other waves look at what it leaves only
                 // after their step's arithmetic (chain_pass waits on sh.rolep_iter), by when it is long done.
-                if (have_prev && !lockstep && wave == wave_Q) {
-                    role_prepublish_send(cs, role_prepublish_plan(cs, sh, rg, iter - 1, sh.base, lane, HTM_ALLOW2 && NCH > 0), launch);
+                if (have_prev && rolep_on && wave == wave_Q) {
+                    role_prepublish_send(cs, role_prepublish_plan(cs, sh, rg, iter - 1, sh.base, lane, HTM_ALLOW2 && NCH > 0, lockstep), launch);
                     if (lane == 0) __hip_atomic_store(&sh.rolep_iter, iter, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
@@ -966,7 +1079,8 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
                             undo_chain(cs, sh, rg, c);
                             sh.redone[c] = 1;
                             // workers that get to an order of this chain late may have read the step just taken back: whatever
-                            // role P has out for this chain is void
+                            // role P has out for this chain is void -- and the workers are told so
+                            if constexpr (PERSIST) { if (sh.pre_p[0][c] != -1 || sh.pre_p[1][c] != -1) void_slot(cs, c); }
                             sh.pre_p[0][c] = -1; sh.pre_p[1][c] = -1;
                         }
                         p = sh.start_fix[c];                                // corrected by the validation
@@ -974,7 +1088,7 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
                         p = c == 0 ? sh.base : sh.base + rg.hop[(sh.base & rg.mask) * kHops + c - 1];
                     }
                     p = chain_pass<NCH, PERSIST>(f, cs, sh, rg, s_sx, s_sy, s_sz, c, p, iter, lane, launch,
-                                                 PERSIST && have_prev && !lockstep, first);
+                                                 have_prev && rolep_on, first);
                     have_p = true;
                     if (NW > 1 && c + NW < nc) p += rg.hop[(p & rg.mask) * kHops + NW - 2];   // skip NW-1 steps
                 }
@@ -1045,8 +1159,8 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
                             }
                         }
                     }
-                    if (wave == wave_R && done) role_records(cs, sh, iter, lockstep, lane);
-                    if (wave == wave_W && done) role_swap(cs, sh, iter, lockstep, lane, i1, i2, sr, slr);
+                    if (wave == wave_R && done) role_records(cs, sh, iter, lockstep, lane, rec);
+                    if (wave == wave_W && done) role_swap(cs, sh, iter, lockstep, lane, i1, i2, sr, slr, rec);
                 }
                 __syncthreads();                                            // ---- barrier B
                 STAMP(3);   // validation + plan + records + swap
@@ -1072,8 +1186,8 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
             }
         } else {
             // the iteration that waited for k_full: only its end is left (decisions were taken in P0)
-            if (wave == wave_R) role_records(cs, sh, iter, lockstep, lane);
-            if (wave == wave_W) role_swap(cs, sh, iter, lockstep, lane, sh.c.swap_i1, sh.c.swap_i2, sh.c.swap_r, sh.c.swap_logr);
+            if (wave == wave_R) role_records(cs, sh, iter, lockstep, lane, rec);
+            if (wave == wave_W) role_swap(cs, sh, iter, lockstep, lane, sh.c.swap_i1, sh.c.swap_i2, sh.c.swap_r, sh.c.swap_logr, rec);
             if (tid == 0) {
                 if (lockstep) sh.c.stage = ST_WAIT_SWAP;
                 else { sh.c.iter_done = iter; sh.c.stage = ST_IDLE; }
@@ -1082,10 +1196,15 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
             resume = false;
         }
         // ---------------- after the barrier: swap + records of the chains this wave owns ---------------
+        if (lockrun) {
+            // the exchange first (it is what the other ranks wait for), the records of wave 0's chains after it
+            if (wave == 0) exchange_records(cs, sh, s_gath, iter, lane, wmax);
+        }
         for (int c = wave; c < nc; c += NW) post_chain(cs, sh, c, iter, lane);
+        if (lockrun) __syncthreads();                             // ---- barrier C: temperatures and base of the next iteration
         have_prev = true;
         STAMP(4);   // post
-        if (lockstep) break;
+        if (lockstep && !lockrun) break;
     }
     __syncthreads();
     for (int k = tid; k < 7 * nc; k += blockDim.x) {          // flush this launch's counters
@@ -1213,27 +1332,27 @@ __device__ __forceinline__ void worker_body(const FwdDev &f, const ChainsDev &cs
                     int r = spin ? check(b) : 0;
                     if (r == 1 && s_job[3] != 0xffffffffu) {
                         // The order was sent ahead of the chain's latest commit: wait until that store is what memory returns
-                        // (the other waves read the chain's state only after this wave has seen it).  An order can be void by
-                        // the time it is looked at -- the chain repeated a pass and wrote the element again -- and then the
-                        // value never shows: the wait ends as soon as the slot holds a newer order, or after 200 us, and the
-                        // order is dropped (had it been a live one, the master's own bounded wait reports it).
+                        // (the other waves read the chain's state only after this wave has seen it).  If the master takes the
+                        // order back meanwhile -- the chain repeated a pass and rewrote the element, so the value never shows --
+                        // it says so by rewriting the slot (void_slot, or a newer order): the order is dropped and the worker
+                        // keeps polling.  No clock decides here; the bounds below are fail-stops (master gone, 30 s).
                         const unsigned long long want = ((unsigned long long)s_job[4] << 32) | s_job[5];
-                        const unsigned long long t0c = __builtin_amdgcn_s_memrealtime();
-                        for (;;) {
-                            // the clock is read BEFORE the value: a wave that was switched out in between (processes sharing
-                            // the GPU) finds the value when it comes back instead of an expired clock
-                            const unsigned long long t_now = __builtin_amdgcn_s_memrealtime();
+                        for (unsigned spins = 0;; ++spins) {
                             if ((unsigned long long)__double_as_longlong(ld_agent(cs.xall + s_job[3])) == want) break;
                             const unsigned now_tag = (unsigned)(ld_agent(slots + (size_t)chain * kGranPerSlot) >> 32);
-                            if (now_tag != tag || t_now - t0c > 20000ull) {
+                            if (now_tag != tag) {
 #ifdef HTM_STAMPS
                                 if (lane == 0 && w == 0 && cs.stamps) {
                                     cs.stamps[112] += 1; cs.stamps[113] = chain; cs.stamps[114] = tag; cs.stamps[115] = s_job[3]; cs.stamps[116] = want;
                                     cs.stamps[117] = (unsigned long long)__double_as_longlong(ld_agent(cs.xall + s_job[3])); cs.stamps[118] = s_job[0]; cs.stamps[119] = now_tag;
                                 }
 #endif
-                                r = 0; tag = 0; chain = -1;      // dropped: keep polling
+                                r = 0; tag = 0; chain = -1;      // taken back: keep polling
                                 break;
+                            }
+                            if ((spins & 63u) == 63u) {          // fail-stops only
+                                if (ld_agent(&cs.ps->quit) > launch) { r = -1; tag = 0; chain = -1; break; }
+                                if (__builtin_amdgcn_s_memrealtime() - t0 > 3000000000ull) { r = -1; tag = 0; chain = -1; break; }
                             }
                             __builtin_amdgcn_s_sleep(1);
                         }

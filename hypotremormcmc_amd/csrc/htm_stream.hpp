@@ -4,8 +4,8 @@
 // that depends on chain state only through HOW MANY draws each chain step takes.  The values themselves,
 // and everything derived from a value at a given stream position, are independent of the chains.  So the
 // stream is produced ahead of time:
-//   k_rawgen       one wavefront, the recurrence itself on the scalar ALU (serial by nature), 64 draws per
-//                  coalesced store
+//   k_rawgen       the recurrence itself, in parallel: xorshift128 is GF(2)-linear, so every lane jumps to the start
+//                  of its own 64-draw segment with precomputed powers of the transition matrix
 //   k_stream_tr    per position: rand_u, log(rand_u), the Box-Muller value that starts there
 //   k_stream_rec   per position: the chain step that would START there, decoded (proposal type, element,
 //                  event, draws consumed) with its Gaussian and its Metropolis draw
@@ -20,21 +20,65 @@ constexpr int kHops = 8;          // hop tables cover 1..8 chain steps (k_step h
 constexpr int kRecLag = 16;       // a record at p reads transforms up to p+5, a swap plan up to p+13
 constexpr int kHopLag = 6 * kHops;
 
-__global__ __launch_bounds__(64) void k_rawgen(StreamDev sd, long long start, int n)
+// ---- the recurrence itself, in parallel by jump-ahead ---------------------------------------------------------
+// xorshift128 (mod_random.f90:63-71) is linear over GF(2): one step is state' = T * state for a fixed 128 x 128 bit
+// matrix T (state = x | y << 32 | z << 64 | w << 96).  The host precomputes J[b] = T^(64 * 2^b) (htm_jump_table),
+// stored as 128 columns of 4 words.  Segment g of 64 draws starts from  T^(64 g) * s0 = prod_{bits b of g} J[b] * s0,
+// so every LANE can start its own segment: a wave produces 64 segments = 4 096 consecutive draws, transposes them
+// through LDS and writes them with coalesced 256-B stores.  Bit-identical to the serial stream by construction.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));      // one matrix column
+constexpr int kJumpLevels = 20;       // segments per call < 2^20 (ring capacity <= 2^24 positions)
+
+__device__ __forceinline__ void jump_apply(uint32_t (&s)[4], const u32x4 *J)
 {
-    const int lane = threadIdx.x;
-    uint32_t x = __builtin_amdgcn_readfirstlane(sd.gen[0]), y = __builtin_amdgcn_readfirstlane(sd.gen[1]);
-    uint32_t z = __builtin_amdgcn_readfirstlane(sd.gen[2]), w = __builtin_amdgcn_readfirstlane(sd.gen[3]);
-    for (int blk = 0; blk < n; blk += 64) {
-        uint32_t mine = 0;
-#pragma unroll 16
-        for (int k = 0; k < 64; ++k) {
-            const uint32_t r = xs128_next(x, y, z, w);
-            mine = (lane == k) ? r : mine;
+    uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+    for (int wd = 0; wd < 4; ++wd) {
+        const uint32_t v = s[wd];
+#pragma unroll 8
+        for (int bit = 0; bit < 32; ++bit) {
+            const u32x4 col = ld_const(J + wd * 32 + bit);           // wave-uniform: scalar load
+            const uint32_t m = 0u - ((v >> bit) & 1u);
+            a0 ^= col.x & m; a1 ^= col.y & m; a2 ^= col.z & m; a3 ^= col.w & m;
         }
-        sd.raw[(start + blk + lane) & sd.mask] = mine;
     }
-    if (lane == 0) { sd.gen[0] = x; sd.gen[1] = y; sd.gen[2] = z; sd.gen[3] = w; }
+    s[0] = a0; s[1] = a1; s[2] = a2; s[3] = a3;
+}
+
+// grid = ceil(n / 4096) workgroups of ONE wave; n a multiple of 64.  gen_in: state after the last produced draw
+// (read by every wave); gen_out: the state after this call's last draw (a different buffer: no race with the readers).
+__global__ __launch_bounds__(64) void k_rawgen(StreamDev sd, long long start, int n, const u32x4 *jump,
+                                               const uint32_t *gen_in, uint32_t *gen_out)
+{
+    __shared__ uint32_t tile[64 * 65];
+    const int lane = threadIdx.x;
+    const int n_seg = n >> 6;
+    const int g = blockIdx.x * 64 + lane;                 // this lane's segment
+    uint32_t s[4] = {gen_in[0], gen_in[1], gen_in[2], gen_in[3]};
+    // bits 6.. of g are uniform over the wave (scalar branch), bits 0..5 differ by lane (predicated)
+    for (int b = 6; b < kJumpLevels; ++b)
+        if ((blockIdx.x >> (b - 6)) & 1) jump_apply(s, jump + (size_t)b * 128);
+    for (int b = 0; b < 6; ++b) {
+        uint32_t t[4] = {s[0], s[1], s[2], s[3]};
+        jump_apply(t, jump + (size_t)b * 128);
+        if ((lane >> b) & 1) { s[0] = t[0]; s[1] = t[1]; s[2] = t[2]; s[3] = t[3]; }
+    }
+    uint32_t x = s[0], y = s[1], z = s[2], w = s[3];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) tile[lane * 65 + k] = xs128_next(x, y, z, w);
+    if (g == n_seg - 1) { gen_out[0] = x; gen_out[1] = y; gen_out[2] = z; gen_out[3] = w; }
+    __syncthreads();
+    const int seg0 = blockIdx.x * 64;
+    for (int k = 0; k < 64 && seg0 + k < n_seg; ++k)
+        sd.raw[(start + (long long)(seg0 + k) * 64 + lane) & sd.mask] = tile[k * 65 + lane];
+}
+
+// the same stream drawn serially by one lane (htm_selftest compares the two)
+__global__ void k_rawgen_serial(uint32_t *out, int n, const uint32_t *gen_in, uint32_t *gen_out)
+{
+    uint32_t x = gen_in[0], y = gen_in[1], z = gen_in[2], w = gen_in[3];
+    for (int k = 0; k < n; ++k) out[k] = xs128_next(x, y, z, w);
+    gen_out[0] = x; gen_out[1] = y; gen_out[2] = z; gen_out[3] = w;
 }
 
 __global__ __launch_bounds__(256) void k_stream_tr(StreamDev sd, long long start, long long end)

@@ -12,8 +12,11 @@ module htm_c_api
   public :: htm_chains_lik_count, htm_chains_lik_read, htm_chains_sample_count, htm_chains_sample_read
   public :: htm_chains_iterations_done
   public :: htm_chains_step_begin, htm_chains_swap_record_host, htm_chains_step_end_host, htm_chains_drain
+  public :: htm_chains_xchg_handle, htm_chains_xchg_connect, htm_chains_run_lockstep_direct, HTM_XCHG_HANDLE_BYTES
   public :: htm_device_count, htm_quantiles
   public :: htm_chains_checkpoint_size, htm_chains_checkpoint_save, htm_chains_checkpoint_load
+
+  integer(c_size_t), parameter :: HTM_XCHG_HANDLE_BYTES = 64_c_size_t
 
   !> one `type model` group stacked over the chains of the rank (include/htm_hip.h: htm_model_init)
   type, bind(C) :: htm_model_init
@@ -161,6 +164,27 @@ module htm_c_api
        real(c_double), intent(in) :: gathered(*)
        integer(c_int) :: rc
      end function htm_chains_step_end_host
+     !> persistent lock-step (include/htm_hip.h): swap records exchanged inside the kernel through peer-mapped inboxes
+     function htm_chains_xchg_handle(handle, ipc_handle, handle_bytes) bind(C, name="htm_chains_xchg_handle") result(rc)
+       import :: c_int, c_ptr, c_char, c_size_t
+       type(c_ptr), value :: handle
+       character(kind=c_char), intent(out) :: ipc_handle(*)
+       integer(c_size_t), value :: handle_bytes
+       integer(c_int) :: rc
+     end function htm_chains_xchg_handle
+     function htm_chains_xchg_connect(handle, ipc_handles, handle_bytes) bind(C, name="htm_chains_xchg_connect") result(rc)
+       import :: c_int, c_ptr, c_char, c_size_t
+       type(c_ptr), value :: handle
+       character(kind=c_char), intent(in) :: ipc_handles(*)
+       integer(c_size_t), value :: handle_bytes
+       integer(c_int) :: rc
+     end function htm_chains_xchg_connect
+     function htm_chains_run_lockstep_direct(handle, n_iter) bind(C, name="htm_chains_run_lockstep_direct") result(rc)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: handle
+       integer(c_int), value :: n_iter
+       integer(c_int) :: rc
+     end function htm_chains_run_lockstep_direct
      function htm_chains_drain(handle) bind(C, name="htm_chains_drain") result(rc)
        import :: c_int, c_ptr
        type(c_ptr), value :: handle

@@ -35,6 +35,7 @@ program hypo_tremor_mcmc_hip
   integer, allocatable :: win_id(:)
   double precision, allocatable :: x_mu(:), y_mu(:)
   integer :: n_events, n_sta, n_chains, i, j, io, id, ierr, rank, n_ranks
+  logical :: direct = .false.
   integer(c_int) :: n_dev
   real(c_double), allocatable :: rec(:), gathered(:)
   double precision :: dummy
@@ -171,8 +172,43 @@ program hypo_tremor_mcmc_hip
 #ifdef HTM_MPI
   ! main loop of src/hypo_tremor_mcmc.f90:236-284 with swap_temperature (src/cls_parallel.f90:100-216) as ONE
   ! all-gather of every rank's record {pair chosen by rank 0, pending judge_swap draw, (T, L) of its chains}
+  ! Fastest transport first: persistent lock-step -- every rank's kernel writes its record straight into the other
+  ! ranks' inboxes (peer-mapped device memory, xGMI between the GPUs of a node) and never leaves the GPU.  Set-up =
+  ! one MPI_Allgather of the inboxes' IPC handles; taken only if EVERY rank could map every peer (HTM_XCHG=0: never).
+  block
+    character(kind=c_char) :: xh(HTM_XCHG_HANDLE_BYTES)
+    character(kind=c_char), allocatable :: xh_all(:)
+    character(len=8) :: env
+    integer :: ok_mine, ok_all, elen, estat
+    allocate(xh_all(HTM_XCHG_HANDLE_BYTES * n_ranks))
+    xh = c_null_char
+    ok_mine = 1
+    call get_environment_variable("HTM_XCHG", env, elen, estat)
+    if (estat == 0 .and. elen > 0) then
+       if (env(1:1) == "0") ok_mine = 0
+    end if
+    if (ok_mine == 1) then
+       if (htm_chains_xchg_handle(chains, xh, HTM_XCHG_HANDLE_BYTES) /= 0) ok_mine = 0
+    end if
+    call mpi_allgather(xh, int(HTM_XCHG_HANDLE_BYTES), MPI_BYTE, xh_all, int(HTM_XCHG_HANDLE_BYTES), MPI_BYTE, &
+         & MPI_COMM_WORLD, ierr)
+    if (ok_mine == 1) then
+       if (htm_chains_xchg_connect(chains, xh_all, HTM_XCHG_HANDLE_BYTES) /= 0) ok_mine = 0
+    end if
+    call mpi_allreduce(ok_mine, ok_all, 1, MPI_INTEGER, MPI_MIN, MPI_COMM_WORLD, ierr)
+    direct = ok_all == 1
+  end block
+  if (direct) then
+     if (rank == 0) print *, "swap exchange: in-kernel (peer-mapped inboxes)"
+     call mpi_barrier(MPI_COMM_WORLD, ierr)
+     do i = 0, para%n_iter - 1, 1000
+        call check(htm_chains_run_lockstep_direct(chains, int(min(1000, para%n_iter - i), c_int)), &
+             & "htm_chains_run_lockstep_direct")
+        if (rank == 0) call summary(min(i + 1000, para%n_iter))
+     end do
+  end if
   allocate(rec(4 + 2 * n_chains), gathered((4 + 2 * n_chains) * n_ranks))
-  do i = 1, para%n_iter
+  do i = 1, merge(0, para%n_iter, direct)      ! compatibility path: records staged through host memory + MPI_Allgather
      call check(htm_chains_step_begin(chains), "htm_chains_step_begin")
      call check(htm_chains_swap_record_host(chains, rec), "htm_chains_swap_record_host")
      call mpi_allgather(rec, size(rec), MPI_DOUBLE_PRECISION, gathered, size(rec), MPI_DOUBLE_PRECISION, &

@@ -3,9 +3,11 @@
 
 One process per GPU.  The reference exchanges a 4-int broadcast plus two 2-double messages per iteration
 over MPI; here every rank contributes ONE small record {pair chosen by rank 0, its pending judge_swap
-draw, (T, L) of all its chains} to a single all-gather per iteration (RCCL over xGMI via
-torch.distributed's "nccl" backend, gloo on CPU for tests) and every rank evaluates the identical swap
-decision from the gathered records on its device.
+draw, (T, L) of all its chains} per iteration and every rank evaluates the identical swap decision from the
+n_procs records on its device.  Transports, fastest first: (1) persistent lock-step -- the kernels write the
+records straight into each other's memory (peer-mapped inboxes over xGMI, set up with one all-gather of IPC
+handles) and never leave the GPU; (2) one RCCL all-gather per iteration enqueued from C (torch.distributed's
+"nccl" backend = RCCL over xGMI); (3) torch.distributed calls per iteration (gloo on CPU for tests).
 
 `LocalWorld` runs all ranks of a job inside one process on one device (record exchange = device copies);
 it exists for parity tests on a single GPU.
@@ -82,7 +84,38 @@ class TorchWorld:
         self.gathered = torch.zeros(self.world * self.rec.numel(), dtype=torch.float64, device=self.rec.device)
         # records a rank may hold between drains: n_chains per iteration at most
         self.drain_every = 4096
-        self.fast = self._try_direct_rccl()
+        self.direct = self._try_direct_exchange()
+        self.fast = None if self.direct else self._try_direct_rccl()
+
+    def _try_direct_exchange(self):
+        """Persistent lock-step (htm_chains_run_lockstep_direct): every rank's kernel writes its swap record straight
+        into the other ranks' inboxes (peer-mapped device memory, xGMI) and stays resident over the iterations.  Set-up
+        = one all-gather of the inboxes' IPC handles over this group (RCCL, or gloo in the CPU-launched tests); used
+        only if EVERY rank could map every peer, else the per-iteration all-gather paths below take over.
+        HTM_XCHG=0 disables it."""
+        import os
+
+        if os.environ.get("HTM_XCHG", "1") == "0" or not isinstance(self.r, DeviceRank):
+            return False
+        torch, dist, cs = self.torch, self.dist, self.r.cs
+        dev = self.gathered.device if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
+        nb = cs.XCHG_HANDLE_BYTES
+        ok, mine = 1, bytes(nb)
+        try:
+            mine = cs.xchg_handle()
+        except Exception:
+            ok = 0
+        t_in = torch.tensor(list(mine), dtype=torch.uint8, device=dev)
+        t_out = torch.empty(self.world * nb, dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(t_out, t_in, group=self.group)
+        if ok:
+            try:
+                cs.xchg_connect(bytes(t_out.cpu().numpy().tobytes()) if self.world > 1 else None)
+            except Exception:
+                ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(int(flag.item()))
 
     def _try_direct_rccl(self):
         """(function pointer, communicator) of RCCL's ncclAllGather on torch's own communicator, so that the
@@ -121,6 +154,10 @@ class TorchWorld:
         self.r.step_end(self.gathered)
 
     def run(self, n_iter: int):
+        if self.direct:
+            self.dist.barrier(group=self.group)      # the ranks' kernels start together (the exchange waits 20 s for a peer)
+            self.r.cs.run_lockstep_direct(n_iter)
+            return
         if self.fast is not None:
             self.r.cs.run_lockstep(n_iter, self.fast[0], self.fast[1], self.gathered.data_ptr())
             self.r.drain()

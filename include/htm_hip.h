@@ -175,6 +175,21 @@ int htm_chains_run_lockstep(htm_chains *hc, int n_iter, htm_allgather_fn allgath
  * compatibility path -- the RCCL path above keeps everything on the device. */
 int htm_chains_swap_record_host(htm_chains *hc, double *record);
 int htm_chains_step_end_host(htm_chains *hc, const double *gathered_records);
+/* Persistent lock-step: the swap exchange of src/cls_parallel.f90:100-216 INSIDE the kernel.  Each rank owns an
+ * inbox in its GPU's memory; a rank's kernel writes its swap record straight into every rank's inbox (peer-mapped
+ * memory over xGMI, tagged 8-byte granules, system-scope stores) and polls its own -- no kernel boundary and no
+ * collective per iteration, so the kernel stays resident over all iterations like the single-rank loop.
+ *   xchg_handle   allocates the inbox and returns its IPC handle (HTM_XCHG_HANDLE_BYTES bytes);
+ *   xchg_connect  takes the handles of ALL ranks in rank order (exchanged by the caller: MPI_Allgather, or
+ *                 torch.distributed's all-gather over RCCL), `handle_bytes` apart, and maps the peers' inboxes
+ *                 (n_procs == 1: handles may be NULL);
+ *   run_lockstep_direct  n_iter lock-step iterations; synchronous; every rank must call it with the same n_iter.
+ * The transport-agnostic step_begin / step_end protocol above stays available (and is what a rank falls back to
+ * when peer mapping is refused). */
+#define HTM_XCHG_HANDLE_BYTES 64
+int htm_chains_xchg_handle(htm_chains *hc, void *handle, size_t handle_bytes);
+int htm_chains_xchg_connect(htm_chains *hc, const void *handles, size_t handle_bytes);
+int htm_chains_run_lockstep_direct(htm_chains *hc, int n_iter);
 int htm_chains_sync(htm_chains *hc);        /* wait + raise device-side error flags */
 int htm_chains_drain(htm_chains *hc);       /* sync + move device record buffers to host memory */
 
@@ -241,6 +256,11 @@ int htm_quantiles_dev(int device, const double *d_samples, long n_mod, long n_pa
                       const int ranks_1based[3], double *d_out, void *hip_stream);
 
 int htm_selftest(int device);
+
+/* mod_random's generator (reference src/mod_random.f90:60-74) is linear over GF(2): the state after n draws is
+ * T^n * state.  Host-only (no device needed): used to seek in a rank's stream and by the tests that pin the
+ * jump tables of the device generator.  state = {x, y, z, w} as in mod_random.f90:30. */
+int htm_rng_jump(const uint32_t state_in[4], unsigned long long n_draws, uint32_t state_out[4]);
 
 #ifdef __cplusplus
 }

@@ -185,10 +185,15 @@ def test_many_chains_per_rank(nc):
     assert np.array_equal(a, oa) and np.array_equal(b, ob)
 
 
-def test_rccl_lockstep_loop_equals_single_rank_driver():
-    """The multi-GPU driver loop (htm_chains_run_lockstep: one k_mcmc launch + one ncclAllGather per iteration,
-    enqueued from C) on a real RCCL communicator of one rank must produce the bits of the single-rank driver."""
+@pytest.mark.parametrize("transport", ["direct", "rccl"])
+def test_rccl_lockstep_loop_equals_single_rank_driver(transport, monkeypatch):
+    """The multi-GPU driver loops on a real RCCL process group of one rank must produce the bits of the single-rank
+    driver: "direct" = persistent lock-step (htm_chains_run_lockstep_direct: swap records exchanged inside the kernel
+    through the inboxes), "rccl" = htm_chains_run_lockstep (one k_mcmc launch + one ncclAllGather per iteration,
+    enqueued from C)."""
     import socket
+
+    monkeypatch.setenv("HTM_XCHG", "1" if transport == "direct" else "0")
 
     import torch
     import torch.distributed as dist
@@ -207,7 +212,10 @@ def test_rccl_lockstep_loop_equals_single_rank_driver():
                             device_id=torch.device("cuda", 0))
     try:
         tw = TorchWorld(b[0])
-        assert tw.fast is not None, "direct RCCL entry not found: the C loop was not exercised"
+        if transport == "direct":
+            assert tw.direct, "the in-kernel exchange was not set up"
+        else:
+            assert tw.fast is not None and not tw.direct, "direct RCCL entry not found: the C loop was not exercised"
         tw.run(300)
         tw.run(n_iter - 300)
         torch.cuda.synchronize()
@@ -389,11 +397,14 @@ def test_random_stream_ring_wraps_around(lockstep, monkeypatch):
     assert np.array_equal(a, oa) and np.array_equal(b, ob)
 
 
-def _gloo_device_worker(rank, world, port, name, q):
+def _gloo_device_worker(rank, world, port, name, q, transport="staged"):
     import sys
 
     sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HTM_XCHG="1" if transport == "direct" else "0")
+    if transport == "direct" and name == "c4":
+        os.environ["HTM_MAX_WORKERS"] = "24"       # 8 persistent kernels share one GPU here: leave them room to co-reside
     import torch.distributed as dist
 
     from hypotremormcmc_amd import driver
@@ -406,8 +417,13 @@ def _gloo_device_worker(rank, world, port, name, q):
         obs = ObsData.from_arrays(data.sta_x, data.sta_y, data.t_obs, data.t_stdv, data.a_obs, data.a_stdv)
         fwd, cs = driver.build_rank(params, data.sta_x, data.sta_y, data.sta_z, obs, rank, n_procs=world, device=0)
         tw = TorchWorld(cs)
-        assert tw.host_staged and tw.fast is None
-        tw.run(int(params["n_iter"]))
+        if transport == "direct":
+            assert tw.direct, "peer mapping of the inboxes failed"
+        else:
+            assert tw.host_staged and tw.fast is None and not tw.direct
+        n_iter = int(params["n_iter"])
+        tw.run(n_iter // 3)                     # in pieces: a launch ends and the next one picks the exchange up
+        tw.run(n_iter - n_iter // 3)
         it, ch, lk = cs.likelihood_trace()
         ok = np.array_equal(it, fx[f"lik_iter_{rank}"]) and np.allclose(lk, fx[f"lik_{rank}"], rtol=RTOL_TRACE, atol=0)
         npr, nac = tw.reduce_counts()
@@ -417,10 +433,13 @@ def _gloo_device_worker(rank, world, port, name, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,world", [("c1", 2), ("timeonly", 3)])
-def test_torchworld_across_processes_sharing_the_gpu(name, world):
-    """TorchWorld + device-resident chains in 2-3 separate processes (one GPU, so gloo with host-staged records
-    instead of RCCL): per-rank traces and the reduced counters against the reference's MPI run."""
+@pytest.mark.parametrize("name,world,transport", [("c1", 2, "staged"), ("timeonly", 3, "staged"), ("c1", 2, "direct"),
+                                                  ("timeonly", 3, "direct"), ("rejects", 2, "direct"), ("fixedcorr", 2, "direct")])
+def test_torchworld_across_processes_sharing_the_gpu(name, world, transport):
+    """TorchWorld + device-resident chains in 2-3 separate processes sharing the one GPU: per-rank traces and the
+    reduced counters against the reference's MPI run.  "staged": gloo with host-staged records per iteration;
+    "direct": persistent lock-step -- each process's kernel writes its swap records into the other processes'
+    inboxes (IPC-mapped device memory, the mapping a multi-GPU node uses over xGMI) and stays resident."""
     import socket
 
     import torch.multiprocessing as mp
@@ -430,7 +449,7 @@ def test_torchworld_across_processes_sharing_the_gpu(name, world):
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_gloo_device_worker, args=(r, world, port, name, q)) for r in range(world)]
+    procs = [ctx.Process(target=_gloo_device_worker, args=(r, world, port, name, q, transport)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=400) for _ in range(world)]

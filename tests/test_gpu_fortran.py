@@ -103,11 +103,13 @@ def test_unmodified_reference_driver_on_hip_forward_shim(tmp_path):
         np.testing.assert_allclose(v[:, 0], fx[f"lik_{rank}"][:n], rtol=1e-9, atol=0)
 
 
+@pytest.mark.parametrize("transport", ["direct", "staged"])
 @pytest.mark.parametrize("name", ["c1", "timeonly", "fixedcorr", "rejects"])
-def test_fortran_mpi_driver_reproduces_reference_outputs(name, tmp_path):
+def test_fortran_mpi_driver_reproduces_reference_outputs(name, transport, tmp_path):
     """hypo_tremor_mcmc_hip_mpi under real MPI (2-3 processes sharing the GPU): an MPI program like the reference,
-    every rank's chains device-resident, one MPI_Allgather of the swap records per iteration.  All output
-    files of all ranks against what the reference wrote under the same mpiexec."""
+    every rank's chains device-resident.  "direct": persistent lock-step, the kernels exchange the swap records
+    through IPC-mapped inboxes (handles all-gathered over MPI once); "staged": one MPI_Allgather of host-staged
+    records per iteration.  All output files of all ranks against what the reference wrote under the same mpiexec."""
     mpiexec = "/opt/conda/bin/mpiexec"
     exe = os.path.join(BUILD, "hypo_tremor_mcmc_hip_mpi")
     if not (os.path.exists(exe) and os.path.exists(mpiexec)):
@@ -116,9 +118,11 @@ def test_fortran_mpi_driver_reproduces_reference_outputs(name, tmp_path):
     n_procs = int(params["n_procs"])
     synth.write_dataset(str(tmp_path), data)
     synth.write_param_file(str(tmp_path / "run.in"), **{k: v for k, v in params.items()})
-    r = subprocess.run([mpiexec, "-np", str(n_procs), exe, "run.in"], cwd=tmp_path, timeout=900, capture_output=True,
-                       text=True)
+    env = dict(os.environ, HTM_XCHG="1" if transport == "direct" else "0")
+    r = subprocess.run([mpiexec, "-np", str(n_procs), exe, "run.in"], cwd=tmp_path, timeout=300, capture_output=True,
+                       text=True, env=env)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert ("swap exchange: in-kernel" in r.stdout) == (transport == "direct"), r.stdout[-800:]
     E, S = data.n_events, data.n_sta
     for rank in range(n_procs):
         it, v = _records(tmp_path / ("likelihood%02d.out" % rank), 1)

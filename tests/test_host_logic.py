@@ -118,3 +118,31 @@ def test_fortran_host_layer_builds_and_fails_loudly_without_gpu(tmp_path):
     r = subprocess.run([exe, "p.in"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0
     assert "no HIP device" in (r.stderr + r.stdout) or "libhtm_hip" in (r.stderr + r.stdout)
+
+
+def test_rng_jump_ahead_equals_serial_stream():
+    """htm_rng_jump (host GF(2) powers of the xorshift128 step, the tables the device generator k_rawgen starts its
+    segments from) against the serial generator of src/mod_random.f90:60-74, for jump lengths around the table's
+    block sizes (64 * 2^b) and for all three golden seeds of SURVEY 8a."""
+    import ctypes as C
+
+    from hypotremormcmc_amd import _lib
+    from hypotremormcmc_amd.mod_random import Xorshift128
+
+    lib = _lib.load()
+    for rank in (0, 1, 2):
+        g = Xorshift128(rank)
+        s0 = (C.c_uint32 * 4)(*g.state)
+        done = 0
+        for n in (0, 1, 2, 63, 64, 65, 127, 128, 64 * 37 + 5, 4095, 4096, 4097, 1 << 16, (1 << 18) + 64 * 3):
+            while done < n:
+                g._next(); done += 1
+            out = (C.c_uint32 * 4)()
+            _lib.check(lib.htm_rng_jump(s0, n, out))
+            assert tuple(out) == g.state, (rank, n)
+    # composition: jump(a) then jump(b) == jump(a + b), far beyond what a serial loop could check
+    a, b = 10 ** 15 + 7, 3 * 10 ** 12 + 11
+    s0 = (C.c_uint32 * 4)(*Xorshift128(0).state)
+    sa, sab, sd = (C.c_uint32 * 4)(), (C.c_uint32 * 4)(), (C.c_uint32 * 4)()
+    _lib.check(lib.htm_rng_jump(s0, a, sa)); _lib.check(lib.htm_rng_jump(sa, b, sab)); _lib.check(lib.htm_rng_jump(s0, a + b, sd))
+    assert tuple(sab) == tuple(sd)
