@@ -43,9 +43,10 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
 def algorithmic_bytes(E, S, w=8):
-    """bytes per full evaluation and per single-event partial update."""
-    b_full = 4 * w * S * E + 3 * w * E + 5 * w * S + w
-    b_part = 4 * w * S + 6 * w + 5 * w * S + 2 * w
+    """bytes per full evaluation and per single-event partial update; w = bytes of one element of the
+    four observation streams (8, or 4 with the fp32 forward -- everything else stays fp64)."""
+    b_full = 4 * w * S * E + 3 * 8 * E + 5 * 8 * S + 8
+    b_part = 4 * w * S + 6 * 8 + 5 * 8 * S + 2 * 8
     return b_full, b_part
 
 
@@ -73,7 +74,8 @@ def _host_cores():
 def _reference_run(work, exe, params, ranks, n_it, timeout):
     from hypotremormcmc_amd import synth
 
-    synth.write_param_file(os.path.join(work, "run.in"), **dict(params, n_iter=n_it, n_burn=n_it, n_interval=1000))
+    ref_params = {k: v for k, v in params.items() if k != "forward_precision"}      # the reference stops on a key it does not know
+    synth.write_param_file(os.path.join(work, "run.in"), **dict(ref_params, n_iter=n_it, n_burn=n_it, n_interval=1000))
     t0 = time.perf_counter()
     subprocess.run(["/opt/conda/bin/mpiexec", "-np", str(ranks), exe, "run.in"], cwd=work, check=True, timeout=timeout,
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
@@ -180,6 +182,8 @@ def parse_args(argv=None):
     ap.add_argument("--chains", type=int, default=N_CHAINS)
     ap.add_argument("--events", type=int, default=N_EVENTS)
     ap.add_argument("--stations", type=int, default=N_STA)
+    ap.add_argument("--forward-precision", choices=["fp64", "fp32"], default="fp64",
+                    help="fp32: single-precision forward model, fp64 sums and accept (BASELINE configs[4]; statistical tolerance)")
     ap.add_argument("--force-lockstep", action="store_true",
                     help="N = 1 only: drive the multi-rank code path (swap records exchanged every iteration) with one rank")
     return ap.parse_args(argv)
@@ -224,7 +228,8 @@ def main(argv=None):
     n_warm, n_timed = args.warmup * ips, args.steps * ips
     data = synth.make_synthetic(E, S, SEED)
     params = dict(synth.DEFAULT_PARAMS, n_procs=world, n_chains=nc, n_cool=1,
-                  n_iter=n_warm + n_timed + 10 ** 6, n_burn=2 * 10 ** 9, n_interval=1000)
+                  n_iter=n_warm + n_timed + 10 ** 6, n_burn=2 * 10 ** 9, n_interval=1000,
+                  forward_precision=args.forward_precision)
 
     # Test hook (tests/test_bench_launcher.py): "module:function" supplying the per-rank engine, so that launcher,
     # rendezvous, timing protocol and the JSON contract run on a box without a GPU (gloo).  Never a measurement:
@@ -292,12 +297,12 @@ def main(argv=None):
     assert done == n_warm + n_timed, (done, n_warm + n_timed)
 
     value = world * nc * n_timed / dt
-    b_full, b_part = algorithmic_bytes(E, S)
+    b_full, b_part = algorithmic_bytes(E, S, 4 if args.forward_precision == "fp32" else 8)
     out = {
         "metric": "MCMC proposal steps/sec (whole node), 1k events x 64 stn",
         "value": value, "unit": "proposal steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f64" if args.forward_precision == "fp64" else "f32 forward / f64 sums + accept", "data": "synthetic",
         "config": {"workload": f"{E} events x {S} stations, {nc} chains/GPU x {world} GPU(s), swap every "
                                f"iteration, all solve_*/use_* = T (BASELINE configs[{2 if world == 1 else 3}])",
                    "chains_per_gpu": nc, "n_events": E, "n_sta": S, "seed": SEED,

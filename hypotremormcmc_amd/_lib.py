@@ -44,6 +44,7 @@ SIGNATURES = {
     "htm_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "htm_forward_create": (C.c_int, [C.c_int, C.c_int] + [dp] * 7 + [C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
     "htm_forward_destroy": (C.c_int, [vp]),
+    "htm_forward_set_precision": (C.c_int, [vp, C.c_int]),
     "htm_forward_set_stream": (C.c_int, [vp, vp]),
     "htm_forward_reset_stream": (C.c_int, [vp]),
     "htm_forward_loglik_full": (C.c_int, [vp, dp, dp, C.c_double, dp, C.c_double, dp]),
@@ -72,9 +73,15 @@ SIGNATURES = {
     "htm_quantiles_dev": (C.c_int, [C.c_int, vp, C.c_long, C.c_long, C.c_long, C.POINTER(C.c_int), vp, vp]),
     "htm_chains_swap_record_host": (C.c_int, [vp, dp]),
     "htm_chains_step_end_host": (C.c_int, [vp, dp]),
+    "htm_comm_unique_id": (C.c_int, [vp, C.c_size_t]),
+    "htm_comm_create": (C.c_int, [vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
+    "htm_comm_destroy": (C.c_int, [vp]),
+    "htm_comm_allgather": (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
+    "htm_chains_run_lockstep_comm": (C.c_int, [vp, C.c_int, vp]),
     "htm_chains_xchg_handle": (C.c_int, [vp, vp, C.c_size_t]),
     "htm_chains_xchg_connect": (C.c_int, [vp, vp, C.c_size_t]),
     "htm_chains_run_lockstep_direct": (C.c_int, [vp, C.c_int]),
+    "htm_chains_xchg_probe": (C.c_int, [vp, C.c_uint, C.c_double]),
     "htm_chains_checkpoint_size": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
     "htm_chains_checkpoint_save": (C.c_int, [vp, vp, C.c_size_t]),
     "htm_chains_checkpoint_load": (C.c_int, [vp, vp, C.c_size_t]),

@@ -130,6 +130,10 @@ class ChainSet:
             buf = C.create_string_buffer(handles, len(handles))
             check(self._lib.htm_chains_xchg_connect(self.handle, buf, self.XCHG_HANDLE_BYTES))
 
+    def xchg_probe(self, token: int = 1, seconds: float = 10.0):
+        """Collective: every rank's probe kernel must see the tokens of all ranks in its inbox (raises otherwise)."""
+        check(self._lib.htm_chains_xchg_probe(self.handle, int(token), float(seconds)))
+
     def run_lockstep_direct(self, n_iter: int):
         check(self._lib.htm_chains_run_lockstep_direct(self.handle, int(n_iter)))
 

@@ -101,6 +101,12 @@ struct FwdDev {
     const double *t_obs, *t_prec, *a_obs, *a_prec;     // [E][S]  (station fastest)
     const double *psum_t, *psum_a;                     // [E]  sum_j prec(j,i), summed in station order
     double const_sum;   // sum over used data types of sum_{j,i} (log_2pi_half + log_stdv(j,i))
+    // fp32 forward / fp64 accept (BASELINE configs[4], htm_forward_set_precision): the four observation streams once
+    // more as float (half the bytes of a full evaluation), and the flag that makes event_misfit compute the synthetic
+    // travel time / amplitude (distance, sqrt, division, log: cls_forward.f90:115-118, :201-204) in single precision.
+    // Demean sums, residuals, the misfit sum and the Metropolis decision stay fp64 (:125-132, :281-299).
+    const float *t_obs32, *t_prec32, *a_obs32, *a_prec32;
+    int fp32;           // host-side dispatch only: the F32 = true instantiations of the kernels are launched
 };
 
 // Immutable inputs (priors, step sizes, precision sums) at a wave-uniform address: a load through the constant
@@ -129,7 +135,7 @@ struct ObsRegs {
     double pst, psa;     // sum_j precision(j, event), time and amplitude
 };
 
-template <int NCH>
+template <int NCH, bool F32 = false>
 __device__ __forceinline__ void load_obs_regs(ObsRegs<NCH> &ob, const FwdDev &f, int ev, int lane)
 {
     const size_t base = (size_t)ev * (size_t)f.S;
@@ -139,15 +145,20 @@ __device__ __forceinline__ void load_obs_regs(ObsRegs<NCH> &ob, const FwdDev &f,
         const bool valid = j < f.S;
         ob.tob[c] = ob.tpr[c] = ob.aob[c] = ob.apr[c] = 0.0;
         if (valid) {
-            if (f.use_time) { ob.tob[c] = f.t_obs[base + j]; ob.tpr[c] = f.t_prec[base + j]; }
-            if (f.use_amp)  { ob.aob[c] = f.a_obs[base + j]; ob.apr[c] = f.a_prec[base + j]; }
+            if constexpr (F32) {   // the float streams, promoted (exactly) to the registers' fp64
+                if (f.use_time) { ob.tob[c] = (double)f.t_obs32[base + j]; ob.tpr[c] = (double)f.t_prec32[base + j]; }
+                if (f.use_amp)  { ob.aob[c] = (double)f.a_obs32[base + j]; ob.apr[c] = (double)f.a_prec32[base + j]; }
+            } else {
+                if (f.use_time) { ob.tob[c] = f.t_obs[base + j]; ob.tpr[c] = f.t_prec[base + j]; }
+                if (f.use_amp)  { ob.aob[c] = f.a_obs[base + j]; ob.apr[c] = f.a_prec[base + j]; }
+            }
         }
     }
     ob.pst = f.use_time ? ld_const(f.psum_t + ev) : 1.0;      // wave-uniform: scalar loads
     ob.psa = f.use_amp ? ld_const(f.psum_a + ev) : 1.0;
 }
 
-template <int NCH, int NPOS>
+template <int NCH, int NPOS, bool F32 = false>
 __device__ __forceinline__ void event_misfit(const FwdDev &f, const ObsRegs<NCH> &ob, int lane,
                                              const StaRegs<NCH> &st, const double (&px)[NPOS],
                                              const double (&py)[NPOS], const double (&pz)[NPOS], double beta,
@@ -159,6 +170,32 @@ __device__ __forceinline__ void event_misfit(const FwdDev &f, const ObsRegs<NCH>
     double red[2 * NPOS];
 #pragma unroll
     for (int k = 0; k < 2 * NPOS; ++k) red[k] = 0.0;
+    if constexpr (F32) {
+        // single-precision forward: the coordinate differences are formed in fp64 (they are what the model state is),
+        // everything after them -- distance, travel time, amplitude -- is fp32 arithmetic on the hardware's own
+        // sqrt / reciprocal / log2 (v_sqrt_f32, v_rcp_f32, v_log_f32: ~1 ulp), then promoted for the fp64 sums
+        const float rbeta = __builtin_amdgcn_rcpf((float)beta);
+        const float katt = (float)(kPi * kFreq) * __builtin_amdgcn_rcpf((float)qbeta);
+#pragma unroll
+        for (int p = 0; p < NPOS; ++p) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const bool valid = (lane + 64 * c) < f.S;
+                const float dx = (float)(px[p] - st.sx[c]), dy = (float)(py[p] - st.sy[c]), dz = (float)(pz[p] - st.sz[c]);
+                float d = __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz);
+                if (!valid) d = 1.0f;
+                ts[p][c] = 0.0; as[p][c] = 0.0;
+                if (f.use_time) {
+                    ts[p][c] = (double)(d * rbeta - (float)st.tc[c]);
+                    red[2 * p] += valid ? tpr[c] * (ts[p][c] - tob[c]) : 0.0;
+                }
+                if (f.use_amp) {
+                    as[p][c] = (double)(-(d * katt) - __builtin_amdgcn_logf(d) * 0.69314718055994531f - (float)st.ac[c]);
+                    red[2 * p + 1] += valid ? apr[c] * (as[p][c] - aob[c]) : 0.0;
+                }
+            }
+        }
+    } else {
 #pragma unroll
     for (int p = 0; p < NPOS; ++p) {
 #pragma unroll
@@ -177,6 +214,7 @@ __device__ __forceinline__ void event_misfit(const FwdDev &f, const ObsRegs<NCH>
                 red[2 * p + 1] += valid ? apr[c] * (as[p][c] - aob[c]) : 0.0;
             }
         }
+    }
     }
     wave_sum<2 * NPOS>(red);
     const double pst = ob.pst, psa = ob.psa;

@@ -5,6 +5,7 @@
 #include "htm_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <array>
@@ -184,7 +185,21 @@ int launch_full(htm_forward *h, const FullJob &jb, int gy)
 {
     dim3 grid(h->n_wg, gy), block(256);
     const size_t smem = 0;
-    if (jb.desc) {
+    if (h->dev.fp32 && (h->nch == 1 || h->nch == 2 || h->nch == 4)) {        // fp32 forward (htm_forward_set_precision)
+        if (jb.desc) {
+            switch (h->nch) {
+            case 1: hipLaunchKernelGGL((k_full<1, false, true>), grid, block, smem, h->stream, h->dev, jb); break;
+            case 2: hipLaunchKernelGGL((k_full<2, false, true>), grid, block, smem, h->stream, h->dev, jb); break;
+            default: hipLaunchKernelGGL((k_full<4, false, true>), grid, block, smem, h->stream, h->dev, jb); break;
+            }
+        } else {
+            switch (h->nch) {
+            case 1: hipLaunchKernelGGL((k_full<1, true, true>), grid, block, smem, h->stream, h->dev, jb); break;
+            case 2: hipLaunchKernelGGL((k_full<2, true, true>), grid, block, smem, h->stream, h->dev, jb); break;
+            default: hipLaunchKernelGGL((k_full<4, true, true>), grid, block, smem, h->stream, h->dev, jb); break;
+            }
+        }
+    } else if (jb.desc) {
         switch (h->nch) {
         case 1: hipLaunchKernelGGL((k_full<1, false>), grid, block, smem, h->stream, h->dev, jb); break;
         case 2: hipLaunchKernelGGL((k_full<2, false>), grid, block, smem, h->stream, h->dev, jb); break;
@@ -208,6 +223,12 @@ int launch_mcmc(htm_chains *hc, int mode, int target, const double *gathered)
     htm_forward *h = hc->fwd;
     dim3 grid(1 + hc->dev.n_workers), block(512);
     const unsigned long long seq = ++hc->launch_seq;      // this chain set's k_mcmc launches, counted from 1
+    if (h->dev.fp32) {
+        if (h->nch == 1) hipLaunchKernelGGL((k_mcmc<1, true>), grid, block, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax, seq);
+        else hipLaunchKernelGGL((k_mcmc<2, true>), grid, block, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax, seq);
+        HIPCHK(hipGetLastError());
+        return HTM_OK;
+    }
     switch (h->nch) {
     case 1: hipLaunchKernelGGL(k_mcmc<1>, grid, block, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax, seq); break;
     case 2: hipLaunchKernelGGL(k_mcmc<2>, grid, block, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax, seq); break;
@@ -221,6 +242,12 @@ int launch_step(htm_chains *hc, int mode, int target, const double *gathered)
 {
     htm_forward *h = hc->fwd;
     dim3 grid(1), block(64 * hc->nw);
+    if (h->dev.fp32) {
+        if (h->nch == 1) hipLaunchKernelGGL((k_step<1, true>), grid, block, hc->step_smem, h->stream, h->dev, hc->dev_np, mode, target, gathered, hc->ring_size, hc->wmax);
+        else hipLaunchKernelGGL((k_step<2, true>), grid, block, hc->step_smem, h->stream, h->dev, hc->dev_np, mode, target, gathered, hc->ring_size, hc->wmax);
+        HIPCHK(hipGetLastError());
+        return HTM_OK;
+    }
     switch (h->nch) {
     case 1: hipLaunchKernelGGL(k_step<1>, grid, block, hc->step_smem, h->stream, h->dev, hc->dev_np, mode, target, gathered, hc->ring_size, hc->wmax); break;
     case 2: hipLaunchKernelGGL(k_step<2>, grid, block, hc->step_smem, h->stream, h->dev, hc->dev_np, mode, target, gathered, hc->ring_size, hc->wmax); break;
@@ -413,6 +440,33 @@ int htm_forward_destroy(htm_forward *h)
     return HTM_OK;
 }
 
+int htm_forward_set_precision(htm_forward *h, int forward_fp32)
+{
+    if (!h) return fail(HTM_EINVAL, "NULL handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (!forward_fp32) { h->dev.fp32 = 0; return HTM_OK; }
+    if (h->nch != 1 && h->nch != 2) return fail(HTM_EINVAL, "the fp32 forward covers n_sta <= 128 (this handle has %d stations)", h->S);
+    if (!h->dev.t_obs32) {
+        // the four observation streams once more as float: the bytes a full evaluation reads are halved
+        const size_t n = (size_t)h->S * h->E;
+        std::vector<double> tmp(n);
+        std::vector<float> f32(n);
+        const double *src[4] = {h->dev.t_obs, h->dev.t_prec, h->dev.a_obs, h->dev.a_prec};
+        const float **dst[4] = {&h->dev.t_obs32, &h->dev.t_prec32, &h->dev.a_obs32, &h->dev.a_prec32};
+        for (int k = 0; k < 4; ++k) {
+            HIPCHK(hipMemcpy(tmp.data(), src[k], n * sizeof(double), hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < n; ++i) f32[i] = (float)tmp[i];
+            float *p = nullptr;
+            int rc = dev_upload(h->pool, &p, f32.data(), n);
+            if (rc) return rc;
+            *dst[k] = p;
+        }
+    }
+    h->dev.fp32 = 1;
+    return HTM_OK;
+}
+
 int htm_forward_set_stream(htm_forward *h, void *hip_stream)
 {
     if (!h) return fail(HTM_EINVAL, "NULL handle");
@@ -468,8 +522,16 @@ int htm_forward_loglik_partial(htm_forward *h, int evt_id, const double hypo_old
     HIPCHK(hipMemcpyAsync(h->d_tc, t_corr, h->S * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_ac, a_corr, h->S * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_scal + 4, sc, sizeof(sc), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_partial_one, dim3(1), dim3(64), 0, h->stream, h->dev, evt_id - 1, h->d_scal + 4,
-                       h->d_scal + 7, h->d_tc, h->d_ac, vs, qs, log_likelihood_old, h->d_scal + 2);
+    if (h->dev.fp32 && h->nch <= 2 && h->nch >= 1) {
+        if (h->nch == 1) hipLaunchKernelGGL((k_partial_one<1, true>), dim3(1), dim3(64), 0, h->stream, h->dev, evt_id - 1, h->d_scal + 4, h->d_scal + 7, h->d_tc, h->d_ac, vs, qs, log_likelihood_old, h->d_scal + 2);
+        else hipLaunchKernelGGL((k_partial_one<2, true>), dim3(1), dim3(64), 0, h->stream, h->dev, evt_id - 1, h->d_scal + 4, h->d_scal + 7, h->d_tc, h->d_ac, vs, qs, log_likelihood_old, h->d_scal + 2);
+    } else
+    switch (h->nch) {
+    case 1: hipLaunchKernelGGL(k_partial_one<1>, dim3(1), dim3(64), 0, h->stream, h->dev, evt_id - 1, h->d_scal + 4, h->d_scal + 7, h->d_tc, h->d_ac, vs, qs, log_likelihood_old, h->d_scal + 2); break;
+    case 2: hipLaunchKernelGGL(k_partial_one<2>, dim3(1), dim3(64), 0, h->stream, h->dev, evt_id - 1, h->d_scal + 4, h->d_scal + 7, h->d_tc, h->d_ac, vs, qs, log_likelihood_old, h->d_scal + 2); break;
+    case 4: hipLaunchKernelGGL(k_partial_one<4>, dim3(1), dim3(64), 0, h->stream, h->dev, evt_id - 1, h->d_scal + 4, h->d_scal + 7, h->d_tc, h->d_ac, vs, qs, log_likelihood_old, h->d_scal + 2); break;
+    default: hipLaunchKernelGGL(k_partial_one<0>, dim3(1), dim3(64), 0, h->stream, h->dev, evt_id - 1, h->d_scal + 4, h->d_scal + 7, h->d_tc, h->d_ac, vs, qs, log_likelihood_old, h->d_scal + 2); break;
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(log_likelihood, h->d_scal + 2, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -776,7 +838,8 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
     hc->step_smem = lds_fixed + (size_t)hc->ring_size * lds_pos + (1 + hc->dev.mirror_steps) * (size_t)hc->dev.mirror_n * sizeof(double);
     if (hc->step_smem > lds_cap) return cleanup(fail(HTM_EINVAL, "n_chains / n_sta too large for k_step's LDS budget"));
     if (hc->step_smem > 48 * 1024) {
-        const void *fn = h->nch == 1 ? (const void *)k_step<1> : h->nch == 2 ? (const void *)k_step<2> : (const void *)k_step<0>;
+        const void *fn = h->dev.fp32 ? (h->nch == 1 ? (const void *)k_step<1, true> : (const void *)k_step<2, true>)
+                         : h->nch == 1 ? (const void *)k_step<1> : h->nch == 2 ? (const void *)k_step<2> : (const void *)k_step<0>;
         HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hc->step_smem));
     }
     if (hipEventCreateWithFlags(&hc->ev_wd, hipEventDisableTiming) != hipSuccess) return cleanup(fail(HTM_EHIP, "hipEventCreate failed"));
@@ -788,7 +851,8 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
         // Master and workers of a k_mcmc launch wait for each other, so every block must be RESIDENT: never ask for more
         // worker blocks than the device can hold next to the master (a partitioned or CU-masked GPU has fewer CUs; every
         // block carries the master's LDS size).  Workers take events round-robin, so fewer of them only take longer.
-        const void *fn = h->nch == 1 ? (const void *)k_mcmc<1> : h->nch == 2 ? (const void *)k_mcmc<2> : (const void *)k_mcmc<0>;
+        const void *fn = h->dev.fp32 ? (h->nch == 1 ? (const void *)k_mcmc<1, true> : (const void *)k_mcmc<2, true>)
+                         : h->nch == 1 ? (const void *)k_mcmc<1> : h->nch == 2 ? (const void *)k_mcmc<2> : (const void *)k_mcmc<0>;
         if (hc->step_smem > 48 * 1024) HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hc->step_smem));
         int per_cu = 0, n_cu = 0;
         HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 512, hc->step_smem));
@@ -1213,6 +1277,25 @@ int htm_chains_xchg_connect(htm_chains *hc, const void *handles, size_t handle_b
     return HTM_OK;
 }
 
+int htm_chains_xchg_probe(htm_chains *hc, unsigned token, double seconds)
+{
+    if (!hc) return fail(HTM_EINVAL, "NULL handle");
+    if (!hc->xchg_ready) return fail(HTM_ESTATE, "htm_chains_xchg_connect has not been called");
+    HIPCHK(hipSetDevice(hc->fwd->device));
+    int *d_res = nullptr;
+    int rc = dev_alloc(hc->pool, &d_res, 1);
+    if (rc) return rc;
+    HIPCHK(hipMemset(d_res, 0, sizeof(int)));
+    const unsigned long long ticks = (unsigned long long)(std::max(0.01, std::min(seconds, 60.0)) * 1e8);
+    hipLaunchKernelGGL(k_xchg_probe, dim3(1), dim3(64), 0, hc->fwd->stream, hc->dev, token & 0x7fffffffu, ticks, d_res);
+    HIPCHK(hipGetLastError());
+    int res = 0;
+    HIPCHK(hipMemcpyAsync(&res, d_res, sizeof(int), hipMemcpyDeviceToHost, hc->fwd->stream));
+    if ((rc = bounded_stream_sync(hc, "inbox probe"))) return rc;
+    if (!res) return fail(HTM_ESTATE, "inbox probe: the tokens of the other ranks did not arrive within %.1f s", seconds);
+    return HTM_OK;
+}
+
 // n_iter lock-step iterations with the exchange inside the kernel: one k_mcmc launch runs until the target, or until
 // some rank asks everybody to stop (its record buffers or its produced random stream are nearly used up); then every
 // rank drains / refills and launches again.  All ranks leave a launch after the same iteration.
@@ -1254,6 +1337,113 @@ int htm_chains_run_lockstep_direct(htm_chains *hc, int n_iter)
     hc->last_full = hc->h_ctrl.n_full_evals - hc->run_full0;
     hc->last_part = hc->h_ctrl.n_partial_evals - hc->run_part0;
     return drain_records(hc);
+}
+
+// ---- RCCL reached from the C ABI (so that a Fortran / C host needs no Python to use RCCL for the swap) ----------
+// librccl is bound at run time (dlopen): the library itself does not link against it, and inside a PyTorch process the
+// copy torch has already loaded is reused.  Only the four entry points the swap needs.
+struct htm_comm {
+    void *lib = nullptr, *comm = nullptr;
+    int rank = 0, n_ranks = 1, device = 0;
+    int (*all_gather)(const void *, void *, size_t, int, void *, void *) = nullptr;
+    int (*comm_destroy)(void *) = nullptr;
+    double *d_gathered = nullptr;
+    size_t gathered_cap = 0;
+};
+namespace {
+struct NcclId { char b[HTM_COMM_ID_BYTES]; };
+void *rccl_open()
+{
+    static void *lib = [] {
+        const char *names[] = {getenv("HTM_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        void *h = nullptr;
+        for (const char *n : names) {
+            if (!n || !*n) continue;
+            if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD))) break;      // already in the process (PyTorch's copy)
+        }
+        for (const char *n : names) {
+            if (h) break;
+            if (!n || !*n) continue;
+            h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        }
+        return h;
+    }();
+    return lib;
+}
+}  // namespace
+
+int htm_comm_unique_id(void *id, size_t id_bytes)
+{
+    if (!id || id_bytes < HTM_COMM_ID_BYTES) return fail(HTM_EINVAL, "id buffer must hold %d bytes", HTM_COMM_ID_BYTES);
+    void *lib = rccl_open();
+    if (!lib) return fail(HTM_ENODEVICE, "librccl.so not found (%s)", dlerror());
+    auto get_id = reinterpret_cast<int (*)(NcclId *)>(dlsym(lib, "ncclGetUniqueId"));
+    if (!get_id) return fail(HTM_ENODEVICE, "ncclGetUniqueId not found in librccl");
+    NcclId u;
+    std::memset(&u, 0, sizeof(u));
+    const int st = get_id(&u);
+    if (st != 0) return fail(HTM_EHIP, "ncclGetUniqueId failed with status %d", st);
+    std::memset(id, 0, id_bytes);
+    std::memcpy(id, &u, sizeof(u));
+    return HTM_OK;
+}
+
+int htm_comm_create(const void *id, size_t id_bytes, int rank, int n_ranks, int device, htm_comm **out)
+{
+    if (!out) return fail(HTM_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (!id || id_bytes < HTM_COMM_ID_BYTES || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(HTM_EINVAL, "bad argument");
+    int rc = use_device(device);
+    if (rc) return rc;
+    void *lib = rccl_open();
+    if (!lib) return fail(HTM_ENODEVICE, "librccl.so not found (%s)", dlerror());
+    auto init_rank = reinterpret_cast<int (*)(void **, int, NcclId, int)>(dlsym(lib, "ncclCommInitRank"));
+    auto all_gather = reinterpret_cast<int (*)(const void *, void *, size_t, int, void *, void *)>(dlsym(lib, "ncclAllGather"));
+    auto destroy = reinterpret_cast<int (*)(void *)>(dlsym(lib, "ncclCommDestroy"));
+    if (!init_rank || !all_gather || !destroy) return fail(HTM_ENODEVICE, "librccl lacks ncclCommInitRank / ncclAllGather / ncclCommDestroy");
+    NcclId u;
+    std::memcpy(&u, id, sizeof(u));
+    void *comm = nullptr;
+    const int st = init_rank(&comm, n_ranks, u, rank);
+    if (st != 0 || !comm) return fail(HTM_EHIP, "ncclCommInitRank failed with status %d (RCCL refuses two ranks on one device)", st);
+    htm_comm *c = new htm_comm();
+    c->lib = lib; c->comm = comm; c->rank = rank; c->n_ranks = n_ranks; c->device = device;
+    c->all_gather = all_gather; c->comm_destroy = destroy;
+    *out = c;
+    return HTM_OK;
+}
+
+int htm_comm_destroy(htm_comm *c)
+{
+    if (!c) return HTM_OK;
+    (void)hipSetDevice(c->device);
+    if (c->d_gathered) (void)hipFree(c->d_gathered);
+    if (c->comm && c->comm_destroy) (void)c->comm_destroy(c->comm);
+    delete c;
+    return HTM_OK;
+}
+
+int htm_comm_allgather(htm_comm *c, const void *d_send, void *d_recv, size_t bytes_per_rank, void *hip_stream)
+{
+    if (!c || !d_send || !d_recv) return fail(HTM_EINVAL, "NULL argument");
+    const int st = c->all_gather(d_send, d_recv, bytes_per_rank, 0 /* ncclInt8 */, c->comm, hip_stream);
+    if (st != 0) return fail(HTM_EHIP, "ncclAllGather failed with status %d", st);
+    return HTM_OK;
+}
+
+int htm_chains_run_lockstep_comm(htm_chains *hc, int n_iter, htm_comm *c)
+{
+    if (!hc || !c) return fail(HTM_EINVAL, "NULL argument");
+    if (c->n_ranks != hc->dev.n_procs || c->rank != hc->dev.rank) return fail(HTM_EINVAL, "communicator rank/size do not match the chain set");
+    HIPCHK(hipSetDevice(hc->fwd->device));
+    const size_t words = (4 + 2 * (size_t)hc->dev.n_chains) * (size_t)c->n_ranks;
+    if (words > c->gathered_cap) {
+        if (c->d_gathered) HIPCHK(hipFree(c->d_gathered));
+        c->d_gathered = nullptr;
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_gathered), words * sizeof(double)));
+        c->gathered_cap = words;
+    }
+    return htm_chains_run_lockstep(hc, n_iter, c->all_gather, c->comm, c->d_gathered);
 }
 
 int htm_chains_swap_record(htm_chains *hc, void **d_record, size_t *record_bytes)

@@ -33,7 +33,7 @@ struct FullJob {
 // reduced in a fixed order by the consumer (deterministic).
 // BATCH only gives the two launch shapes distinct kernel names (profilers list them separately):
 // false = work order from k_step inside the MCMC loop, true = n_models stacked models.
-template <int NCH, bool BATCH>
+template <int NCH, bool BATCH, bool F32 = false>
 __global__ __launch_bounds__(256) void k_full(FwdDev f, FullJob jb)
 {
     __shared__ double s_red[4];
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void k_full(FwdDev f, FullJob jb)
     ObsRegs<NR> ob_keep;
     const bool keep_obs = NCH > 0 && jb.epw == 1 && (int)(blockIdx.x * 4 + wave) < f.E;
     if constexpr (NCH > 0) {
-        if (keep_obs) load_obs_regs<NCH>(ob_keep, f, blockIdx.x * 4 + wave, lane);
+        if (keep_obs) load_obs_regs<NCH, F32>(ob_keep, f, blockIdx.x * 4 + wave, lane);
     }
     for (int k = k0; k < nm; k += kstep) {
         const int m = jb.desc ? en.chain : k;
@@ -88,11 +88,11 @@ __global__ __launch_bounds__(256) void k_full(FwdDev f, FullJob jb)
                     const double pz[1] = {(ov && ov_cmp == 2) ? ov_val : hyp[3 * ev + 2]};
                     double out[1];
                     if (keep_obs) {
-                        event_misfit<NCH, 1>(f, ob_keep, lane, st, px, py, pz, beta, q, out);
+                        event_misfit<NCH, 1, F32>(f, ob_keep, lane, st, px, py, pz, beta, q, out);
                     } else {
                         ObsRegs<NCH> ob;
-                        load_obs_regs<NCH>(ob, f, ev, lane);
-                        event_misfit<NCH, 1>(f, ob, lane, st, px, py, pz, beta, q, out);
+                        load_obs_regs<NCH, F32>(ob, f, ev, lane);
+                        event_misfit<NCH, 1, F32>(f, ob, lane, st, px, py, pz, beta, q, out);
                     }
                     lane_acc += out[0];
                 }
@@ -167,6 +167,7 @@ __global__ __launch_bounds__(256) void k_syn(FwdDev f, const double *hypo, const
 }
 
 // partially_update_log_likelihood for one event, one wave (host-pointer API)
+template <int NCH, bool F32 = false>
 __global__ __launch_bounds__(64) void k_partial_one(FwdDev f, int ev, const double *xyz_old,
                                                     const double *xyz_new, const double *tc,
                                                     const double *ac, double beta, double q, double L_old,
@@ -175,7 +176,15 @@ __global__ __launch_bounds__(64) void k_partial_one(FwdDev f, int ev, const doub
     const int lane = threadIdx.x;
     double px[2] = {xyz_old[0], xyz_new[0]}, py[2] = {xyz_old[1], xyz_new[1]}, pz[2] = {xyz_old[2], xyz_new[2]};
     double out[2];
-    event_misfit_generic<2>(f, ev, lane, f.sx, f.sy, f.sz, tc, ac, 0, -1, 0.0, px, py, pz, beta, q, out);
+    if constexpr (NCH > 0) {        // the register path of the chain kernels (honours the fp32-forward mode)
+        StaRegs<NCH> st;
+        ObsRegs<NCH> ob;
+        load_sta_regs<NCH>(st, f.S, lane, f.sx, f.sy, f.sz, tc, ac, 0, -1, 0.0);
+        load_obs_regs<NCH, F32>(ob, f, ev, lane);
+        event_misfit<NCH, 2, F32>(f, ob, lane, st, px, py, pz, beta, q, out);
+    } else {
+        event_misfit_generic<2>(f, ev, lane, f.sx, f.sy, f.sz, tc, ac, 0, -1, 0.0, px, py, pz, beta, q, out);
+    }
     const double tot = wave_sum1(out[0] - out[1]);
     if (lane == 0) *L_out = L_old + tot;
 }

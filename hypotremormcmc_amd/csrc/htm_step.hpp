@@ -234,7 +234,7 @@ __device__ __forceinline__ bool metropolis(double L_new, double L_cur, double T,
 // worker blocks from HERE, by the chain's own wave, as soon as the proposed value is known: the order goes out
 // while the other chain waves are still in their partial updates, so the workers' round trip is hidden behind
 // them.  The wave then collects the workers' partial sums, judges and commits like any other step.
-template <int NCH, bool PERSIST>
+template <int NCH, bool PERSIST, bool F32>
 __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, StepShared &sh, const Ring &rg,
                                           const double *s_sx, const double *s_sy, const double *s_sz, int c,
                                           int p, int iter, int lane, unsigned long long launch, bool wait_rolep, bool first_pass)
@@ -274,7 +274,7 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
     if (partial) {
         if constexpr (NCH > 0) {
             load_sta_regs<NCH>(st, f.S, lane, s_sx, s_sy, s_sz, tc, ac, 0, -1, 0.0);
-            load_obs_regs<NCH>(ob, f, ev, lane);      // in flight while the proposal is worked out
+            load_obs_regs<NCH, F32>(ob, f, ev, lane);      // in flight while the proposal is worked out
         }
     }
     // A full-evaluation step whose order went out two iterations ahead may need the one-event correction (below): its
@@ -294,7 +294,7 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
                 const double *hypd = cs.hypo.x + (size_t)c * cs.hypo.nx + 3 * d_e;
                 d_ex = ld_state(hypd, vzd); d_ey = ld_state(hypd + 1, vzd); d_ez = ld_state(hypd + 2, vzd);
                 load_sta_regs<NCH>(st, f.S, lane, s_sx, s_sy, s_sz, tc, ac, 0, -1, 0.0);
-                load_obs_regs<NCH>(ob, f, d_e, lane);
+                load_obs_regs<NCH, F32>(ob, f, d_e, lane);
             }
         }
     }
@@ -332,7 +332,7 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
             const double py[2] = {hy, cmp == 1 ? x_new : hy};
             const double pz[2] = {hz, cmp == 2 ? x_new : hz};
             double out[2];
-            if constexpr (NCH > 0) event_misfit<NCH, 2>(f, ob, lane, st, px, py, pz, beta, q, out);
+            if constexpr (NCH > 0) event_misfit<NCH, 2, F32>(f, ob, lane, st, px, py, pz, beta, q, out);
             else event_misfit_generic<2>(f, ev, lane, s_sx, s_sy, s_sz, tc, ac, 0, -1, 0.0, px, py, pz, beta, q, out);
             CSTAMP(2);   // event_misfit
             L_new = L_cur + wave_sum1(out[0] - out[1]);
@@ -454,7 +454,7 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
                                 const double *hyp = cs.hypo.x + (size_t)c * cs.hypo.nx + 3 * e;
                                 d_ex = ld_state(hyp, vzd); d_ey = ld_state(hyp + 1, vzd); d_ez = ld_state(hyp + 2, vzd);
                                 load_sta_regs<NCH>(st, f.S, lane, s_sx, s_sy, s_sz, tc, ac, 0, -1, 0.0);
-                                load_obs_regs<NCH>(ob, f, e, lane);
+                                load_obs_regs<NCH, F32>(ob, f, e, lane);
                             }
                             if (type == 2 || type == 4) {      // this step's proposed correction, on the lane of its station
 #pragma unroll
@@ -466,7 +466,7 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
                             const double pyd[2] = {pcmp == 1 ? prev_xold : d_ey, d_ey};
                             const double pzd[2] = {pcmp == 2 ? prev_xold : d_ez, d_ez};
                             double outd[2];
-                            event_misfit<NCH, 2>(f, ob, lane, st, pxd, pyd, pzd, type == 1 ? x_new : beta, type == 3 ? x_new : q, outd);
+                            event_misfit<NCH, 2, F32>(f, ob, lane, st, pxd, pyd, pzd, type == 1 ? x_new : beta, type == 3 ? x_new : q, outd);
                             L_new = L_new + wave_sum1(outd[0] - outd[1]);
                         }
                     }
@@ -904,7 +904,7 @@ __device__ __forceinline__ void exchange_records(const ChainsDev &cs, StepShared
 // PERSIST = true: this is block 0 of a k_mcmc launch; full evaluations are handed to the worker blocks of the
 // same launch through PSync (no kernel exit).  PERSIST = false: the kernel exits at a hand-over and k_full runs
 // as its own launch (fallback path, also used for profiling the two stages separately).
-template <int NCH, bool PERSIST>
+template <int NCH, bool PERSIST, bool F32>
 __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, int mode, int target_arg,
                                           const double *gathered, int ring_size, int wmax, unsigned long long launch)
 {
@@ -1087,7 +1087,7 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
                     } else if (!have_p) {                                   // optimistic start: c steps after base
                         p = c == 0 ? sh.base : sh.base + rg.hop[(sh.base & rg.mask) * kHops + c - 1];
                     }
-                    p = chain_pass<NCH, PERSIST>(f, cs, sh, rg, s_sx, s_sy, s_sz, c, p, iter, lane, launch,
+                    p = chain_pass<NCH, PERSIST, F32>(f, cs, sh, rg, s_sx, s_sy, s_sz, c, p, iter, lane, launch,
                                                  have_prev && rolep_on, first);
                     have_p = true;
                     if (NW > 1 && c + NW < nc) p += rg.hop[(p & rg.mask) * kHops + NW - 2];   // skip NW-1 steps
@@ -1221,11 +1221,11 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
 #endif
 }
 
-template <int NCH>
+template <int NCH, bool F32 = false>
 __global__ __launch_bounds__(512) void k_step(FwdDev f, ChainsDev cs, int mode, int target_arg,
                                                const double *gathered, int ring_size, int wmax)
 {
-    step_body<NCH, false>(f, cs, mode, target_arg, gathered, ring_size, wmax, 0ull);
+    step_body<NCH, false, F32>(f, cs, mode, target_arg, gathered, ring_size, wmax, 0ull);
 }
 
 // Worker block of a k_mcmc launch: waits for work orders of its own launch and evaluates its event tile of
@@ -1235,7 +1235,7 @@ __global__ __launch_bounds__(512) void k_step(FwdDev f, ChainsDev cs, int mode, 
 // granules (data is the flag); chain state is read with agent-scope loads after the job word has been seen
 // (the master drained its stores before publishing it).  Leaves when the master has finished (PSync::quit)
 // or after a bounded wait.
-template <int NCH>
+template <int NCH, bool F32>
 __device__ __forceinline__ void worker_body(const FwdDev &f, const ChainsDev &cs, unsigned long long launch)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1258,7 +1258,7 @@ __device__ __forceinline__ void worker_body(const FwdDev &f, const ChainsDev &cs
             st.sx[c] = valid ? f.sx[j] : 0.0; st.sy[c] = valid ? f.sy[j] : 0.0; st.sz[c] = valid ? f.sz[j] : 0.0;
             st.tc[c] = 0.0; st.ac[c] = 0.0;
         }
-        if (ev0 < f.E) load_obs_regs<NCH>(ob0, f, ev0, lane);
+        if (ev0 < f.E) load_obs_regs<NCH, F32>(ob0, f, ev0, lane);
     }
 
     int *s_chain = reinterpret_cast<int *>(smem + 136);
@@ -1405,7 +1405,7 @@ __device__ __forceinline__ void worker_body(const FwdDev &f, const ChainsDev &cs
                 for (int ev = ev0; ev < f.E; ev += 8 * W) {
                     const int evn = ev + 8 * W;
                     if (evn < f.E) {
-                        load_obs_regs<NCH>(ob_nxt, f, evn, lane);
+                        load_obs_regs<NCH, F32>(ob_nxt, f, evn, lane);
                         nx = ld_agent(hyp + 3 * evn); ny = ld_agent(hyp + 3 * evn + 1); nz = ld_agent(hyp + 3 * evn + 2);
                     }
                     const bool ov = ev == ov_evt;
@@ -1415,7 +1415,7 @@ __device__ __forceinline__ void worker_body(const FwdDev &f, const ChainsDev &cs
                     const double py[1] = {(ov && ov_cmp == 1) ? ov_val : cy};
                     const double pz[1] = {(ov && ov_cmp == 2) ? ov_val : cz};
                     double out[1];
-                    event_misfit<NCH, 1>(f, ob_cur, lane, st, px, py, pz, beta, q, out);
+                    event_misfit<NCH, 1, F32>(f, ob_cur, lane, st, px, py, pz, beta, q, out);
                     lane_acc += out[0];
                     ob_cur = ob_nxt; cx = nx; cy = ny; cz = nz;
                 }
@@ -1451,21 +1451,47 @@ __device__ __forceinline__ void worker_body(const FwdDev &f, const ChainsDev &cs
     }
 }
 
+// Probe of the peer-mapped inboxes (htm_chains_xchg_probe): one wave writes a token record into every rank's inbox and
+// waits (bounded, `ticks` of the 100 MHz clock) until the tokens of all ranks have arrived in its own -- the same
+// stores, loads and scopes exchange_records uses, so a mapping whose writes are not visible to a polling kernel is
+// found at set-up, not inside a run.  Token tags have the top bit set: no iteration number ever matches them.
+__global__ __launch_bounds__(64) void k_xchg_probe(ChainsDev cs, unsigned token, unsigned long long ticks, int *result)
+{
+    const int lane = threadIdx.x, np = cs.n_procs, G = cs.xg;
+    const unsigned tag = 0x80000000u | token;
+    if (lane < 2)
+        for (int q = 0; q < np; ++q)
+            st_sys(ld_const(cs.outbox + q) + (size_t)(0 * np + cs.rank) * G + lane, ((unsigned long long)tag << 32) | (unsigned)cs.rank);
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    bool ok = false;
+    for (;;) {
+        bool mine = true;
+        for (int r = lane >> 1; r < np; r += 32) {
+            const unsigned long long v = ld_sys(cs.inbox + (size_t)r * G + (lane & 1));
+            mine = mine && (unsigned)(v >> 32) == tag && (unsigned)v == (unsigned)r;
+        }
+        if (__all(mine)) { ok = true; break; }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > ticks) break;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    if (lane == 0) *result = ok ? 1 : 0;
+}
+
 // One launch = the chain master (block 0) + W full-evaluation workers (blocks 1..W), all resident.
 // `launch` = the host's count of k_mcmc launches of this chain set (1, 2, ...): orders and the quit word carry it, so
 // nothing a previous launch left in memory can be mistaken for this launch's.
-template <int NCH>
+template <int NCH, bool F32 = false>
 __global__ __launch_bounds__(512) void k_mcmc(FwdDev f, ChainsDev cs, int mode, int target_arg,
                                                const double *gathered, int ring_size, int wmax,
                                                unsigned long long launch)
 {
     if (blockIdx.x == 0) {
-        step_body<NCH, true>(f, cs, mode, target_arg, gathered, ring_size, wmax, launch);
+        step_body<NCH, true, F32>(f, cs, mode, target_arg, gathered, ring_size, wmax, launch);
         // every exit of the master comes through here (its returns are uniform over the block): release the workers
         __syncthreads();
         if (threadIdx.x == 0) st_agent(&cs.ps->quit, launch + 1ull);
     } else {
-        worker_body<NCH>(f, cs, launch);
+        worker_body<NCH, F32>(f, cs, launch);
     }
 }
 

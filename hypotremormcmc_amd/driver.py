@@ -103,13 +103,19 @@ def _has(params, key):
     return key in (params.values if isinstance(params, Param) else params)
 
 
+def _raw(params, key):
+    return (params.values if isinstance(params, Param) else params)[key]
+
+
 def build_rank(params, sta_x, sta_y, sta_z, obs, rank, n_procs=None, device=0, fwd=None, **caps):
     """Forward + ChainSet of one rank.  `obs` needs get_t_obs().. and make_initial_guess()."""
     n_sta, n_events = obs.n_sta, obs.n_events
     g = lambda k: _get(params, k)
     if fwd is None:
+        # optional key (not in the reference's grammar): forward_precision = fp32 | fp64; HTM_FORWARD_PRECISION overrides
+        prec = os.environ.get("HTM_FORWARD_PRECISION") or (str(_raw(params, "forward_precision")) if _has(params, "forward_precision") else "fp64")
         fwd = Forward(n_sta=n_sta, n_events=n_events, sta_x=sta_x, sta_y=sta_y, sta_z=sta_z, obs=obs,
-                      use_amp=g("use_amp"), use_time=g("use_time"), device=device)
+                      use_amp=g("use_amp"), use_time=g("use_time"), device=device, forward_precision=prec)
     x_mu, y_mu = obs.make_initial_guess()
     models, temps, rng = build_initial_models(params, n_sta, n_events, x_mu, y_mu, rank)
     cs = ChainSet(fwd, models, temps, rng.state, n_procs=n_procs if n_procs is not None else g("n_procs"),

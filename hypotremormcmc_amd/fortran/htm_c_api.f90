@@ -12,11 +12,13 @@ module htm_c_api
   public :: htm_chains_lik_count, htm_chains_lik_read, htm_chains_sample_count, htm_chains_sample_read
   public :: htm_chains_iterations_done
   public :: htm_chains_step_begin, htm_chains_swap_record_host, htm_chains_step_end_host, htm_chains_drain
-  public :: htm_chains_xchg_handle, htm_chains_xchg_connect, htm_chains_run_lockstep_direct, HTM_XCHG_HANDLE_BYTES
+  public :: htm_chains_xchg_handle, htm_chains_xchg_connect, htm_chains_xchg_probe, htm_chains_run_lockstep_direct
+  public :: HTM_XCHG_HANDLE_BYTES, HTM_COMM_ID_BYTES
+  public :: htm_comm_unique_id, htm_comm_create, htm_comm_destroy, htm_chains_run_lockstep_comm
   public :: htm_device_count, htm_quantiles
   public :: htm_chains_checkpoint_size, htm_chains_checkpoint_save, htm_chains_checkpoint_load
 
-  integer(c_size_t), parameter :: HTM_XCHG_HANDLE_BYTES = 64_c_size_t
+  integer(c_size_t), parameter :: HTM_XCHG_HANDLE_BYTES = 64_c_size_t, HTM_COMM_ID_BYTES = 128_c_size_t
 
   !> one `type model` group stacked over the chains of the rank (include/htm_hip.h: htm_model_init)
   type, bind(C) :: htm_model_init
@@ -179,6 +181,39 @@ module htm_c_api
        integer(c_size_t), value :: handle_bytes
        integer(c_int) :: rc
      end function htm_chains_xchg_connect
+     !> RCCL from Fortran (include/htm_hip.h): rank 0 draws the id, MPI_Bcast carries it, every rank creates its communicator
+     function htm_comm_unique_id(id, id_bytes) bind(C, name="htm_comm_unique_id") result(rc)
+       import :: c_int, c_char, c_size_t
+       character(kind=c_char), intent(out) :: id(*)
+       integer(c_size_t), value :: id_bytes
+       integer(c_int) :: rc
+     end function htm_comm_unique_id
+     function htm_comm_create(id, id_bytes, rank, n_ranks, device, comm) bind(C, name="htm_comm_create") result(rc)
+       import :: c_int, c_char, c_size_t, c_ptr
+       character(kind=c_char), intent(in) :: id(*)
+       integer(c_size_t), value :: id_bytes
+       integer(c_int), value :: rank, n_ranks, device
+       type(c_ptr), intent(out) :: comm
+       integer(c_int) :: rc
+     end function htm_comm_create
+     function htm_comm_destroy(comm) bind(C, name="htm_comm_destroy") result(rc)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: comm
+       integer(c_int) :: rc
+     end function htm_comm_destroy
+     function htm_chains_run_lockstep_comm(handle, n_iter, comm) bind(C, name="htm_chains_run_lockstep_comm") result(rc)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: handle, comm
+       integer(c_int), value :: n_iter
+       integer(c_int) :: rc
+     end function htm_chains_run_lockstep_comm
+     function htm_chains_xchg_probe(handle, token, seconds) bind(C, name="htm_chains_xchg_probe") result(rc)
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: handle
+       integer(c_int), value :: token
+       real(c_double), value :: seconds
+       integer(c_int) :: rc
+     end function htm_chains_xchg_probe
      function htm_chains_run_lockstep_direct(handle, n_iter) bind(C, name="htm_chains_run_lockstep_direct") result(rc)
        import :: c_int, c_ptr
        type(c_ptr), value :: handle

@@ -35,7 +35,7 @@ program hypo_tremor_mcmc_hip
   integer, allocatable :: win_id(:)
   double precision, allocatable :: x_mu(:), y_mu(:)
   integer :: n_events, n_sta, n_chains, i, j, io, id, ierr, rank, n_ranks
-  logical :: direct = .false.
+  logical :: direct = .false., want_rccl = .false.
   integer(c_int) :: n_dev
   real(c_double), allocatable :: rec(:), gathered(:)
   double precision :: dummy
@@ -186,6 +186,10 @@ program hypo_tremor_mcmc_hip
     call get_environment_variable("HTM_XCHG", env, elen, estat)
     if (estat == 0 .and. elen > 0) then
        if (env(1:1) == "0") ok_mine = 0
+       if (env(1:min(4, elen)) == "rccl") then      ! HTM_XCHG=rccl: one RCCL all-gather per iteration from this Fortran host
+          ok_mine = 0
+          want_rccl = .true.
+       end if
     end if
     if (ok_mine == 1) then
        if (htm_chains_xchg_handle(chains, xh, HTM_XCHG_HANDLE_BYTES) /= 0) ok_mine = 0
@@ -196,6 +200,11 @@ program hypo_tremor_mcmc_hip
        if (htm_chains_xchg_connect(chains, xh_all, HTM_XCHG_HANDLE_BYTES) /= 0) ok_mine = 0
     end if
     call mpi_allreduce(ok_mine, ok_all, 1, MPI_INTEGER, MPI_MIN, MPI_COMM_WORLD, ierr)
+    if (ok_all == 1) then     ! every rank mapped every peer: prove that writes into the inboxes reach a polling kernel
+       call mpi_barrier(MPI_COMM_WORLD, ierr)
+       if (htm_chains_xchg_probe(chains, 1_c_int, 10.0_c_double) /= 0) ok_mine = 0
+       call mpi_allreduce(ok_mine, ok_all, 1, MPI_INTEGER, MPI_MIN, MPI_COMM_WORLD, ierr)
+    end if
     direct = ok_all == 1
   end block
   if (direct) then
@@ -206,6 +215,42 @@ program hypo_tremor_mcmc_hip
              & "htm_chains_run_lockstep_direct")
         if (rank == 0) call summary(min(i + 1000, para%n_iter))
      end do
+  end if
+  ! Second transport: RCCL driven from Fortran.  Rank 0 draws RCCL's unique id, MPI_Bcast carries it, every rank joins the
+  ! communicator (ncclCommInitRank), and the loop of htm_chains_run_lockstep -- one k_mcmc launch + one ncclAllGather
+  ! per iteration, all enqueued from C on the chains' stream -- runs without a host synchronisation per iteration.
+  ! RCCL wants one device per rank (it refuses two ranks on one GPU): then the program falls through to the next path.
+  if (.not. direct .and. want_rccl) then
+     block
+       character(kind=c_char) :: cid(HTM_COMM_ID_BYTES)
+       type(c_ptr) :: comm
+       integer :: ok_mine, ok_all
+       cid = c_null_char
+       ok_mine = 1
+       if (rank == 0) then
+          if (htm_comm_unique_id(cid, HTM_COMM_ID_BYTES) /= 0) ok_mine = 0
+       end if
+       call mpi_bcast(cid, int(HTM_COMM_ID_BYTES), MPI_BYTE, 0, MPI_COMM_WORLD, ierr)
+       call mpi_allreduce(ok_mine, ok_all, 1, MPI_INTEGER, MPI_MIN, MPI_COMM_WORLD, ierr)
+       if (ok_all == 1) then
+          if (htm_comm_create(cid, HTM_COMM_ID_BYTES, int(rank, c_int), int(n_ranks, c_int), &
+               & int(htm_default_device, c_int), comm) /= 0) ok_mine = 0
+          call mpi_allreduce(ok_mine, ok_all, 1, MPI_INTEGER, MPI_MIN, MPI_COMM_WORLD, ierr)
+       end if
+       if (ok_all == 1) then
+          if (rank == 0) print *, "swap exchange: RCCL all-gather per iteration"
+          do i = 0, para%n_iter - 1, 1000
+             call check(htm_chains_run_lockstep_comm(chains, int(min(1000, para%n_iter - i), c_int), comm), &
+                  & "htm_chains_run_lockstep_comm")
+             call check(htm_chains_drain(chains), "htm_chains_drain")
+             if (rank == 0) call summary(min(i + 1000, para%n_iter))
+          end do
+          direct = .true.         ! (the iterations are done)
+          call check(htm_comm_destroy(comm), "htm_comm_destroy")
+       else if (rank == 0) then
+          print *, "RCCL communicator not available: ", htm_error_message()
+       end if
+     end block
   end if
   allocate(rec(4 + 2 * n_chains), gathered((4 + 2 * n_chains) * n_ranks))
   do i = 1, merge(0, para%n_iter, direct)      ! compatibility path: records staged through host memory + MPI_Allgather

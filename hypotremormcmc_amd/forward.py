@@ -38,7 +38,8 @@ class ObsArrays:
 
 
 class Forward:
-    def __init__(self, n_sta, n_events, sta_x, sta_y, sta_z, obs, use_amp=True, use_time=True, device=0):
+    def __init__(self, n_sta, n_events, sta_x, sta_y, sta_z, obs, use_amp=True, use_time=True, device=0,
+                 forward_precision="fp64"):
         self._lib = _lib.load()
         self.n_sta, self.n_events = int(n_sta), int(n_events)
         n = self.n_sta * self.n_events
@@ -49,6 +50,9 @@ class Forward:
                                            int(bool(use_time)), int(bool(use_amp)), int(device), C.byref(h)))
         self.handle = h
         self.device = device
+        self.forward_precision = "fp64"
+        if str(forward_precision).lower() in ("fp32", "f32", "single"):
+            self.set_precision("fp32")
 
     def close(self):
         if getattr(self, "handle", None):
@@ -60,6 +64,13 @@ class Forward:
             self.close()
         except Exception:
             pass
+
+    def set_precision(self, precision: str):
+        """"fp32": single-precision forward model with fp64 sums and accept (BASELINE configs[4]; statistical
+        tolerance, no reference counterpart); "fp64": the reference's arithmetic.  Before creating chains."""
+        fp32 = str(precision).lower() in ("fp32", "f32", "single")
+        check(self._lib.htm_forward_set_precision(self.handle, int(fp32)))
+        self.forward_precision = "fp32" if fp32 else "fp64"
 
     def set_stream(self, hip_stream: int):
         """Use the caller's HIP stream (0 = the default stream, e.g. torch.cuda.current_stream().cuda_stream)."""

@@ -115,6 +115,16 @@ class TorchWorld:
                 ok = 0
         flag = torch.tensor([ok], dtype=torch.int32, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        if not int(flag.item()):
+            return False
+        # every rank mapped every peer: prove that writes into the inboxes reach a polling kernel (all ranks probe together)
+        dist.barrier(group=self.group)
+        try:
+            cs.xchg_probe(token=1, seconds=10.0)
+        except Exception:
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
         return bool(int(flag.item()))
 
     def _try_direct_rccl(self):

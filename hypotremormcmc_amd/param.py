@@ -11,7 +11,10 @@ from __future__ import annotations
 import os
 
 INT_KEYS = {"n_procs", "n_pair_thred", "n_iter", "n_burn", "n_interval", "n_chains", "n_cool"}
-STR_KEYS = {"station_file", "time_id_file", "cmp1", "cmp2", "data_dir", "filename_format"}
+STR_KEYS = {"station_file", "time_id_file", "cmp1", "cmp2", "data_dir", "filename_format",
+            # optional key of this build, not in the reference's grammar (its files never contain it):
+            # forward_precision = fp64 | fp32  (fp32 forward model with fp64 sums and accept, BASELINE configs[4])
+            "forward_precision"}
 BOOL_KEYS = {"solve_vs", "solve_qs", "solve_t_corr", "solve_a_corr", "use_amp", "use_time"}
 REAL_KEYS = {
     "t_win_conv", "t_win_corr", "t_step_corr", "alpha", "vs_min", "vs_max", "b_min", "b_max", "z_guess",

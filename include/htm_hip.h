@@ -61,6 +61,14 @@ int htm_forward_create(int n_sta, int n_events,
                        int use_time, int use_amp, int device, htm_forward **out);
 int htm_forward_destroy(htm_forward *h);
 
+/* fp32 forward / fp64 accept (BASELINE configs[4]; the reference is fp64 throughout, so this mode has no reference
+ * counterpart and carries a STATISTICAL tolerance): forward_fp32 = 1 makes every kernel of this
+ * handle compute the synthetic travel times / amplitudes (src/cls_forward.f90:115-118, :201-204 -- distance, sqrt,
+ * division, log) in single precision and stream the observations as float (half the bytes of a full
+ * evaluation); the weighted demean sums (:125-132), residuals, the misfit sum (:281-299) and the Metropolis
+ * decision (src/cls_mcmc.f90:194-199) stay fp64.  n_sta <= 128.  Call before htm_chains_create. */
+int htm_forward_set_precision(htm_forward *h, int forward_fp32);
+
 /* Run all work of this handle (and of chain sets created from it) on the caller's HIP stream, e.g.
  * torch's current stream so that RCCL collectives enqueued by torch.distributed order with our kernels.
  * hip_stream is used as given: NULL is HIP's default (null) stream -- which is what torch's default
@@ -183,13 +191,30 @@ int htm_chains_step_end_host(htm_chains *hc, const double *gathered_records);
  *   xchg_connect  takes the handles of ALL ranks in rank order (exchanged by the caller: MPI_Allgather, or
  *                 torch.distributed's all-gather over RCCL), `handle_bytes` apart, and maps the peers' inboxes
  *                 (n_procs == 1: handles may be NULL);
+ *   xchg_probe    (optional, collective) a one-wave kernel writes a token into every rank's inbox and waits up to
+ *                 `seconds` for all ranks' tokens in its own: proves at set-up that peer writes reach a polling kernel;
  *   run_lockstep_direct  n_iter lock-step iterations; synchronous; every rank must call it with the same n_iter.
  * The transport-agnostic step_begin / step_end protocol above stays available (and is what a rank falls back to
  * when peer mapping is refused). */
 #define HTM_XCHG_HANDLE_BYTES 64
 int htm_chains_xchg_handle(htm_chains *hc, void *handle, size_t handle_bytes);
 int htm_chains_xchg_connect(htm_chains *hc, const void *handles, size_t handle_bytes);
+int htm_chains_xchg_probe(htm_chains *hc, unsigned token, double seconds);
 int htm_chains_run_lockstep_direct(htm_chains *hc, int n_iter);
+/* RCCL from a C / Fortran host (no Python): a communicator over librccl, bound at run time with dlopen (inside a
+ * PyTorch process its copy is reused).  Rank 0 calls htm_comm_unique_id and broadcasts the HTM_COMM_ID_BYTES bytes
+ * (MPI_Bcast in hypo_tremor_mcmc_hip_mpi); every rank then calls htm_comm_create (collective = ncclCommInitRank).
+ * htm_chains_run_lockstep_comm = htm_chains_run_lockstep with ncclAllGather on that communicator: the swap of
+ * src/cls_parallel.f90:100-216 as one RCCL all-gather per iteration, enqueued on the chains' stream without host
+ * synchronisation.  htm_comm_allgather moves any bytes (e.g. the inboxes' IPC handles of the persistent lock-step).
+ * RCCL wants one device per rank: two ranks on one GPU are refused by ncclCommInitRank. */
+typedef struct htm_comm htm_comm;
+#define HTM_COMM_ID_BYTES 128
+int htm_comm_unique_id(void *id, size_t id_bytes);
+int htm_comm_create(const void *id, size_t id_bytes, int rank, int n_ranks, int device, htm_comm **out);
+int htm_comm_destroy(htm_comm *c);
+int htm_comm_allgather(htm_comm *c, const void *d_send, void *d_recv, size_t bytes_per_rank, void *hip_stream);
+int htm_chains_run_lockstep_comm(htm_chains *hc, int n_iter, htm_comm *c);
 int htm_chains_sync(htm_chains *hc);        /* wait + raise device-side error flags */
 int htm_chains_drain(htm_chains *hc);       /* sync + move device record buffers to host memory */
 

@@ -137,6 +137,29 @@ def test_fortran_mpi_driver_reproduces_reference_outputs(name, transport, tmp_pa
     assert [int(r_[2].split()[1]) for r_ in rows] == fx["n_accept"].tolist()
 
 
+def test_fortran_mpi_driver_over_rccl(tmp_path):
+    """HTM_XCHG=rccl: the Fortran MPI program reaches RCCL through the C ABI (htm_comm_*: unique id from rank 0 over
+    MPI_Bcast, ncclCommInitRank, one ncclAllGather per iteration enqueued from C).  One rank here -- RCCL refuses two
+    ranks on one device, and this box has one GPU; the multi-rank protocol itself is covered by the transports above."""
+    mpiexec = "/opt/conda/bin/mpiexec"
+    exe = os.path.join(BUILD, "hypo_tremor_mcmc_hip_mpi")
+    if not (os.path.exists(exe) and os.path.exists(mpiexec)):
+        pytest.skip("MPI driver or MPICH not present on this box")
+    fx, data, params = load_case("c2")
+    synth.write_dataset(str(tmp_path), data)
+    synth.write_param_file(str(tmp_path / "run.in"), **{k: v for k, v in params.items()})
+    r = subprocess.run([mpiexec, "-np", "1", exe, "run.in"], cwd=tmp_path, timeout=300, capture_output=True, text=True,
+                       env=dict(os.environ, HTM_XCHG="rccl"))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert "swap exchange: RCCL" in r.stdout, r.stdout[-800:]
+    it, v = _records(tmp_path / "likelihood00.out", 1)
+    assert np.array_equal(it, fx["lik_iter_0"])
+    np.testing.assert_allclose(v[:, 0], fx["lik_0"], rtol=1e-9, atol=0)
+    rows = [ln.split('"') for ln in open(tmp_path / "proposal_count.txt")]
+    assert [int(r_[2].split()[0]) for r_ in rows] == fx["n_propose"].tolist()
+    assert [int(r_[2].split()[1]) for r_ in rows] == fx["n_accept"].tolist()
+
+
 @pytest.mark.parametrize("name", ["c1", "timeonly", "fixedcorr"])
 def test_fortran_statistics_program_writes_the_reference_stat_files(name, tmp_path):
     """hypo_tremor_statistics_hip on the sample files the reference's step 5 wrote (rebuilt from the fixture):

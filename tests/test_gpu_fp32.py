@@ -1,0 +1,129 @@
+"""GPU: the fp32-forward / fp64-accept mode (BASELINE configs[4]: 10 000 events x 128 stations, fp32 forward with
+fp64 accept; htm_forward_set_precision).
+
+The reference is fp64 throughout (src/cls_forward.f90), so this mode has no bit-level oracle: its tolerance is
+STATISTICAL and stated here.  What is single precision: the synthetic travel time and amplitude of a
+station-event pair (distance, sqrt, division, log; src/cls_forward.f90:115-118, :201-204) and the stored
+observations.  What stays fp64: coordinate differences, the weighted demean sums (:125-132), residuals, the misfit
+sum (:281-299), the Metropolis decision (src/cls_mcmc.f90:194-199) -- checked against the fp64 oracle:
+
+  T1  full log-likelihood: |L32 - L64| <= 3e-6 |L64|                    (random models, 1 000 x 64 and 10 000 x 128)
+  T2  single-event update: the ERROR of the log-likelihood difference a proposal is judged on,
+      e = (L32_new - L32_old) - (L64_new - L64_old), has |mean| <= 2e-3, rms <= 1e-2 over random proposals with
+      the sample file's step sizes -- three to four orders below the differences themselves (rms ~ 10) --
+  T3  and flips fewer than 0.5 % of Metropolis decisions made with common random numbers;
+  T4  chains: over a few hundred iterations at the configs[4] per-GPU shape (16 chains) the fp32 and the fp64 run
+      accept the same number of proposals per type within 4 binomial sigma + 2 % and their cold chains'
+      log-likelihoods agree to 2e-3 relative.
+The measured values are written to gpurun_out/fp32_tolerances.txt."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _note(line):
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "fp32_tolerances.txt"), "a") as fh:
+            fh.write(line + "\n")
+    except OSError:
+        pass
+
+
+def _forwards(data):
+    from hypotremormcmc_amd.forward import Forward
+    from hypotremormcmc_amd.obs_data import ObsData
+
+    obs = ObsData.from_arrays(data.sta_x, data.sta_y, data.t_obs, data.t_stdv, data.a_obs, data.a_stdv)
+    kw = dict(n_sta=data.n_sta, n_events=data.n_events, sta_x=data.sta_x, sta_y=data.sta_y, sta_z=data.sta_z, obs=obs)
+    return Forward(**kw), Forward(forward_precision="fp32", **kw)
+
+
+def _model(data, rng):
+    hypo = data.ev_xyz + rng.normal(0, 1.5, data.ev_xyz.shape)
+    hypo[:, 2] = np.abs(hypo[:, 2]) + 0.5
+    return (hypo.reshape(-1), rng.normal(0, 0.2, data.n_sta), 3.0 + rng.normal(0, 0.2), rng.normal(0, 0.02, data.n_sta),
+            250.0 + rng.normal(0, 30.0))
+
+
+@pytest.mark.parametrize("E,S,seed", [(1000, 64, 1), (10000, 128, 5)])
+def test_fp32_full_and_partial_likelihood_against_fp64(E, S, seed):
+    from hypotremormcmc_amd import synth
+    from oracle import oracle
+
+    data = synth.make_synthetic(E, S, seed)
+    f64, f32 = _forwards(data)
+    orc = oracle.Forward(data.sta_x, data.sta_y, data.sta_z, data.t_obs, data.t_stdv, data.a_obs, data.a_stdv, True, True)
+    rng = np.random.default_rng(100 + seed)
+    # ---- T1
+    worst = 0.0
+    for _ in range(4):
+        h, tc, vs, ac, qs = _model(data, rng)
+        L64, L32 = f64.calc_log_likelihood(h, tc, vs, ac, qs), f32.calc_log_likelihood(h, tc, vs, ac, qs)
+        Lo = orc.calc_log_likelihood(h, tc, vs, ac, qs)
+        assert abs(L64 - Lo) <= 1e-9 * abs(Lo)      # (the oracle's serial sum drifts ~1e-10 at 1.3 M terms)
+        worst = max(worst, abs(L32 - Lo) / abs(Lo))
+    _note(f"T1 {E}x{S}: max |L32 - L64| / |L64| = {worst:.3e}")
+    assert worst <= 3e-6
+    # ---- T2, T3: proposals of the sample file's step sizes (0.4 km horizontal, 0.4 km depth), common random numbers
+    h, tc, vs, ac, qs = _model(data, rng)
+    L0 = orc.calc_log_likelihood(h, tc, vs, ac, qs)
+    n = 400
+    err, dL = np.empty(n), np.empty(n)
+    for k in range(n):
+        evt = int(rng.integers(1, E + 1))
+        h2 = h.copy()
+        h2[3 * (evt - 1) + int(rng.integers(0, 3))] += rng.normal(0, 0.4)
+        d64 = orc.partially_update_log_likelihood(evt, h, L0, h2, tc, vs, ac, qs) - L0
+        d32 = f32.partially_update_log_likelihood(evt, h, L0, h2, tc, vs, ac, qs) - L0
+        d64g = f64.partially_update_log_likelihood(evt, h, L0, h2, tc, vs, ac, qs) - L0
+        assert abs(d64g - d64) <= 1e-9 * max(1.0, abs(d64)) + 1e-6     # L0 ~ 1e6: the difference carries ~1e-10 of it
+        err[k], dL[k] = d32 - d64, d64
+    logr = np.log(rng.uniform(size=n))
+    flips = np.mean((logr <= dL) != (logr <= dL + err))
+    _note(f"T2 {E}x{S}: error of the judged difference: mean {err.mean():.3e} rms {np.sqrt((err ** 2).mean()):.3e} max {np.abs(err).max():.3e}; "
+          f"differences rms {np.sqrt((dL ** 2).mean()):.3e}; T3 decision flips {flips:.4f}")
+    assert abs(err.mean()) <= 2e-3 and np.sqrt((err ** 2).mean()) <= 1e-2
+    assert flips <= 0.005
+
+
+def test_fp32_chains_at_the_configs4_shape_agree_statistically():
+    from hypotremormcmc_amd import driver, synth
+    from hypotremormcmc_amd.obs_data import ObsData
+
+    E, S, nc, n_iter = 10000, 128, 16, 400
+    data = synth.make_synthetic(E, S, 5)
+    obs = ObsData.from_arrays(data.sta_x, data.sta_y, data.t_obs, data.t_stdv, data.a_obs, data.a_stdv)
+    res = {}
+    for prec in ("fp64", "fp32"):
+        params = dict(synth.DEFAULT_PARAMS, n_procs=1, n_chains=nc, n_cool=4, n_iter=n_iter, n_burn=100, n_interval=4,
+                      forward_precision=prec)
+        fwd, cs = driver.build_rank(params, data.sta_x, data.sta_y, data.sta_z, obs, 0, n_procs=1)
+        assert fwd.forward_precision == prec
+        cs.run(n_iter)
+        it, ch, lk = cs.likelihood_trace()
+        res[prec] = dict(counts=cs.counts(), it=it, lk=lk, first=np.array([lk[i] for i in range(len(it)) if it[i] == 1]))
+        del cs, fwd
+    # the first iteration evaluates every chain's initial model in full: same models, so T1 applies to each record
+    a, b = res["fp64"]["first"], res["fp32"]["first"]
+    assert len(a) == len(b) > 0
+    rel0 = np.max(np.abs(a - b) / np.abs(a))
+    (p64, a64), (p32, a32) = res["fp64"]["counts"], res["fp32"]["counts"]
+    assert np.array_equal(p64, p32) or abs(int(p64.sum()) - int(p32.sum())) <= 0.02 * p64.sum()
+    lines = []
+    for k in range(7):
+        n = max(int(p64[k]), 1)
+        r64, r32 = a64[k] / n, a32[k] / max(int(p32[k]), 1)
+        tol = 4.0 * np.sqrt(max(r64 * (1 - r64), 0.05) / n) * np.sqrt(2.0) + 0.02
+        lines.append(f"type {k + 1}: proposed {int(p64[k])}/{int(p32[k])} accepted {int(a64[k])}/{int(a32[k])} (tolerance {tol:.3f})")
+        assert abs(r64 - r32) <= tol, lines[-1]
+    m64 = res["fp64"]["lk"][res["fp64"]["it"] > 200].mean(); m32 = res["fp32"]["lk"][res["fp32"]["it"] > 200].mean()
+    _note(f"T4 {E}x{S}x{nc}: first-iteration records max rel {rel0:.3e}; mean cold log-likelihood after 200 it fp64 {m64:.6e} fp32 {m32:.6e} "
+          f"(rel {abs(m64 - m32) / abs(m64):.3e}); " + "; ".join(lines))
+    assert rel0 <= 3e-6
+    assert abs(m64 - m32) <= 2e-3 * abs(m64)
