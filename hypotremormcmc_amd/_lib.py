@@ -138,7 +138,10 @@ def load():
         )
     _share_hip_runtime_with_torch()
     lib = C.CDLL(LIB_PATH)
+    older_build = os.environ.get("HTM_LIB") and os.environ.get("HTM_LIB_OLDER_BUILD") == "1"   # tools/ab.sh: A/B against a build of an older header
     for name, (res, args) in SIGNATURES.items():
+        if older_build and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)  # AttributeError if the header and the library disagree
         fn.restype = res
         fn.argtypes = args

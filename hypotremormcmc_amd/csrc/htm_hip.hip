@@ -223,12 +223,21 @@ int launch_mcmc(htm_chains *hc, int mode, int target, const double *gathered)
     htm_forward *h = hc->fwd;
     dim3 grid(1 + hc->dev.n_workers), block(512);
     const unsigned long long seq = ++hc->launch_seq;      // this chain set's k_mcmc launches, counted from 1
-    if (h->dev.fp32) {
-        if (h->nch == 1) hipLaunchKernelGGL((k_mcmc<1, true>), grid, block, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax, seq);
-        else hipLaunchKernelGGL((k_mcmc<2, true>), grid, block, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax, seq);
+#define HTM_LAUNCH_MCMC(N, F, L) hipLaunchKernelGGL((k_mcmc<N, F, L>), grid, block, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax, seq)
+    if (mode == MODE_LOCKRUN) {           // persistent lock-step: its own instantiations (the exchange is compiled into them only)
+        if (h->dev.fp32) { if (h->nch == 1) HTM_LAUNCH_MCMC(1, true, true); else HTM_LAUNCH_MCMC(2, true, true); }
+        else if (h->nch == 1) HTM_LAUNCH_MCMC(1, false, true);
+        else if (h->nch == 2) HTM_LAUNCH_MCMC(2, false, true);
+        else HTM_LAUNCH_MCMC(0, false, true);
         HIPCHK(hipGetLastError());
         return HTM_OK;
     }
+    if (h->dev.fp32) {
+        if (h->nch == 1) HTM_LAUNCH_MCMC(1, true, false); else HTM_LAUNCH_MCMC(2, true, false);
+        HIPCHK(hipGetLastError());
+        return HTM_OK;
+    }
+#undef HTM_LAUNCH_MCMC
     switch (h->nch) {
     case 1: hipLaunchKernelGGL(k_mcmc<1>, grid, block, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax, seq); break;
     case 2: hipLaunchKernelGGL(k_mcmc<2>, grid, block, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax, seq); break;
@@ -853,7 +862,13 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
         // block carries the master's LDS size).  Workers take events round-robin, so fewer of them only take longer.
         const void *fn = h->dev.fp32 ? (h->nch == 1 ? (const void *)k_mcmc<1, true> : (const void *)k_mcmc<2, true>)
                          : h->nch == 1 ? (const void *)k_mcmc<1> : h->nch == 2 ? (const void *)k_mcmc<2> : (const void *)k_mcmc<0>;
-        if (hc->step_smem > 48 * 1024) HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hc->step_smem));
+        const void *fn_lock = h->dev.fp32 ? (h->nch == 1 ? (const void *)k_mcmc<1, true, true> : (const void *)k_mcmc<2, true, true>)
+                              : h->nch == 1 ? (const void *)k_mcmc<1, false, true> : h->nch == 2 ? (const void *)k_mcmc<2, false, true>
+                              : (const void *)k_mcmc<0, false, true>;
+        if (hc->step_smem > 48 * 1024) {
+            HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hc->step_smem));
+            HIPCHK(hipFuncSetAttribute(fn_lock, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hc->step_smem));
+        }
         int per_cu = 0, n_cu = 0;
         HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 512, hc->step_smem));
         HIPCHK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device));

@@ -57,6 +57,8 @@ struct StepShared {
     int catchup;                  // written between the barriers: the LDS window must be extended first
     int rolep_iter;               // role P has finished for this iteration (see step_body)
     double xrec[4 + 2 * kMaxChains];   // MODE_LOCKRUN: this rank's swap record of the iteration (what goes to every rank's inbox)
+    int xdone;                    // MODE_LOCKRUN: the swap of every iteration <= xdone has been applied (see exchange_finish)
+    int xstop, xspec;             // decided by role V: this rank asks for a stop; the next iteration starts before the swap is known
     Ctrl c;
 #ifdef HTM_STAMPS
     unsigned long long stamp_acc[96];   // diagnostic cycle accounting of this launch, flushed to ChainsDev::stamps at its end
@@ -75,6 +77,10 @@ struct Ring {                     // LDS window of the stream rings, index = rel
     int mir_n;
     bool mir_steps;
 };
+
+constexpr int kPassRestart = -1;  // chain_pass: the swap of the iteration before moved this rank's stream position: start again
+constexpr int kPassAbort = -2;    // chain_pass: the job stops (or failed) after the iteration before: this step is not taken
+
 
 // one stream position in flight from the global rings to the LDS window
 struct PfRegs {
@@ -234,10 +240,11 @@ __device__ __forceinline__ bool metropolis(double L_new, double L_cur, double T,
 // worker blocks from HERE, by the chain's own wave, as soon as the proposed value is known: the order goes out
 // while the other chain waves are still in their partial updates, so the workers' round trip is hidden behind
 // them.  The wave then collects the workers' partial sums, judges and commits like any other step.
-template <int NCH, bool PERSIST, bool F32>
+template <int NCH, bool PERSIST, bool F32, bool LOCK>
 __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, StepShared &sh, const Ring &rg,
                                           const double *s_sx, const double *s_sy, const double *s_sz, int c,
-                                          int p, int iter, int lane, unsigned long long launch, bool wait_rolep, bool first_pass)
+                                          int p, int iter, int lane, unsigned long long launch, bool wait_rolep, bool first_pass,
+                                          int xwait, int base_used)
 {
     const int M = rg.mask;
 #ifdef HTM_STAMPS
@@ -301,7 +308,12 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
     const double x_old = rl_f64(gathered_v, 0);
     const double hx = rl_f64(gathered_v, 1), hy = rl_f64(gathered_v, 2), hz = rl_f64(gathered_v, 3);
     const double beta = rl_f64(gathered_v, 4), q = rl_f64(gathered_v, 5);
-    const double T = sh.temp[c], L_cur = sh.L[c];
+    const double L_cur = sh.L[c];
+    // MODE_LOCKRUN runs the front of this step -- loads, proposal, misfit -- while the swap records of the iteration
+    // before (xwait) are still travelling between the ranks.  Everything that needs the swap's outcome waits HERE, just
+    // before the decision: the temperature, whether the job goes on, and where this rank's stream really stands (the
+    // judge_swap draw is taken from the stream of the rank owning chain 1 of the pair, cls_parallel.f90:163).
+    // Wave 0 collects the records and decides the swap before its own step (step_body); the others wait for its word here.
     CSTAMP(0);   // decode + load issue
     const double x_new = x_old + g * step;                      // cls_model.f90:172
     const double da = x_new - mu, db = x_old - mu;
@@ -336,8 +348,7 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
             else event_misfit_generic<2>(f, ev, lane, s_sx, s_sy, s_sz, tc, ac, 0, -1, 0.0, px, py, pz, beta, q, out);
             CSTAMP(2);   // event_misfit
             L_new = L_cur + wave_sum1(out[0] - out[1]);
-            acc = metropolis(L_new, L_cur, T, lpr, r, logr) ? 1 : 0;
-            CSTAMP(3);   // final sum + decision
+            CSTAMP(3);   // final sum
         } else {
             need_full = 1;
             if constexpr (PERSIST) {
@@ -471,13 +482,19 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
                         }
                     }
                 }
-                acc = metropolis(L_new, L_cur, T, lpr, r, logr) ? 1 : 0;
 #ifdef HTM_STAMPS
                 if (lane == 0 && cs.stamps) atomicAdd(&cs.stamps[25], __builtin_amdgcn_s_memrealtime());
 #endif
             }
         }
     }
+    if (LOCK && xwait >= 0) {
+        while (__hip_atomic_load(&sh.xdone, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < xwait) __builtin_amdgcn_s_sleep(1);
+        if (sh.c.stop || sh.c.err) return kPassAbort;
+        if (sh.base != base_used) return kPassRestart;
+    }
+    const double T = sh.temp[c];
+    if (ok != 0 && (partial || PERSIST)) acc = metropolis(L_new, L_cur, T, lpr, r, logr) ? 1 : 0;   // cls_mcmc.f90:193-203
     if (lane == 0) {
         const int cool = (T < 1.0 + kEps) ? 1 : 0;
         Proposal &pr = sh.prop[c];
@@ -819,14 +836,19 @@ __device__ __forceinline__ void apply_swap(const ChainsDev &cs, StepShared &sh, 
 // has failed.  Inbox parity = iter & 1: a rank can be at most one iteration ahead of the slowest one.
 constexpr int kXLoads = 8;        // granule loads per lane in flight while polling
 
-__device__ __forceinline__ void exchange_records(const ChainsDev &cs, StepShared &sh, double *s_gath, int iter, int lane,
-                                                 int wmax)
+// every thread, after the roles of an iteration: does this rank ask everybody to stop after it?
+__device__ __forceinline__ bool want_stop_now(const ChainsDev &cs, const StepShared &sh, int wmax)
+{
+    const int nc = cs.n_chains;
+    return sh.c.n_lik + 2 * nc > cs.cap_lik || sh.c.n_smp + 2 * nc > cs.cap_smp || sh.avail < sh.base + 3 * wmax;
+}
+
+// one wave: this rank's record of iteration `iter` into every rank's inbox
+__device__ __forceinline__ void exchange_post(const ChainsDev &cs, const StepShared &sh, int iter, int lane, bool want_stop)
 {
     const int nc = cs.n_chains, RW = 4 + 2 * nc, G = cs.xg, np = cs.n_procs, par = iter & 1;
     const unsigned tag = (unsigned)iter;
-    const bool want_stop = sh.c.n_lik + 2 * nc > cs.cap_lik || sh.c.n_smp + 2 * nc > cs.cap_smp || sh.avail < sh.base + 3 * wmax;
     const unsigned ctl = (want_stop ? 1u : 0u) | (sh.c.err ? 2u : 0u);
-    // ---- post
     for (int g0 = 0; g0 < G; g0 += 64) {
         const int g = g0 + lane;
         if (g < G) {
@@ -840,7 +862,14 @@ __device__ __forceinline__ void exchange_records(const ChainsDev &cs, StepShared
             for (int q = 0; q < np; ++q) st_sys(ld_const(cs.outbox + q) + (size_t)(par * np + cs.rank) * G + g, v);
         }
     }
-    // ---- collect: rows of 64 granules, row = (rank r, chunk k of its record); kXLoads rows in flight
+}
+
+// the same wave, later: wait for the n_procs records of iteration `iter`, decide the swap, publish sh.xdone = iter.
+// Rows of 64 granules, row = (rank r, chunk k of its record); kXLoads rows in flight.
+__device__ __forceinline__ void exchange_finish(const ChainsDev &cs, StepShared &sh, double *s_gath, int iter, int lane)
+{
+    const int nc = cs.n_chains, RW = 4 + 2 * nc, G = cs.xg, np = cs.n_procs, par = iter & 1;
+    const unsigned tag = (unsigned)iter;
     const unsigned long long *in = cs.inbox + (size_t)par * np * G;
     unsigned *gu = reinterpret_cast<unsigned *>(s_gath);
     const int chunks = (G + 63) >> 6, rows = np * chunks;
@@ -878,13 +907,14 @@ __device__ __forceinline__ void exchange_records(const ChainsDev &cs, StepShared
         }
     }
     const bool stop_any = __ballot((anyctl & 1u) != 0) != 0ull, err_any = __ballot((anyctl & 2u) != 0) != 0ull;
-    if (lane == 0 && !dead) {
-        if (sh.c.err == 0 && sh.c.stage == ST_WAIT_SWAP) {
+    if (lane == 0) {
+        if (!dead && sh.c.err == 0 && sh.c.stage == ST_WAIT_SWAP) {
             apply_swap(cs, sh, s_gath);                         // iteration done; rank1 consumed its judge_swap draw
             sh.base = (int)(sh.c.spos - sh.origin);
         }
         if (stop_any && sh.c.stop == 0) sh.c.stop = 3;          // everybody leaves after this iteration
         if (err_any && sh.c.err == 0) sh.c.err = -11;           // a peer reported a failure
+        __hip_atomic_store(&sh.xdone, iter, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 }
 
@@ -904,7 +934,7 @@ __device__ __forceinline__ void exchange_records(const ChainsDev &cs, StepShared
 // PERSIST = true: this is block 0 of a k_mcmc launch; full evaluations are handed to the worker blocks of the
 // same launch through PSync (no kernel exit).  PERSIST = false: the kernel exits at a hand-over and k_full runs
 // as its own launch (fallback path, also used for profiling the two stages separately).
-template <int NCH, bool PERSIST, bool F32>
+template <int NCH, bool PERSIST, bool F32, bool LOCK>
 __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, int mode, int target_arg,
                                           const double *gathered, int ring_size, int wmax, unsigned long long launch)
 {
@@ -937,7 +967,7 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
     const bool lockstep = (mode != MODE_RUN);
     // MODE_LOCKRUN: lock-step with the swap records exchanged inside the launch (exchange_records) -- the kernel stays
     // resident over the iterations, so the orders of role P and the LDS state carry over as in the single-rank loop
-    const bool lockrun = PERSIST && mode == MODE_LOCKRUN;
+    constexpr bool lockrun = PERSIST && LOCK;          // (the host launches the LOCK instantiation with MODE_LOCKRUN only)
     const bool rolep_on = PERSIST && (!lockstep || lockrun);
     double *rec = lockrun ? sh.xrec : cs.swap_rec;
     // helper roles between the barriers: validation+bookkeeping on wave 0, records and swap on other waves
@@ -982,6 +1012,7 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
         const long long av = sh.hop_end - sh.c.spos;
         sh.avail = av > (1 << 30) ? (1 << 30) : (int)av;
         sh.fill = 0; sh.base = 0; sh.redo = -1; sh.sw_do = 0; sh.catchup = 0; sh.rolep_iter = -1;
+        sh.xdone = sh.c.iter_done; sh.xstop = 0; sh.xspec = 0;
     }
     for (int c = tid; c < kMaxChains; c += blockDim.x) { sh.pre_p[0][c] = -1; sh.pre_p[1][c] = -1; sh.redone[c] = 0; }
     {
@@ -1033,11 +1064,16 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
 
     bool have_prev = false;          // an iteration has completed in this launch (role P has something to look at)
     int fill_next = 0;               // wave_P: window extent staged in the last roles phase, published before the next barrier A
+    int it_local = sh.c.iter_done;   // iterations through their roles in this rank (MODE_LOCKRUN: the last one's swap may be pending)
+    bool xpend = false;              // MODE_LOCKRUN: the records of iteration it_local are posted, its swap not yet decided
+    bool leave = false;
     for (;;) {
-        const int iter = sh.c.iter_done + 1;
+        const int iter = it_local + 1;
         if (__builtin_expect(!resume, 1)) {
             // ---------------- anything left to do? ---------------------------------------------------
-            if (sh.c.iter_done >= sh.c.iter_target || sh.c.stop || sh.c.err) break;
+            // (xpend: iteration `iter` starts on the bet that the job goes on -- role V made sure that neither the target
+            // nor this rank's buffers end it; sh.c is being updated by the wave that decides the swap, nobody reads it here)
+            if (!(lockrun && xpend) && (sh.c.iter_done >= sh.c.iter_target || sh.c.stop || sh.c.err)) break;
             if (sh.c.n_lik + nc > cs.cap_lik || sh.c.n_smp + nc > cs.cap_smp) {
                 __syncthreads();
                 if (tid == 0) { if (lockstep) sh.c.err = -5; else sh.c.stop = 1; }
@@ -1072,6 +1108,9 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
                 const int pf_limit = min(min(sh.base + 4 * wmax, sh.avail), sh.base + rg.mask + 1 - 8);   // two iterations + their swaps ahead (role P)
                 int p = 0;
                 bool have_p = false;
+                // the swap of the iteration before: wave 0 waits for the ranks' records and decides it, then takes its own
+                // step; the other waves are in their steps' fronts meanwhile and ask for the outcome at their decisions
+                if constexpr (lockrun) { if (xpend && first && wave == 0) exchange_finish(cs, sh, s_gath, iter - 1, lane); }
                 for (int c = wave; c < nc; c += NW) {
                     if (c < redo) continue;
                     if (__builtin_expect(!first, 0)) {
@@ -1084,11 +1123,22 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
                             sh.pre_p[0][c] = -1; sh.pre_p[1][c] = -1;
                         }
                         p = sh.start_fix[c];                                // corrected by the validation
-                    } else if (!have_p) {                                   // optimistic start: c steps after base
-                        p = c == 0 ? sh.base : sh.base + rg.hop[(sh.base & rg.mask) * kHops + c - 1];
+                    }                                                       // else: optimistic start, c steps after base (below)
+                    int base_used = sh.base;
+                    if (first && !have_p) p = c == 0 ? base_used : base_used + rg.hop[(base_used & rg.mask) * kHops + c - 1];
+                    int xw = (lockrun && xpend && first && !have_p) ? iter - 1 : -1;       // the wave's first step of the iteration waits for the swap
+                    int r;
+                    for (;;) {
+                        r = chain_pass<NCH, PERSIST, F32, LOCK>(f, cs, sh, rg, s_sx, s_sy, s_sz, c, p, iter, lane, launch,
+                                                          have_prev && rolep_on, first, xw, base_used);
+                        if (r != kPassRestart) break;
+                        // the swap took its judge draw from THIS rank's stream: every step of the iteration starts elsewhere
+                        base_used = sh.base;
+                        p = hop_ahead(rg, base_used, c);
+                        xw = -1;
                     }
-                    p = chain_pass<NCH, PERSIST, F32>(f, cs, sh, rg, s_sx, s_sy, s_sz, c, p, iter, lane, launch,
-                                                 have_prev && rolep_on, first);
+                    if (r == kPassAbort) break;                                 // the job stops after the iteration before
+                    p = r;
                     have_p = true;
                     if (NW > 1 && c + NW < nc) p += rg.hop[(p & rg.mask) * kHops + NW - 2];   // skip NW-1 steps
                 }
@@ -1105,6 +1155,12 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
 #endif
                 __syncthreads();                                            // ---- barrier A
                 STAMP(2);   // passes
+                if (lockrun && xpend) {
+                    // every wave has heard about the swap of the iteration before; if that iteration was the last one
+                    // (a rank asked for a stop, or failed) no step of this one was taken: leave
+                    xpend = false;
+                    if (sh.c.stop || sh.c.err) { leave = true; __syncthreads(); break; }
+                }
                 if (wave == wave_P && first) {
                     // one wave without a role keeps the LDS window of the stream ahead while the roles run: 64 more
                     // positions per iteration; the memory latency hides behind the roles phase
@@ -1146,6 +1202,15 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
                                 sh.c.swap_i1 = i1; sh.c.swap_i2 = i2; sh.c.swap_r = sr; sh.c.swap_logr = slr;
                                 sh.c.spos = sh.origin + pos;     // RNG commit: draws consumed so far
                                 sh.base = pos;
+                                if constexpr (lockrun) {
+                                    // rank 0 drew the pair itself: it knows already whether the judge draw will be its own
+                                    if (cs.rank == 0 && i1 >= 0 && i1 / nc == 0) sh.base = pos + 1;
+                                    // (role R is adding this iteration's records meanwhile: at most nc of each)
+                                    const bool my_stop = sh.c.n_lik + 3 * nc > cs.cap_lik || sh.c.n_smp + 3 * nc > cs.cap_smp ||
+                                                         sh.avail < pos + 4 * wmax;
+                                    sh.xstop = my_stop ? 1 : 0;
+                                    sh.xspec = (!my_stop && iter < sh.c.iter_target && sh.c.err == 0 && v.mf == 0) ? 1 : 0;
+                                }
                                 sh.redo = -1;
                                 sh.catchup = (sh.fill < pos + wmax) ? 1 : 0;
                                 sh.c.n_full = __popcll(v.mf);
@@ -1168,6 +1233,7 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
                 redo = sh.redo;
                 first = false;
             }
+            if (leave) break;
             if (sh.redo == -2) {                 // aborted: take everything back, retry in the next launch
                 for (int c = wave; c < nc; c += NW)
                     if (lane == 0) undo_chain(cs, sh, rg, c);
@@ -1196,12 +1262,22 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
             resume = false;
         }
         // ---------------- after the barrier: swap + records of the chains this wave owns ---------------
-        if (lockrun) {
-            // the exchange first (it is what the other ranks wait for), the records of wave 0's chains after it
-            if (wave == 0) exchange_records(cs, sh, s_gath, iter, lane, wmax);
+        if constexpr (lockrun) {
+            // this rank's record goes out first (it is what the other ranks wait for).  Then either the next iteration
+            // starts at once and learns the swap at its first decision (xspec, the usual case), or -- last iteration of the
+            // launch -- wave 0 waits for the records here and everybody meets at barrier C.
+            const bool spec = sh.xspec != 0;
+            if (wave == 0) {
+                exchange_post(cs, sh, iter, lane, sh.xstop != 0);
+                if (!spec) exchange_finish(cs, sh, s_gath, iter, lane);
+            }
+            for (int c = wave; c < nc; c += NW) post_chain(cs, sh, c, iter, lane);
+            if (!spec) __syncthreads();                           // ---- barrier C
+            xpend = spec;
+        } else {
+            for (int c = wave; c < nc; c += NW) post_chain(cs, sh, c, iter, lane);
         }
-        for (int c = wave; c < nc; c += NW) post_chain(cs, sh, c, iter, lane);
-        if (lockrun) __syncthreads();                             // ---- barrier C: temperatures and base of the next iteration
+        it_local = iter;
         have_prev = true;
         STAMP(4);   // post
         if (lockstep && !lockrun) break;
@@ -1225,7 +1301,7 @@ template <int NCH, bool F32 = false>
 __global__ __launch_bounds__(512) void k_step(FwdDev f, ChainsDev cs, int mode, int target_arg,
                                                const double *gathered, int ring_size, int wmax)
 {
-    step_body<NCH, false, F32>(f, cs, mode, target_arg, gathered, ring_size, wmax, 0ull);
+    step_body<NCH, false, F32, false>(f, cs, mode, target_arg, gathered, ring_size, wmax, 0ull);
 }
 
 // Worker block of a k_mcmc launch: waits for work orders of its own launch and evaluates its event tile of
@@ -1480,13 +1556,13 @@ __global__ __launch_bounds__(64) void k_xchg_probe(ChainsDev cs, unsigned token,
 // One launch = the chain master (block 0) + W full-evaluation workers (blocks 1..W), all resident.
 // `launch` = the host's count of k_mcmc launches of this chain set (1, 2, ...): orders and the quit word carry it, so
 // nothing a previous launch left in memory can be mistaken for this launch's.
-template <int NCH, bool F32 = false>
+template <int NCH, bool F32 = false, bool LOCK = false>
 __global__ __launch_bounds__(512) void k_mcmc(FwdDev f, ChainsDev cs, int mode, int target_arg,
                                                const double *gathered, int ring_size, int wmax,
                                                unsigned long long launch)
 {
     if (blockIdx.x == 0) {
-        step_body<NCH, true, F32>(f, cs, mode, target_arg, gathered, ring_size, wmax, launch);
+        step_body<NCH, true, F32, LOCK>(f, cs, mode, target_arg, gathered, ring_size, wmax, launch);
         // every exit of the master comes through here (its returns are uniform over the block): release the workers
         __syncthreads();
         if (threadIdx.x == 0) st_agent(&cs.ps->quit, launch + 1ull);

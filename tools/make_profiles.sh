@@ -3,7 +3,7 @@
 #   tools/make_profiles.sh <tag>        e.g. r01_c  -> gpurun_out/<tag>_{kernel_stats.csv,pmc_summary.txt,bench.json}
 # Counter passes are separate runs with --kernel-trace only (MI355X_MICROARCH.md, HBM section).
 set -e
-TAG=${1:-r01_x}
+TAG=${1:-r02_x}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
@@ -12,10 +12,10 @@ rm -rf "$OUT/prof_${TAG}_stats" "$OUT/prof_${TAG}_fetch" "$OUT/prof_${TAG}_write
 rocprofv3 --kernel-trace --stats -d "$OUT/prof_${TAG}_stats" -o st --output-format csv -- python3 "$ROOT/bench.py" --no-cpu-baseline \
     > "$OUT/${TAG}_bench_under_rocprof.json" 2> "$OUT/prof_${TAG}_stats.log"
 echo "stats pass done"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/prof_${TAG}_fetch" -o pf --output-format csv -- python3 "$ROOT/bench.py" --steps 4000 --warmup 500 --no-cpu-baseline \
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/prof_${TAG}_fetch" -o pf --output-format csv -- python3 "$ROOT/bench.py" --steps 4 --warmup 1 --iters-per-step 1024 --no-cpu-baseline \
     > /dev/null 2> "$OUT/prof_${TAG}_fetch.log"
 echo "fetch pass done"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/prof_${TAG}_write" -o pw --output-format csv -- python3 "$ROOT/bench.py" --steps 4000 --warmup 500 --no-cpu-baseline \
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/prof_${TAG}_write" -o pw --output-format csv -- python3 "$ROOT/bench.py" --steps 4 --warmup 1 --iters-per-step 1024 --no-cpu-baseline \
     > /dev/null 2> "$OUT/prof_${TAG}_write.log"
 echo "write pass done"
 python3 "$ROOT/bench.py" > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
@@ -25,7 +25,7 @@ out, tag = sys.argv[1], sys.argv[2]
 st = glob.glob(os.path.join(out, f"prof_{tag}_stats", "**", "*kernel_stats.csv"), recursive=True)
 if st:
     open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w").write(open(st[0]).read())
-lines = [f"# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace -- python3 bench.py --steps 4000 --warmup 500 --no-cpu-baseline",
+lines = [f"# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace -- python3 bench.py --steps 4 --warmup 1 --iters-per-step 1024 --no-cpu-baseline",
          "# per dispatch, KB as rocprofv3 reports them (raw; gfx950: FETCH_SIZE counts 64 B per 128-B request of wide coalesced reads)",
          "%-34s %-11s %7s %14s %12s %14s" % ("kernel", "counter", "count", "mean", "min", "max")]
 for sub, cname in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
@@ -65,8 +65,8 @@ for sub, cname in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
                 v.append(float(row["Counter_Value"]))
     tot[sub] = sum(v)
     nl = len(v)
-iters = 4500
-json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace), python3 bench.py --steps 4000 --warmup 500 --no-cpu-baseline",
+iters = 5 * 1024
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace), python3 bench.py --steps 4 --warmup 1 --iters-per-step 1024 --no-cpu-baseline",
            "kernel": "htm::k_mcmc<1>", "iterations": iters, "launches": nl,
            "fetch_kb_raw_total": tot["fetch"], "write_kb_total": tot["write"],
            "fetch_bytes_per_iteration_raw": tot["fetch"] * 1024 / iters, "write_bytes_per_iteration": tot["write"] * 1024 / iters,
