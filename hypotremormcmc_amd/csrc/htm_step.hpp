@@ -309,6 +309,7 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
     const double hx = rl_f64(gathered_v, 1), hy = rl_f64(gathered_v, 2), hz = rl_f64(gathered_v, 3);
     const double beta = rl_f64(gathered_v, 4), q = rl_f64(gathered_v, 5);
     const double L_cur = sh.L[c];
+    double T = sh.temp[c];           // (LOCK: read again after the swap is known, below)
     // MODE_LOCKRUN runs the front of this step -- loads, proposal, misfit -- while the swap records of the iteration
     // before (xwait) are still travelling between the ranks.  Everything that needs the swap's outcome waits HERE, just
     // before the decision: the temperature, whether the job goes on, and where this rank's stream really stands (the
@@ -348,7 +349,8 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
             else event_misfit_generic<2>(f, ev, lane, s_sx, s_sy, s_sz, tc, ac, 0, -1, 0.0, px, py, pz, beta, q, out);
             CSTAMP(2);   // event_misfit
             L_new = L_cur + wave_sum1(out[0] - out[1]);
-            CSTAMP(3);   // final sum
+            if constexpr (!LOCK) acc = metropolis(L_new, L_cur, T, lpr, r, logr) ? 1 : 0;      // (LOCK: decided below, once the swap is known)
+            CSTAMP(3);   // final sum + decision
         } else {
             need_full = 1;
             if constexpr (PERSIST) {
@@ -367,7 +369,8 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
                 const double prev_xold = sh.prop[c].x_old, prev_xnew = sh.prop[c].x_new;
                 unsigned long long tk = 0;
                 if (lane == 0) {
-                    tk = pre ? (unsigned long long)sh.pre_tag[par][c] : (atomicAdd(&sh.c.jobs_total, 1ull) % 0x7ffffffeull + 1ull);   // 1 .. 2^31 - 2: never 0 (= empty slot)
+                    tk = pre ? (unsigned long long)sh.pre_tag[par][c] : ((atomicAdd(&sh.c.jobs_total, 1ull) + 1ull) & 0x7fffffffull);
+                    if (tk == 0) tk = 0x7fffffffull;      // 0 = empty slot: never a tag (the counter wraps after 2^31 orders)
                     sh.pre_p[par][c] = -1;
                     // an order of its own overwrites the workers' sums of any order role P has out for this chain (a repeated
                     // pass can bring the step back to the position such an order was written for): those are void now
@@ -482,6 +485,7 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
                         }
                     }
                 }
+                if constexpr (!LOCK) acc = metropolis(L_new, L_cur, T, lpr, r, logr) ? 1 : 0;
 #ifdef HTM_STAMPS
                 if (lane == 0 && cs.stamps) atomicAdd(&cs.stamps[25], __builtin_amdgcn_s_memrealtime());
 #endif
@@ -492,9 +496,9 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
         while (__hip_atomic_load(&sh.xdone, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < xwait) __builtin_amdgcn_s_sleep(1);
         if (sh.c.stop || sh.c.err) return kPassAbort;
         if (sh.base != base_used) return kPassRestart;
+        T = sh.temp[c];
     }
-    const double T = sh.temp[c];
-    if (ok != 0 && (partial || PERSIST)) acc = metropolis(L_new, L_cur, T, lpr, r, logr) ? 1 : 0;   // cls_mcmc.f90:193-203
+    if constexpr (LOCK) { if (ok != 0) acc = metropolis(L_new, L_cur, T, lpr, r, logr) ? 1 : 0; }   // cls_mcmc.f90:193-203
     if (lane == 0) {
         const int cool = (T < 1.0 + kEps) ? 1 : 0;
         Proposal &pr = sh.prop[c];
@@ -741,11 +745,15 @@ __device__ __forceinline__ PreOrder role_prepublish_plan(const ChainsDev &cs, St
     // position (a Rayleigh rejection shifted the stream) or around another step in between (stale2); (b) addressed to the
     // iteration that just ended and never taken (its step started elsewhere and was a partial update).  The workers are
     // told (void_slot) unless a new order of this chain overwrites the slot right now.
-    const bool staleA = in && sh.pre_p[par1][c] != -1 && (sh.pre_p[par1][c] != pA || stale2);
-    const bool deadB = in && sh.pre_p[par2][c] != -1;
-    if (staleA && mode != 1) sh.pre_p[par1][lane] = -1;               // (a one-ahead order replaces the entry)
-    if (deadB && mode != 2) sh.pre_p[par2][lane] = -1;
-    if ((staleA || deadB) && mode == 0 && !(haveA && in)) void_slot(cs, c);   // haveA: the slot holds a live order (written after the dead one)
+    // (Orders are rare -- one step in ten -- so the books are usually empty: one ballot skips all of this.)
+    const int bookA = in ? sh.pre_p[par1][c] : -1, bookB = in ? sh.pre_p[par2][c] : -1;
+    if (__builtin_expect(__ballot(bookA != -1 || bookB != -1) != 0ull, 0)) {
+        const bool staleA = bookA != -1 && (bookA != pA || stale2);
+        const bool deadB = bookB != -1;
+        if (staleA && mode != 1) sh.pre_p[par1][lane] = -1;           // (a one-ahead order replaces the entry)
+        if (deadB && mode != 2) sh.pre_p[par2][lane] = -1;
+        if ((staleA || deadB) && mode == 0 && !(haveA && in)) void_slot(cs, c);   // haveA: the slot holds a live order (written after the dead one)
+    }
     if (lane < nc && mode) {
         const int par = mode == 2 ? par2 : par1;
         sh.pre_p[par][lane] = pJ; sh.pre_tag[par][lane] = po.tag; sh.pre_mode[par][lane] = mode; sh.pre_pa[par][lane] = pA;
@@ -1126,19 +1134,24 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
                     }                                                       // else: optimistic start, c steps after base (below)
                     int base_used = sh.base;
                     if (first && !have_p) p = c == 0 ? base_used : base_used + rg.hop[(base_used & rg.mask) * kHops + c - 1];
-                    int xw = (lockrun && xpend && first && !have_p) ? iter - 1 : -1;       // the wave's first step of the iteration waits for the swap
-                    int r;
-                    for (;;) {
-                        r = chain_pass<NCH, PERSIST, F32, LOCK>(f, cs, sh, rg, s_sx, s_sy, s_sz, c, p, iter, lane, launch,
-                                                          have_prev && rolep_on, first, xw, base_used);
-                        if (r != kPassRestart) break;
-                        // the swap took its judge draw from THIS rank's stream: every step of the iteration starts elsewhere
-                        base_used = sh.base;
-                        p = hop_ahead(rg, base_used, c);
-                        xw = -1;
+                    [[maybe_unused]] int xw = (lockrun && xpend && first && !have_p) ? iter - 1 : -1;       // the wave's first step of the iteration waits for the swap
+                    if constexpr (lockrun) {
+                        int r;
+                        for (;;) {
+                            r = chain_pass<NCH, PERSIST, F32, LOCK>(f, cs, sh, rg, s_sx, s_sy, s_sz, c, p, iter, lane, launch,
+                                                              have_prev && rolep_on, first, xw, base_used);
+                            if (r != kPassRestart) break;
+                            // the swap took its judge draw from THIS rank's stream: every step of the iteration starts elsewhere
+                            base_used = sh.base;
+                            p = hop_ahead(rg, base_used, c);
+                            xw = -1;
+                        }
+                        if (r == kPassAbort) break;                             // the job stops after the iteration before
+                        p = r;
+                    } else {
+                        p = chain_pass<NCH, PERSIST, F32, LOCK>(f, cs, sh, rg, s_sx, s_sy, s_sz, c, p, iter, lane, launch,
+                                                          have_prev && rolep_on, first, -1, 0);
                     }
-                    if (r == kPassAbort) break;                                 // the job stops after the iteration before
-                    p = r;
                     have_p = true;
                     if (NW > 1 && c + NW < nc) p += rg.hop[(p & rg.mask) * kHops + NW - 2];   // skip NW-1 steps
                 }
