@@ -131,17 +131,24 @@ __device__ __forceinline__ void prefetch_all(const ChainsDev &cs, StepShared &sh
     __syncthreads();
 }
 
-__device__ __forceinline__ ModelDev pick_model(const ChainsDev &cs, int type)
+// The rank's parameter vector is ONE allocation per field, groups in proposal-type order [vs | t_corr | qs | a_corr | hypo],
+// each [n_chains][nx] (ChainsDev::xall and friends): every element is base + integer offset -- scalar arithmetic on one
+// pointer instead of a choice between the five ModelDev windows (fewer kernel arguments alive in the loop).
+struct GroupOff { int tc, qs, ac, hy, nh; };
+__device__ __forceinline__ GroupOff group_offsets(const ChainsDev &cs)
 {
-    ModelDev m;
-    const bool v = type == 1, t = type == 2, q = type == 3, a = type == 4;
-    m.x = v ? cs.vs.x : t ? cs.tc.x : q ? cs.qs.x : a ? cs.ac.x : cs.hypo.x;
-    m.mu = v ? cs.vs.mu : t ? cs.tc.mu : q ? cs.qs.mu : a ? cs.ac.mu : cs.hypo.mu;
-    m.sigma = v ? cs.vs.sigma : t ? cs.tc.sigma : q ? cs.qs.sigma : a ? cs.ac.sigma : cs.hypo.sigma;
-    m.step = v ? cs.vs.step : t ? cs.tc.step : q ? cs.qs.step : a ? cs.ac.step : cs.hypo.step;
-    m.ptype = v ? cs.vs.ptype : t ? cs.tc.ptype : q ? cs.qs.ptype : a ? cs.ac.ptype : cs.hypo.ptype;
-    m.nx = (v || q) ? 1 : (t || a) ? cs.S : cs.hypo.nx;
-    return m;
+    const int nc = cs.n_chains, S = cs.S;
+    GroupOff g;
+    g.tc = nc; g.qs = nc + nc * S; g.ac = 2 * nc + nc * S; g.hy = 2 * nc + 2 * nc * S; g.nh = 3 * cs.E;
+    return g;
+}
+// element idx of chain c's model of proposal type `type` (1 vs, 2 t_corr, 3 qs, 4 a_corr, 5..7 hypo)
+__device__ __forceinline__ int elem_offset(const ChainsDev &cs, int type, int c, int idx)
+{
+    const GroupOff g = group_offsets(cs);
+    const int goff = type == 1 ? 0 : type == 2 ? g.tc : type == 3 ? g.qs : type == 4 ? g.ac : g.hy;
+    const int gnx = (type == 1 || type == 3) ? 1 : (type == 2 || type == 4) ? cs.S : g.nh;
+    return goff + c * gnx + idx;
 }
 
 // inclusive prefix sum over the 64 lanes (DPP row_shr scan + row_bcast, ints)
@@ -259,7 +266,7 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
     const int evt = __builtin_amdgcn_readfirstlane(dec.z), dec_w = __builtin_amdgcn_readfirstlane(dec.w);
     const double g = rg.pg[p & M], r_ring = rg.pr[p & M], logr_ring = rg.plogr[p & M];
     const bool partial = evt > 0 && iter > 1;       // hypo_tremor_mcmc.f90:246
-    const int nc_ = cs.n_chains, S_ = cs.S, nh = cs.hypo.nx;
+    const int nc_ = cs.n_chains, S_ = cs.S, nh = 3 * cs.E;
     const int off_tc = nc_, off_qs = nc_ + nc_ * S_, off_ac = 2 * nc_ + nc_ * S_, off_hy = 2 * nc_ + 2 * nc_ * S_;
     const int goff = type == 1 ? 0 : type == 2 ? off_tc : type == 3 ? off_qs : type == 4 ? off_ac : off_hy;
     const int gnx = (type == 1 || type == 3) ? 1 : (type == 2 || type == 4) ? S_ : nh;
@@ -275,7 +282,7 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
     const double gathered_v = cs.xall[goffs];
     const double mu = ld_const(cs.muall + o), sigma = ld_const(cs.sgall + o), step = ld_const(cs.stall + o);
     const int ptype = ld_const(cs.ptall + o);
-    const double *tc = cs.tc.x + (size_t)c * cs.S, *ac = cs.ac.x + (size_t)c * cs.S;
+    const double *tc = cs.xall + off_tc + c * S_, *ac = cs.xall + off_ac + c * S_;
     StaRegs<(NCH > 0 ? NCH : 1)> st;
     ObsRegs<(NCH > 0 ? NCH : 1)> ob;
     if (partial) {
@@ -298,7 +305,7 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
                 dhint = true;
                 d_e = __builtin_amdgcn_readfirstlane(pv.evt) - 1;
                 const int vzd = opaque_zero();
-                const double *hypd = cs.hypo.x + (size_t)c * cs.hypo.nx + 3 * d_e;
+                const double *hypd = cs.xall + off_hy + c * nh + 3 * d_e;
                 d_ex = ld_state(hypd, vzd); d_ey = ld_state(hypd + 1, vzd); d_ez = ld_state(hypd + 2, vzd);
                 load_sta_regs<NCH>(st, f.S, lane, s_sx, s_sy, s_sz, tc, ac, 0, -1, 0.0);
                 load_obs_regs<NCH, F32>(ob, f, d_e, lane);
@@ -465,7 +472,7 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
                             const int e = prev_evt - 1, pcmp = prev_idx - 3 * e;
                             if (!(dhint && d_e == e)) {        // the hint missed: request the inputs now
                                 const int vzd = opaque_zero();
-                                const double *hyp = cs.hypo.x + (size_t)c * cs.hypo.nx + 3 * e;
+                                const double *hyp = cs.xall + off_hy + c * nh + 3 * e;
                                 d_ex = ld_state(hyp, vzd); d_ey = ld_state(hyp + 1, vzd); d_ez = ld_state(hyp + 2, vzd);
                                 load_sta_regs<NCH>(st, f.S, lane, s_sx, s_sy, s_sz, tc, ac, 0, -1, 0.0);
                                 load_obs_regs<NCH, F32>(ob, f, e, lane);
@@ -526,10 +533,8 @@ __device__ __forceinline__ void undo_chain(const ChainsDev &cs, StepShared &sh, 
     Proposal &pr = sh.prop[c];
     if (pr.cool) sh.np[c * 7 + pr.type - 1] -= 1;
     if (pr.accepted) {
-        const ModelDev Mo = pick_model(cs, pr.type);
-        double *px = Mo.x + (size_t)c * Mo.nx + pr.idx;
-        st_agent(px, pr.x_old);
-        const long long om = px - cs.xall;
+        const int om = elem_offset(cs, pr.type, c, pr.idx);
+        st_agent(cs.xall + om, pr.x_old);
         if (om < rg.mir_n) rg.mx[om] = pr.x_old;
         sh.L[c] = pr.L_old;
         cs.L[c] = pr.L_old;
@@ -724,9 +729,9 @@ __device__ __forceinline__ PreOrder role_prepublish_plan(const ChainsDev &cs, St
     // wait until they read that value back
     const Proposal pr = sh.prop[c];
     const int ct = pr.type;
-    const int o_hy = 2 * nc + 2 * nc * S_ + c * cs.hypo.nx;
+    const int o_hy = 2 * nc + 2 * nc * S_ + c * 3 * cs.E;
     const int cgoff = ct == 1 ? 0 : ct == 2 ? nc : ct == 3 ? nc + nc * S_ : ct == 4 ? 2 * nc + nc * S_ : 2 * nc + 2 * nc * S_;
-    const int cgnx = (ct == 1 || ct == 3) ? 1 : (ct == 2 || ct == 4) ? S_ : cs.hypo.nx;
+    const int cgnx = (ct == 1 || ct == 3) ? 1 : (ct == 2 || ct == 4) ? S_ : 3 * cs.E;
     const unsigned long long xb = (unsigned long long)__double_as_longlong(x_new);
     const unsigned long long cb = (unsigned long long)__double_as_longlong(pr.x_new);
     // two-ahead: the workers wait for the commit of the iteration that just ended by reading its value back; the step in
@@ -788,18 +793,19 @@ __device__ __forceinline__ void post_chain(const ChainsDev &cs, StepShared &sh, 
         if (sl >= 0) { cs.lik_iter[sl] = iter; cs.lik_chain[sl] = c; cs.lik_val[sl] = sh.L[c]; }
     }
     if (ss >= 0) {
-        const int nh = cs.hypo.nx, S = cs.S, rec = nh + 2 * S + 2;
+        const GroupOff go = group_offsets(cs);
+        const int nh = go.nh, S = cs.S, rec = nh + 2 * S + 2;
         double *dst = cs.smp_data + (size_t)ss * rec;
-        const double *hx = cs.hypo.x + (size_t)c * nh;
+        const double *hx = cs.xall + go.hy + (size_t)c * nh;
         const int vz = opaque_zero();
         for (int k = lane; k < nh; k += 64) dst[k] = ld_state(hx + k, vz);
         for (int k = lane; k < S; k += 64) {
-            dst[nh + k] = ld_state(cs.tc.x + (size_t)c * S + k, vz);
-            dst[nh + S + k] = ld_state(cs.ac.x + (size_t)c * S + k, vz);
+            dst[nh + k] = ld_state(cs.xall + go.tc + (size_t)c * S + k, vz);
+            dst[nh + S + k] = ld_state(cs.xall + go.ac + (size_t)c * S + k, vz);
         }
         if (lane == 0) {
-            dst[nh + 2 * S] = ld_state(cs.vs.x + c, vz);
-            dst[nh + 2 * S + 1] = ld_state(cs.qs.x + c, vz);
+            dst[nh + 2 * S] = ld_state(cs.xall + c, vz);
+            dst[nh + 2 * S + 1] = ld_state(cs.xall + go.qs + c, vz);
             cs.smp_iter[ss] = iter; cs.smp_chain[ss] = c;
         }
     }
@@ -1057,8 +1063,7 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
                 pr.L_new = -wave_sum1(acc) - f.const_sum;      // cls_forward.f90:277-300
                 pr.accepted = metropolis(pr.L_new, sh.L[c], sh.temp[c], pr.lpr, pr.r_judge, pr.logr_judge) ? 1 : 0;
                 if (lane == 0 && pr.accepted) {                // cls_mcmc.f90:207-219
-                    const ModelDev Mo = pick_model(cs, pr.type);
-                    st_agent(Mo.x + (size_t)c * Mo.nx + pr.idx, pr.x_new);
+                    st_agent(cs.xall + elem_offset(cs, pr.type, c, pr.idx), pr.x_new);
                     sh.L[c] = pr.L_new;
                     cs.L[c] = pr.L_new;
                     if (pr.cool) sh.na[c * 7 + pr.type - 1] += 1;
@@ -1208,8 +1213,8 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
                                 FullEntry *en = &cs.desc->e[slot];
                                 en->chain = lane; en->type = pr.type; en->idx = pr.idx; en->pad = 0;
                                 en->x_new = pr.x_new;
-                                en->beta = pr.type == 1 ? pr.x_new : ld_state(cs.vs.x + lane, vz);
-                                en->q = pr.type == 3 ? pr.x_new : ld_state(cs.qs.x + lane, vz);
+                                en->beta = pr.type == 1 ? pr.x_new : ld_state(cs.xall + lane, vz);
+                                en->q = pr.type == 3 ? pr.x_new : ld_state(cs.xall + (cs.n_chains + cs.n_chains * cs.S) + lane, vz);
                             }
                             if (lane == 0) {
                                 sh.c.swap_i1 = i1; sh.c.swap_i2 = i2; sh.c.swap_r = sr; sh.c.swap_logr = slr;
@@ -1466,15 +1471,16 @@ __device__ __forceinline__ void worker_body(const FwdDev &f, const ChainsDev &cs
             const double ov_val = __longlong_as_double((long long)(((unsigned long long)s_job[1] << 32) | s_job[2]));
             // vs and qs of the evaluated model: chain state unless they are the proposal (same round of loads as
             // the corrections and the event coordinates below)
-            const double beta_c = ld_agent(cs.vs.x + m), q_c = ld_agent(cs.qs.x + m);
+            const GroupOff go = group_offsets(cs);
+            const double beta_c = ld_agent(cs.xall + m), q_c = ld_agent(cs.xall + go.qs + m);
             const double beta = type == 1 ? ov_val : beta_c, q = type == 3 ? ov_val : q_c;
             int ov_kind = 0, ov_idx = -1, ov_evt = -1, ov_cmp = 0;
-            const int r_off = (int)s_job[6] - 1 - (2 * cs.n_chains + 2 * cs.n_chains * cs.S + m * cs.hypo.nx);
+            const int r_off = (int)s_job[6] - 1 - (go.hy + m * go.nh);
             const int r_evt = s_job[6] ? r_off / 3 : -1, r_cmp = s_job[6] ? r_off - 3 * (r_off / 3) : 0;
             if (type == 2 || type == 4) { ov_kind = type; ov_idx = idx; }
             else if (type >= 5) { ov_evt = idx / 3; ov_cmp = idx - 3 * ov_evt; }
-            const double *hyp = cs.hypo.x + (size_t)m * cs.hypo.nx;
-            const double *tc = cs.tc.x + (size_t)m * cs.S, *ac = cs.ac.x + (size_t)m * cs.S;
+            const double *hyp = cs.xall + go.hy + (size_t)m * go.nh;
+            const double *tc = cs.xall + go.tc + (size_t)m * cs.S, *ac = cs.xall + go.ac + (size_t)m * cs.S;
             double lane_acc = 0.0;
             if constexpr (NCH > 0) {
 #pragma unroll
