@@ -135,8 +135,8 @@ struct ObsRegs {
     double pst, psa;     // sum_j precision(j, event), time and amplitude
 };
 
-template <int NCH, bool F32 = false>
-__device__ __forceinline__ void load_obs_regs(ObsRegs<NCH> &ob, const FwdDev &f, int ev, int lane)
+template <int NCH, bool F32 = false, class FW>
+__device__ __forceinline__ void load_obs_regs(ObsRegs<NCH> &ob, const FW &f, int ev, int lane)
 {
     const size_t base = (size_t)ev * (size_t)f.S;
 #pragma unroll
@@ -158,8 +158,8 @@ __device__ __forceinline__ void load_obs_regs(ObsRegs<NCH> &ob, const FwdDev &f,
     ob.psa = f.use_amp ? ld_const(f.psum_a + ev) : 1.0;
 }
 
-template <int NCH, int NPOS, bool F32 = false>
-__device__ __forceinline__ void event_misfit(const FwdDev &f, const ObsRegs<NCH> &ob, int lane,
+template <int NCH, int NPOS, bool F32 = false, class FW>
+__device__ __forceinline__ void event_misfit(const FW &f, const ObsRegs<NCH> &ob, int lane,
                                              const StaRegs<NCH> &st, const double (&px)[NPOS],
                                              const double (&py)[NPOS], const double (&pz)[NPOS], double beta,
                                              double q, double (&out)[NPOS])
@@ -241,8 +241,8 @@ __device__ __forceinline__ void event_misfit(const FwdDev &f, const ObsRegs<NCH>
 
 // Generic-S fallback (n_sta > 64*4): strides over stations, recomputing the synthetics in the second
 // pass instead of holding them in registers.
-template <int NPOS>
-__device__ __forceinline__ void event_misfit_generic(const FwdDev &f, int ev, int lane,
+template <int NPOS, class FW>
+__device__ __forceinline__ void event_misfit_generic(const FW &f, int ev, int lane,
                                                      const double *s_sx, const double *s_sy,
                                                      const double *s_sz, const double *tc,
                                                      const double *ac, int ov_kind, int ov_idx,

@@ -223,26 +223,20 @@ int launch_mcmc(htm_chains *hc, int mode, int target, const double *gathered)
     htm_forward *h = hc->fwd;
     dim3 grid(1 + hc->dev.n_workers), block(512);
     const unsigned long long seq = ++hc->launch_seq;      // this chain set's k_mcmc launches, counted from 1
-#define HTM_LAUNCH_MCMC(N, F, L) hipLaunchKernelGGL((k_mcmc<N, F, L>), grid, block, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax, seq)
-    if (mode == MODE_LOCKRUN) {           // persistent lock-step: its own instantiations (the exchange is compiled into them only)
-        if (h->dev.fp32) { if (h->nch == 1) HTM_LAUNCH_MCMC(1, true, true); else HTM_LAUNCH_MCMC(2, true, true); }
-        else if (h->nch == 1) HTM_LAUNCH_MCMC(1, false, true);
-        else if (h->nch == 2) HTM_LAUNCH_MCMC(2, false, true);
-        else HTM_LAUNCH_MCMC(0, false, true);
-        HIPCHK(hipGetLastError());
-        return HTM_OK;
-    }
-    if (h->dev.fp32) {
-        if (h->nch == 1) HTM_LAUNCH_MCMC(1, true, false); else HTM_LAUNCH_MCMC(2, true, false);
-        HIPCHK(hipGetLastError());
-        return HTM_OK;
-    }
+#define HTM_LAUNCH_MCMC(N, F, K) hipLaunchKernelGGL((k_mcmc<N, F, K>), grid, block, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax, seq)
+#define HTM_LAUNCH_MCMC_K(K)                                                                              \
+    do {                                                                                                   \
+        if (h->dev.fp32) { if (h->nch == 1) HTM_LAUNCH_MCMC(1, true, K); else HTM_LAUNCH_MCMC(2, true, K); } \
+        else if (h->nch == 1) HTM_LAUNCH_MCMC(1, false, K);                                                \
+        else if (h->nch == 2) HTM_LAUNCH_MCMC(2, false, K);                                                \
+        else HTM_LAUNCH_MCMC(0, false, K);                                                                 \
+    } while (0)
+    // one instantiation per main loop: the single-rank loop, one lock-step iteration per launch, persistent lock-step
+    if (mode == MODE_RUN) HTM_LAUNCH_MCMC_K(0);
+    else if (mode == MODE_LOCKRUN) HTM_LAUNCH_MCMC_K(2);
+    else HTM_LAUNCH_MCMC_K(1);
+#undef HTM_LAUNCH_MCMC_K
 #undef HTM_LAUNCH_MCMC
-    switch (h->nch) {
-    case 1: hipLaunchKernelGGL(k_mcmc<1>, grid, block, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax, seq); break;
-    case 2: hipLaunchKernelGGL(k_mcmc<2>, grid, block, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax, seq); break;
-    default: hipLaunchKernelGGL(k_mcmc<0>, grid, block, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax, seq); break;
-    }
     HIPCHK(hipGetLastError());
     return HTM_OK;
 }
@@ -860,15 +854,13 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
         // Master and workers of a k_mcmc launch wait for each other, so every block must be RESIDENT: never ask for more
         // worker blocks than the device can hold next to the master (a partitioned or CU-masked GPU has fewer CUs; every
         // block carries the master's LDS size).  Workers take events round-robin, so fewer of them only take longer.
-        const void *fn = h->dev.fp32 ? (h->nch == 1 ? (const void *)k_mcmc<1, true> : (const void *)k_mcmc<2, true>)
-                         : h->nch == 1 ? (const void *)k_mcmc<1> : h->nch == 2 ? (const void *)k_mcmc<2> : (const void *)k_mcmc<0>;
-        const void *fn_lock = h->dev.fp32 ? (h->nch == 1 ? (const void *)k_mcmc<1, true, true> : (const void *)k_mcmc<2, true, true>)
-                              : h->nch == 1 ? (const void *)k_mcmc<1, false, true> : h->nch == 2 ? (const void *)k_mcmc<2, false, true>
-                              : (const void *)k_mcmc<0, false, true>;
-        if (hc->step_smem > 48 * 1024) {
-            HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hc->step_smem));
-            HIPCHK(hipFuncSetAttribute(fn_lock, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hc->step_smem));
-        }
+#define HTM_MCMC_FN(K) (h->dev.fp32 ? (h->nch == 1 ? (const void *)k_mcmc<1, true, K> : (const void *)k_mcmc<2, true, K>)                  \
+                        : h->nch == 1 ? (const void *)k_mcmc<1, false, K> : h->nch == 2 ? (const void *)k_mcmc<2, false, K> : (const void *)k_mcmc<0, false, K>)
+        const void *fns[3] = {HTM_MCMC_FN(0), HTM_MCMC_FN(1), HTM_MCMC_FN(2)};
+#undef HTM_MCMC_FN
+        const void *fn = fns[0];
+        if (hc->step_smem > 48 * 1024)
+            for (const void *g : fns) HIPCHK(hipFuncSetAttribute(g, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hc->step_smem));
         int per_cu = 0, n_cu = 0;
         HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 512, hc->step_smem));
         HIPCHK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device));

@@ -28,6 +28,22 @@
 
 namespace htm {
 
+// Kernel arguments are read where they are used, through references into the kernarg segment (constant address space:
+// scalar loads), re-based at the entry of every phase by an opaque move -- so the ~190 dwords of FwdDev + ChainsDev are
+// never all alive at once.  (Taken by value they are loaded at kernel entry, hoisted out of the iteration loop and
+// carried through it in spilled lanes: ~800 v_readlane reloads in the master's loop.)
+typedef const ChainsDev __attribute__((address_space(4))) &CsRef;
+typedef const FwdDev __attribute__((address_space(4))) &FwRef;
+typedef const StreamDev __attribute__((address_space(4))) &SdRef;
+template <class T>
+__device__ __forceinline__ const T __attribute__((address_space(4))) &rebase(const T __attribute__((address_space(4))) &r)
+{
+    const T __attribute__((address_space(4))) *p = &r;
+    asm volatile("" : "+s"(p));
+    return *p;
+}
+struct KArgLayout { FwdDev f; ChainsDev cs; };
+
 constexpr int kGathStage = 512;   // doubles of LDS for the gathered swap records (else they are read in place)
 
 struct StepShared {
@@ -83,21 +99,23 @@ constexpr int kPassAbort = -2;    // chain_pass: the job stops (or failed) after
 
 
 // one stream position in flight from the global rings to the LDS window
+typedef int i32x4 __attribute__((ext_vector_type(4)));      // (a plain vector: HIP's int4 class keeps temporaries in private memory)
 struct PfRegs {
     double U, LOGU, pg, pr, plogr;
-    int4 dec, sw, h0, h1;
+    i32x4 dec, sw, h0, h1;
     int p;                        // relative position, -1: nothing to store
 };
 
-__device__ __forceinline__ void pf_load(PfRegs &r, const ChainsDev &cs, const StepShared &sh, int p, int limit)
+__device__ __forceinline__ void pf_load(PfRegs &r, CsRef cs_, const StepShared &sh, int p, int limit)
 {
+    CsRef cs = rebase(cs_);
     r.p = -1;
     if (p < limit) {
-        const StreamDev &sd = cs.stream;
+        SdRef sd = cs.stream;
         const long long g = (sh.origin + p) & sd.mask;
         r.U = sd.U[g]; r.LOGU = sd.LOGU[g]; r.pg = sd.pg[g]; r.pr = sd.pr[g]; r.plogr = sd.plogr[g];
-        r.dec = sd.dec[g]; r.sw = sd.sw[g];
-        const int4 *hs = reinterpret_cast<const int4 *>(sd.hop + g * kHops);
+        r.dec = reinterpret_cast<const i32x4 *>(sd.dec)[g]; r.sw = reinterpret_cast<const i32x4 *>(sd.sw)[g];
+        const i32x4 *hs = reinterpret_cast<const i32x4 *>(sd.hop + g * kHops);
         r.h0 = hs[0]; r.h1 = hs[1];
         r.p = p;
     }
@@ -108,16 +126,17 @@ __device__ __forceinline__ void pf_store(const PfRegs &r, const Ring &rg)
     if (r.p >= 0) {
         const int l = r.p & rg.mask;
         rg.U[l] = r.U; rg.LOGU[l] = r.LOGU; rg.pg[l] = r.pg; rg.pr[l] = r.pr; rg.plogr[l] = r.plogr;
-        rg.dec[l] = r.dec; rg.sw[l] = r.sw;
-        int4 *hd = reinterpret_cast<int4 *>(rg.hop + l * kHops);
+        reinterpret_cast<i32x4 *>(rg.dec)[l] = r.dec; reinterpret_cast<i32x4 *>(rg.sw)[l] = r.sw;
+        i32x4 *hd = reinterpret_cast<i32x4 *>(rg.hop + l * kHops);
         hd[0] = r.h0; hd[1] = r.h1;
     }
 }
 
 // every thread of the workgroup: extend the LDS window to cover relative positions < target
 // (kernel start; later only if a long select_pair redraw run ate the look-ahead)
-__device__ __forceinline__ void prefetch_all(const ChainsDev &cs, StepShared &sh, const Ring &rg, int target)
+__device__ __forceinline__ void prefetch_all(CsRef cs_, StepShared &sh, const Ring &rg, int target)
 {
+    CsRef cs = rebase(cs_);
     if (target > sh.avail) target = sh.avail;
     if (target > sh.base + rg.mask + 1 - 8) target = sh.base + rg.mask + 1 - 8;
     const int fl = sh.fill;
@@ -135,16 +154,18 @@ __device__ __forceinline__ void prefetch_all(const ChainsDev &cs, StepShared &sh
 // each [n_chains][nx] (ChainsDev::xall and friends): every element is base + integer offset -- scalar arithmetic on one
 // pointer instead of a choice between the five ModelDev windows (fewer kernel arguments alive in the loop).
 struct GroupOff { int tc, qs, ac, hy, nh; };
-__device__ __forceinline__ GroupOff group_offsets(const ChainsDev &cs)
+__device__ __forceinline__ GroupOff group_offsets(CsRef cs_)
 {
+    CsRef cs = rebase(cs_);
     const int nc = cs.n_chains, S = cs.S;
     GroupOff g;
     g.tc = nc; g.qs = nc + nc * S; g.ac = 2 * nc + nc * S; g.hy = 2 * nc + 2 * nc * S; g.nh = 3 * cs.E;
     return g;
 }
 // element idx of chain c's model of proposal type `type` (1 vs, 2 t_corr, 3 qs, 4 a_corr, 5..7 hypo)
-__device__ __forceinline__ int elem_offset(const ChainsDev &cs, int type, int c, int idx)
+__device__ __forceinline__ int elem_offset(CsRef cs_, int type, int c, int idx)
 {
+    CsRef cs = rebase(cs_);
     const GroupOff g = group_offsets(cs);
     const int goff = type == 1 ? 0 : type == 2 ? g.tc : type == 3 ? g.qs : type == 4 ? g.ac : g.hy;
     const int gnx = (type == 1 || type == 3) ? 1 : (type == 2 || type == 4) ? cs.S : g.nh;
@@ -218,8 +239,9 @@ __device__ __forceinline__ unsigned long long ld_sys(const unsigned long long *p
 // a complete order -- a worker that has not looked yet never takes it, a worker waiting for the order's named commit
 // sees the slot change and drops it.  This is how a void order is SIGNALLED (the chain repeated a pass, or the order
 // was written for a stream position the step does not start at); nothing on the hand-off path is decided by a clock.
-__device__ __forceinline__ void void_slot(const ChainsDev &cs, int c)
+__device__ __forceinline__ void void_slot(CsRef cs_, int c)
 {
+    CsRef cs = rebase(cs_);
     for (int r = 0; r < cs.slot_rep; ++r) st_gran(cs.slots + (size_t)r * cs.slot_stride + c * kGranPerSlot, 0u, 0u);
 }
 
@@ -247,12 +269,15 @@ __device__ __forceinline__ bool metropolis(double L_new, double L_cur, double T,
 // worker blocks from HERE, by the chain's own wave, as soon as the proposed value is known: the order goes out
 // while the other chain waves are still in their partial updates, so the workers' round trip is hidden behind
 // them.  The wave then collects the workers' partial sums, judges and commits like any other step.
-template <int NCH, bool PERSIST, bool F32, bool LOCK>
-__device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, StepShared &sh, const Ring &rg,
+template <int NCH, bool PERSIST, bool F32, int MK>
+__device__ __forceinline__ int chain_pass(FwRef f_, CsRef cs_, StepShared &sh, const Ring &rg,
                                           const double *s_sx, const double *s_sy, const double *s_sz, int c,
                                           int p, int iter, int lane, unsigned long long launch, bool wait_rolep, bool first_pass,
                                           int xwait, int base_used)
 {
+    constexpr bool LOCK = MK == 2;         // persistent lock-step (the swap of the iteration before may still be open)
+    CsRef cs = rebase(cs_);
+    FwRef f = rebase(f_);
     const int M = rg.mask;
 #ifdef HTM_STAMPS
     const bool stamp_me = cs.stamps && lane == 0 && c == 0;
@@ -408,7 +433,7 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
                 constexpr int kSweep = 4;                 // <= 256 workers (host-checked)
                 unsigned long long hi[2][kSweep], lo[2][kSweep];
                 int which = 0;
-                auto issue = [&](int b) {
+                auto issue = [&](int b) __attribute__((always_inline)) {
 #pragma unroll
                     for (int j = 0; j < kSweep; ++j) {
                         const int k = j * 64 + lane;
@@ -416,7 +441,7 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
                         if (k < cs.n_wg) { hi[b][j] = ld_agent(pg + (size_t)pgs * k); lo[b][j] = ld_agent(pg + (size_t)pgs * k + 1); }
                     }
                 };
-                auto complete = [&](int b) {
+                auto complete = [&](int b) __attribute__((always_inline)) {
                     bool got = true;
 #pragma unroll
                     for (int j = 0; j < kSweep; ++j)
@@ -528,8 +553,9 @@ __device__ __forceinline__ int chain_pass(const FwdDev &f, const ChainsDev &cs, 
 }
 
 // lane 0 of the owning wave: take back the speculative effects of chain c's step
-__device__ __forceinline__ void undo_chain(const ChainsDev &cs, StepShared &sh, const Ring &rg, int c)
+__device__ __forceinline__ void undo_chain(CsRef cs_, StepShared &sh, const Ring &rg, int c)
 {
+    CsRef cs = rebase(cs_);
     Proposal &pr = sh.prop[c];
     if (pr.cool) sh.np[c * 7 + pr.type - 1] -= 1;
     if (pr.accepted) {
@@ -564,8 +590,9 @@ __device__ __forceinline__ Valid validate(const StepShared &sh, int nc, int lane
 }
 
 // role R: record slots (hypo_tremor_mcmc.f90:270-280), step log, per-chain part of the swap record
-__device__ __forceinline__ void role_records(const ChainsDev &cs, StepShared &sh, int iter, bool lockstep, int lane, double *rec)
+__device__ __forceinline__ void role_records(CsRef cs_, StepShared &sh, int iter, bool lockstep, int lane, double *rec)
 {
+    CsRef cs = rebase(cs_);
     const int nc = cs.n_chains;
     const bool in = lane < nc;
     const int c = in ? lane : 0;
@@ -596,9 +623,10 @@ __device__ __forceinline__ void role_records(const ChainsDev &cs, StepShared &sh
 
 // role W: the temperature swap of cls_parallel.f90:121-136 + :285-302 (single rank) or the header of this
 // rank's record (lock-step).  Uniform over the wave; lane 0 writes.
-__device__ __forceinline__ void role_swap(const ChainsDev &cs, StepShared &sh, int iter, bool lockstep, int lane,
+__device__ __forceinline__ void role_swap(CsRef cs_, StepShared &sh, int iter, bool lockstep, int lane,
                                           int i1, int i2, double sr, double slr, double *rec)
 {
+    CsRef cs = rebase(cs_);
     if (lane != 0) return;
     sh.sw_do = 0;
     if (lockstep) {
@@ -614,9 +642,10 @@ __device__ __forceinline__ void role_swap(const ChainsDev &cs, StepShared &sh, i
 
 // select_pair + the judge_swap draw starting at relative position `end` (uniform over the wave).
 // Returns false if the look-ahead window does not cover it (p < 1e-40).
-__device__ __forceinline__ bool swap_plan(const ChainsDev &cs, const StepShared &sh, const Ring &rg, bool lockstep,
+__device__ __forceinline__ bool swap_plan(CsRef cs_, const StepShared &sh, const Ring &rg, bool lockstep,
                                           int end, int &pos_out, int &i1, int &i2, double &sr, double &slr)
 {
+    CsRef cs = rebase(cs_);
     const int nc = cs.n_chains, n_all = cs.n_procs * nc;
     int pos = end;
     i1 = -1; i2 = -1; sr = 0.0; slr = 0.0;
@@ -668,9 +697,10 @@ struct PreOrder {            // per lane (<-> chain)
 // sent two iterations ahead, the workers' round trip disappears behind a whole iteration.  A mode-2 order is
 // evaluated on the state that memory holds when the workers get to it, before or after the step in between commits;
 // the order names that step's element and the worker of that event reports the value it saw (ChainsDev::vused).
-__device__ __forceinline__ PreOrder role_prepublish_plan(const ChainsDev &cs, StepShared &sh, const Ring &rg, int iter,
+__device__ __forceinline__ PreOrder role_prepublish_plan(CsRef cs_, StepShared &sh, const Ring &rg, int iter,
                                                          int pos, int lane, bool allow2, bool lockstep)
 {
+    CsRef cs = rebase(cs_);
     PreOrder po;
     po.job = false; po.c = 0; po.tag = 0; po.w1 = 0; po.x_hi = 0; po.x_lo = 0; po.co = 0xffffffffu; po.c_hi = 0; po.c_lo = 0;
     po.rep = 0;
@@ -765,8 +795,9 @@ __device__ __forceinline__ PreOrder role_prepublish_plan(const ChainsDev &cs, St
     }
     return po;
 }
-__device__ __forceinline__ void role_prepublish_send(const ChainsDev &cs, const PreOrder &po, unsigned long long launch)
+__device__ __forceinline__ void role_prepublish_send(CsRef cs_, const PreOrder &po, unsigned long long launch)
 {
+    CsRef cs = rebase(cs_);
     if (!po.job) return;
     for (int r = 0; r < cs.slot_rep; ++r) {
         unsigned long long *sl = cs.slots + (size_t)r * cs.slot_stride + po.c * kGranPerSlot;
@@ -782,8 +813,9 @@ __device__ __forceinline__ void role_prepublish_send(const ChainsDev &cs, const 
 }
 
 // chain wave, after the second barrier: this iteration's swap (if it touches chain c) and its records
-__device__ __forceinline__ void post_chain(const ChainsDev &cs, StepShared &sh, int c, int iter, int lane)
+__device__ __forceinline__ void post_chain(CsRef cs_, StepShared &sh, int c, int iter, int lane)
 {
+    CsRef cs = rebase(cs_);
     const int sl = sh.slot_l[c], ss = sh.slot_s[c];
     if (lane == 0) {
         if (sh.sw_do) {     // cls_parallel.f90:131-136
@@ -813,8 +845,9 @@ __device__ __forceinline__ void post_chain(const ChainsDev &cs, StepShared &sh, 
 
 // thread 0: temperature swap between chains of any two ranks from the all-gathered records
 // (cls_parallel.f90:118-213, :285-302).  Every rank evaluates the same decision from the same records.
-__device__ __forceinline__ void apply_swap(const ChainsDev &cs, StepShared &sh, const double *gathered)
+__device__ __forceinline__ void apply_swap(CsRef cs_, StepShared &sh, const double *gathered)
 {
+    CsRef cs = rebase(cs_);
     const int nc = cs.n_chains, RW = 4 + 2 * nc;
     const int iter = sh.c.iter_done + 1;
     if (cs.n_procs * nc > 1) {
@@ -851,15 +884,17 @@ __device__ __forceinline__ void apply_swap(const ChainsDev &cs, StepShared &sh, 
 constexpr int kXLoads = 8;        // granule loads per lane in flight while polling
 
 // every thread, after the roles of an iteration: does this rank ask everybody to stop after it?
-__device__ __forceinline__ bool want_stop_now(const ChainsDev &cs, const StepShared &sh, int wmax)
+__device__ __forceinline__ bool want_stop_now(CsRef cs_, const StepShared &sh, int wmax)
 {
+    CsRef cs = rebase(cs_);
     const int nc = cs.n_chains;
     return sh.c.n_lik + 2 * nc > cs.cap_lik || sh.c.n_smp + 2 * nc > cs.cap_smp || sh.avail < sh.base + 3 * wmax;
 }
 
 // one wave: this rank's record of iteration `iter` into every rank's inbox
-__device__ __forceinline__ void exchange_post(const ChainsDev &cs, const StepShared &sh, int iter, int lane, bool want_stop)
+__device__ __forceinline__ void exchange_post(CsRef cs_, const StepShared &sh, int iter, int lane, bool want_stop)
 {
+    CsRef cs = rebase(cs_);
     const int nc = cs.n_chains, RW = 4 + 2 * nc, G = cs.xg, np = cs.n_procs, par = iter & 1;
     const unsigned tag = (unsigned)iter;
     const unsigned ctl = (want_stop ? 1u : 0u) | (sh.c.err ? 2u : 0u);
@@ -880,8 +915,9 @@ __device__ __forceinline__ void exchange_post(const ChainsDev &cs, const StepSha
 
 // the same wave, later: wait for the n_procs records of iteration `iter`, decide the swap, publish sh.xdone = iter.
 // Rows of 64 granules, row = (rank r, chunk k of its record); kXLoads rows in flight.
-__device__ __forceinline__ void exchange_finish(const ChainsDev &cs, StepShared &sh, double *s_gath, int iter, int lane)
+__device__ __forceinline__ void exchange_finish(CsRef cs_, StepShared &sh, double *s_gath, int iter, int lane)
 {
+    CsRef cs = rebase(cs_);
     const int nc = cs.n_chains, RW = 4 + 2 * nc, G = cs.xg, np = cs.n_procs, par = iter & 1;
     const unsigned tag = (unsigned)iter;
     const unsigned long long *in = cs.inbox + (size_t)par * np * G;
@@ -948,10 +984,12 @@ __device__ __forceinline__ void exchange_finish(const ChainsDev &cs, StepShared 
 // PERSIST = true: this is block 0 of a k_mcmc launch; full evaluations are handed to the worker blocks of the
 // same launch through PSync (no kernel exit).  PERSIST = false: the kernel exits at a hand-over and k_full runs
 // as its own launch (fallback path, also used for profiling the two stages separately).
-template <int NCH, bool PERSIST, bool F32, bool LOCK>
-__device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, int mode, int target_arg,
+template <int NCH, bool PERSIST, bool F32, int MK>
+__device__ __forceinline__ void step_body(FwRef f_, CsRef cs_, int mode, int target_arg,
                                           const double *gathered, int ring_size, int wmax, unsigned long long launch)
 {
+    CsRef cs = rebase(cs_);
+    FwRef f = rebase(f_);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     StepShared &sh = *reinterpret_cast<StepShared *>(smem);
     char *carve = smem + ((sizeof(StepShared) + 15) & ~size_t(15));
@@ -969,7 +1007,7 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
     double *s_sy = s_sx + f.S;
     double *s_sz = s_sy + f.S;
     double *s_gath = s_sz + f.S;                   // [kGathStage] the all-gathered swap records, staged
-    rg.mir_n = (PERSIST && (mode == MODE_RUN || mode == MODE_LOCKRUN)) ? cs.mirror_n : 0;
+    rg.mir_n = (PERSIST && (MK == 0 || MK == 2 || (MK < 0 && mode == MODE_RUN))) ? cs.mirror_n : 0;
     rg.mx = s_gath + kGathStage;
     rg.mstep = rg.mx + rg.mir_n;
     rg.mir_steps = cs.mirror_steps != 0;
@@ -978,7 +1016,10 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NW = blockDim.x >> 6;                // every wave is a chain wave
     const int nc = cs.n_chains;
-    const bool lockstep = (mode != MODE_RUN);
+    // MK: which main loop this instantiation is -- 0 the single-rank loop (MODE_RUN), 1 one lock-step iteration per launch
+    // (MODE_ADVANCE / _FINISH / _APPLY), 2 persistent lock-step (MODE_LOCKRUN), -1 decided at run time (k_step)
+    constexpr bool LOCK = MK == 2;
+    const bool lockstep = MK < 0 ? (mode != MODE_RUN) : (MK != 0);
     // MODE_LOCKRUN: lock-step with the swap records exchanged inside the launch (exchange_records) -- the kernel stays
     // resident over the iterations, so the orders of role P and the LDS state carry over as in the single-rank loop
     constexpr bool lockrun = PERSIST && LOCK;          // (the host launches the LOCK instantiation with MODE_LOCKRUN only)
@@ -1011,7 +1052,7 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
 #endif
     for (int k = tid; k < rg.mir_n; k += blockDim.x) { rg.mx[k] = cs.xall[k]; if (rg.mir_steps) rg.mstep[k] = cs.stall[k]; }
     // the gathered records of the previous lock-step iteration come in with the same round of loads
-    const bool do_apply = (mode == MODE_APPLY || mode == MODE_ADVANCE) && gathered != nullptr;
+    const bool do_apply = (MK == 1 || MK < 0) && (mode == MODE_APPLY || mode == MODE_ADVANCE) && gathered != nullptr;
     const int n_gath = cs.n_procs * (4 + 2 * nc);
     const bool staged = do_apply && n_gath <= kGathStage;
     if (staged)
@@ -1041,7 +1082,7 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
     }
     if (mode == MODE_APPLY) return;
 
-    bool resume = (sh.c.stage == ST_WAIT_FULL);
+    bool resume = !PERSIST && (sh.c.stage == ST_WAIT_FULL);     // (k_mcmc evaluates in place: it never waits for k_full)
     if (mode == MODE_FINISH && !resume) return;
     if (sh.c.stage == ST_WAIT_SWAP) return;                   // nothing to do until the swap is applied
     if (!resume && (sh.c.iter_done >= sh.c.iter_target || sh.c.stop || sh.c.err)) return;
@@ -1053,7 +1094,7 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
     STAMP(0);   // prologue
 
     // ---------------- P0: judge + commit of the chains that came back from k_full; first stream window ----
-    if (__builtin_expect(resume, 0)) {
+    if (!PERSIST && __builtin_expect(resume, 0)) {
         if (tid == 0) cs.desc->n = 0;                          // work order consumed
         for (int c = wave; c < nc; c += NW) {
             Proposal pr = cs.prop[c];
@@ -1143,7 +1184,7 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
                     if constexpr (lockrun) {
                         int r;
                         for (;;) {
-                            r = chain_pass<NCH, PERSIST, F32, LOCK>(f, cs, sh, rg, s_sx, s_sy, s_sz, c, p, iter, lane, launch,
+                            r = chain_pass<NCH, PERSIST, F32, MK>(f, cs, sh, rg, s_sx, s_sy, s_sz, c, p, iter, lane, launch,
                                                               have_prev && rolep_on, first, xw, base_used);
                             if (r != kPassRestart) break;
                             // the swap took its judge draw from THIS rank's stream: every step of the iteration starts elsewhere
@@ -1154,7 +1195,7 @@ __device__ __forceinline__ void step_body(const FwdDev &f, const ChainsDev &cs, 
                         if (r == kPassAbort) break;                             // the job stops after the iteration before
                         p = r;
                     } else {
-                        p = chain_pass<NCH, PERSIST, F32, LOCK>(f, cs, sh, rg, s_sx, s_sy, s_sz, c, p, iter, lane, launch,
+                        p = chain_pass<NCH, PERSIST, F32, MK>(f, cs, sh, rg, s_sx, s_sy, s_sz, c, p, iter, lane, launch,
                                                           have_prev && rolep_on, first, -1, 0);
                     }
                     have_p = true;
@@ -1319,7 +1360,8 @@ template <int NCH, bool F32 = false>
 __global__ __launch_bounds__(512) void k_step(FwdDev f, ChainsDev cs, int mode, int target_arg,
                                                const double *gathered, int ring_size, int wmax)
 {
-    step_body<NCH, false, F32, false>(f, cs, mode, target_arg, gathered, ring_size, wmax, 0ull);
+    const KArgLayout __attribute__((address_space(4))) &ka = *(const KArgLayout __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+    step_body<NCH, false, F32, -1>(ka.f, ka.cs, mode, target_arg, gathered, ring_size, wmax, 0ull);
 }
 
 // Worker block of a k_mcmc launch: waits for work orders of its own launch and evaluates its event tile of
@@ -1330,8 +1372,10 @@ __global__ __launch_bounds__(512) void k_step(FwdDev f, ChainsDev cs, int mode, 
 // (the master drained its stores before publishing it).  Leaves when the master has finished (PSync::quit)
 // or after a bounded wait.
 template <int NCH, bool F32>
-__device__ __forceinline__ void worker_body(const FwdDev &f, const ChainsDev &cs, unsigned long long launch)
+__device__ __forceinline__ void worker_body(FwRef f_, CsRef cs_, unsigned long long launch)
 {
+    CsRef cs = rebase(cs_);
+    FwRef f = rebase(f_);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *s_red = reinterpret_cast<double *>(smem);          // [8]
     unsigned *s_tag = reinterpret_cast<unsigned *>(smem + 128);
@@ -1374,7 +1418,7 @@ __device__ __forceinline__ void worker_body(const FwdDev &f, const ChainsDev &cs
             // one poll = the slots of all chains (one load per 8 chains) + the quit word; npoll polls in flight
             constexpr int kPolls = 3;
             unsigned long long x[kPolls][kGroups], qw[kPolls];
-            auto issue = [&](int b) {
+            auto issue = [&](int b) __attribute__((always_inline)) {
 #pragma unroll
                 for (int j = 0; j < kGroups; ++j) {
                     x[b][j] = 0ull;
@@ -1383,7 +1427,7 @@ __device__ __forceinline__ void worker_body(const FwdDev &f, const ChainsDev &cs
                 qw[b] = lane == 63 ? ld_agent(&cs.ps->quit) : 0ull;
             };
             // returns 1: an order was taken (tag, chain, s_job set), -1: the master has quit, 0: nothing yet
-            auto check = [&](int b) -> int {
+            auto check = [&](int b) __attribute__((always_inline)) -> int {
 #pragma unroll
                 for (int j = 0; j < kGroups; ++j) {
                     if (8 * j >= nc) continue;
@@ -1575,18 +1619,19 @@ __global__ __launch_bounds__(64) void k_xchg_probe(ChainsDev cs, unsigned token,
 // One launch = the chain master (block 0) + W full-evaluation workers (blocks 1..W), all resident.
 // `launch` = the host's count of k_mcmc launches of this chain set (1, 2, ...): orders and the quit word carry it, so
 // nothing a previous launch left in memory can be mistaken for this launch's.
-template <int NCH, bool F32 = false, bool LOCK = false>
+template <int NCH, bool F32 = false, int MK = 0>
 __global__ __launch_bounds__(512) void k_mcmc(FwdDev f, ChainsDev cs, int mode, int target_arg,
                                                const double *gathered, int ring_size, int wmax,
                                                unsigned long long launch)
 {
+    const KArgLayout __attribute__((address_space(4))) &ka = *(const KArgLayout __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
     if (blockIdx.x == 0) {
-        step_body<NCH, true, F32, LOCK>(f, cs, mode, target_arg, gathered, ring_size, wmax, launch);
+        step_body<NCH, true, F32, MK>(ka.f, ka.cs, mode, target_arg, gathered, ring_size, wmax, launch);
         // every exit of the master comes through here (its returns are uniform over the block): release the workers
         __syncthreads();
-        if (threadIdx.x == 0) st_agent(&cs.ps->quit, launch + 1ull);
+        if (threadIdx.x == 0) st_agent(&ka.cs.ps->quit, launch + 1ull);
     } else {
-        worker_body<NCH, F32>(f, cs, launch);
+        worker_body<NCH, F32>(ka.f, ka.cs, launch);
     }
 }
 
