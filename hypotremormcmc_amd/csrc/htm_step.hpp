@@ -1229,6 +1229,7 @@ __device__ __forceinline__ void step_body(FwRef f_, CsRef cs_, int mode, int tar
                     fill_next = max(sh.fill, min(sh.fill + 64, pf_limit));
                 }
                 if (wave == 0 || wave == wave_R || wave == wave_W) {
+                    CsRef cs = rebase(cs_);
                     const Valid v = validate<PERSIST>(sh, nc, lane);
                     int pos = 0, i1, i2;
                     double sr, slr;
