@@ -826,7 +826,10 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
     const size_t lds_pos = 5 * sizeof(double) + 2 * sizeof(int4) + kHops * sizeof(int);
     const size_t mir = 2 * (size_t)nc + 2 * (size_t)nc * h->S;
     const size_t lds_cap = 156 * 1024;
-    auto ring_for = [&](int look) { int r = 256; while (r < look * hc->wmax + 64) r *= 2; return r; };
+    // (sized by what an iteration can really draw, 6 per chain step + the swap's, not by wmax's rounding to 64: at 16 chains
+    // the two-iteration window then fits a 512-position ring instead of 1024 -- half the LDS, so the mirror fits too)
+    const int wdraw = 6 * nc + 16;
+    auto ring_for = [&](int look) { int r = 256; while (r < look * wdraw + 64) r *= 2; return r; };
     hc->dev.mirror_n = 0; hc->dev.mirror_steps = 0;
     hc->ring_size = ring_for(2);
     {
