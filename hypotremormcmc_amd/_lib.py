@@ -95,6 +95,7 @@ SIGNATURES = {
     "htm_chains_last_run_stats": (C.c_int, [vp, dp, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "htm_chains_profile": (C.c_int, [vp, C.c_int, dp, C.POINTER(C.c_int), dp, C.POINTER(C.c_int),
                                      C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "htm_select_regress": (C.c_int, [C.c_int, C.c_int, C.c_int, dp, dp, dp, C.c_double, dp, dp, dp, dp, dp]),
     "htm_selftest": (C.c_int, [C.c_int]),
     "htm_rng_jump": (C.c_int, [up, C.c_ulonglong, up]),
 }

@@ -1853,6 +1853,26 @@ int htm_quantiles(int device, const double *samples, long n_mod, long n_par, con
     return rc;
 }
 
+int htm_select_regress(int device, int n_sta, int n_win, const double *sta_x, const double *sta_y, const double *sta_z,
+                       double z_guess, const double *t, const double *t_err, const double *a, const double *a_err, double *out)
+{
+    if (!sta_x || !sta_y || !sta_z || !t || !t_err || !a || !a_err || !out) return fail(HTM_EINVAL, "NULL argument");
+    if (n_sta < 3 || n_win < 1) return fail(HTM_EINVAL, "need n_sta >= 3 and n_win >= 1 (got %d, %d)", n_sta, n_win);
+    int rc = use_device(device);
+    if (rc) return rc;
+    std::vector<void *> pool;
+    auto done = [&](int code) { for (void *p : pool) (void)hipFree(p); return code; };
+    const size_t n = (size_t)n_sta * n_win;
+    double *dx = nullptr, *dy = nullptr, *dz = nullptr, *dt = nullptr, *dte = nullptr, *da = nullptr, *dae = nullptr, *dout = nullptr;
+    if ((rc = dev_upload(pool, &dx, sta_x, n_sta)) || (rc = dev_upload(pool, &dy, sta_y, n_sta)) || (rc = dev_upload(pool, &dz, sta_z, n_sta)) ||
+        (rc = dev_upload(pool, &dt, t, n)) || (rc = dev_upload(pool, &dte, t_err, n)) || (rc = dev_upload(pool, &da, a, n)) ||
+        (rc = dev_upload(pool, &dae, a_err, n)) || (rc = dev_alloc(pool, &dout, 6 * (size_t)n_win))) return done(rc);
+    hipLaunchKernelGGL(k_regress, dim3((n_win + 3) / 4), dim3(256), 0, 0, n_sta, n_win, dx, dy, dz, z_guess, dt, dte, da, dae, dout);
+    if (hipGetLastError() != hipSuccess) return done(fail(HTM_EHIP, "k_regress launch failed"));
+    if (hipMemcpy(out, dout, 6 * (size_t)n_win * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return done(fail(HTM_EHIP, "download failed"));
+    return done(HTM_OK);
+}
+
 int htm_rng_jump(const uint32_t state_in[4], unsigned long long n_draws, uint32_t state_out[4])
 {
     if (!state_in || !state_out) return fail(HTM_EINVAL, "NULL argument");

@@ -202,4 +202,71 @@ __global__ __launch_bounds__(64 * kSelRG) void k_select_pass(const double *x, lo
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Step 4 (`hypo_tremor_select`): per detected window the two weighted linear regressions against the
+// distance from the station of largest amplitude (src/cls_selector.f90:75-132, src/mod_regress.f90:5-58).
+// wave <-> window, lane <-> station (strided beyond 64): one pass for the ten weighted sums of the two regressions,
+// one for the six (unweighted, sic: mod_regress.f90:51-53) centred sums of the two correlation coefficients; distances
+// and the spreading-corrected amplitude are recomputed per pass (three subtractions, a sqrt, a log) rather than kept.
+// out[win] = {vs, b, t0, a0, cc_t, cc_a}, the columns of a regress.dat row after the window id.
+__global__ __launch_bounds__(256) void k_regress(int S, int W, const double *sx, const double *sy, const double *sz,
+                                                 double z_guess, const double *t, const double *t_err, const double *a,
+                                                 const double *a_err, double *out)
+{
+    const int lane = threadIdx.x & 63;
+    const int win = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (win >= W) return;
+    const size_t base = (size_t)win * S;
+    // maxloc(a): the FIRST maximum (cls_selector.f90:99)
+    double best = -1.0e300;
+    int near = 0x7fffffff;
+    for (int j = lane; j < S; j += 64) {
+        const double v = a[base + j];
+        if (v > best) { best = v; near = j; }
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const double ov = __shfl_xor(best, m);
+        const int oi = __shfl_xor(near, m);
+        if (ov > best || (ov == best && oi < near)) { best = ov; near = oi; }
+    }
+    const double nx = sx[near], ny = sy[near];
+    double r[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) r[k] = 0.0;
+    for (int j = lane; j < S; j += 64) {
+        const double dx = sx[j] - nx, dy = sy[j] - ny, dz = sz[j] - z_guess;      // :62-64
+        const double d = sqrt(dx * dx + dy * dy + dz * dz);
+        const double tj = t[base + j], aj = a[base + j] + log(d);                 // :102-103
+        const double wt = 1.0 / (t_err[base + j] * t_err[base + j]), wa = 1.0 / (a_err[base + j] * a_err[base + j]);   // :114, :120
+        r[0] += d * wt; r[1] += tj * wt; r[2] += wt; r[3] += d * tj * wt; r[4] += d * d * wt;      // mod_regress.f90:18-24
+        r[5] += d * wa; r[6] += aj * wa; r[7] += wa; r[8] += d * aj * wa; r[9] += d * d * wa;
+    }
+    wave_sum<10>(r);
+    const double det_t = r[2] * r[4] - r[0] * r[0], det_a = r[7] * r[9] - r[5] * r[5];            // :26
+    const double slope_t = (r[2] * r[3] - r[0] * r[1]) / det_t, icpt_t = (r[4] * r[1] - r[0] * r[3]) / det_t;
+    const double slope_a = (r[7] * r[8] - r[5] * r[6]) / det_a, icpt_a = (r[9] * r[6] - r[5] * r[8]) / det_a;
+    const double mx_t = r[0] / r[2], my_t = r[1] / r[2], mx_a = r[5] / r[7], my_a = r[6] / r[7];    // :48-49
+    double c[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) c[k] = 0.0;
+    for (int j = lane; j < S; j += 64) {
+        const double dx = sx[j] - nx, dy = sy[j] - ny, dz = sz[j] - z_guess;
+        const double d = sqrt(dx * dx + dy * dy + dz * dz);
+        const double tj = t[base + j], aj = a[base + j] + log(d);
+        c[0] += (d - mx_t) * (d - mx_t); c[1] += (tj - my_t) * (tj - my_t); c[2] += (d - mx_t) * (tj - my_t);      // :51-53
+        c[3] += (d - mx_a) * (d - mx_a); c[4] += (aj - my_a) * (aj - my_a); c[5] += (d - mx_a) * (aj - my_a);
+    }
+    wave_sum<6>(c);
+    if (lane == 0) {
+        double *o = out + (size_t)win * 6;
+        o[0] = 1.0 / slope_t;                 // vs   (cls_selector.f90:117)
+        o[1] = -1.0 * slope_a;                // b    (:123)
+        o[2] = icpt_t;                        // t0
+        o[3] = icpt_a;                        // a0
+        o[4] = c[2] / sqrt(c[0] * c[1]);      // cc_t (mod_regress.f90:55)
+        o[5] = c[5] / sqrt(c[3] * c[4]);      // cc_a
+    }
+}
+
 }  // namespace htm

@@ -15,7 +15,7 @@ module htm_c_api
   public :: htm_chains_xchg_handle, htm_chains_xchg_connect, htm_chains_xchg_probe, htm_chains_run_lockstep_direct
   public :: HTM_XCHG_HANDLE_BYTES, HTM_COMM_ID_BYTES
   public :: htm_comm_unique_id, htm_comm_create, htm_comm_destroy, htm_chains_run_lockstep_comm
-  public :: htm_device_count, htm_quantiles
+  public :: htm_device_count, htm_quantiles, htm_select_regress
   public :: htm_chains_checkpoint_size, htm_chains_checkpoint_save, htm_chains_checkpoint_load
 
   integer(c_size_t), parameter :: HTM_XCHG_HANDLE_BYTES = 64_c_size_t, HTM_COMM_ID_BYTES = 128_c_size_t
@@ -235,6 +235,16 @@ module htm_c_api
        real(c_double), intent(out) :: out(*)
        integer(c_int) :: rc
      end function htm_quantiles
+     !> step-4 regressions (include/htm_hip.h): t, t_err, a, a_err (n_sta, n_win); out (6, n_win) = vs, b, t0, a0, cc_t, cc_a
+     function htm_select_regress(device, n_sta, n_win, sta_x, sta_y, sta_z, z_guess, t, t_err, a, a_err, out) &
+          & bind(C, name="htm_select_regress") result(rc)
+       import :: c_int, c_double
+       integer(c_int), value :: device, n_sta, n_win
+       real(c_double), intent(in) :: sta_x(*), sta_y(*), sta_z(*), t(*), t_err(*), a(*), a_err(*)
+       real(c_double), value :: z_guess
+       real(c_double), intent(out) :: out(*)
+       integer(c_int) :: rc
+     end function htm_select_regress
      function htm_device_count(n) bind(C, name="htm_device_count") result(rc)
        import :: c_int
        integer(c_int), intent(out) :: n

@@ -32,6 +32,10 @@ REQUIRED_MCMC = [
 ]
 
 
+# src/cls_param.f90:123-126
+REQUIRED_SELECT = ["n_procs", "station_file", "z_guess", "vs_min", "vs_max", "b_min", "b_max"]
+
+
 class ParamError(SystemExit):
     """The reference `stop`s on a bad parameter file; mirrored as SystemExit with its message."""
 
@@ -76,10 +80,9 @@ class Param:
                 if nv is None:
                     continue
                 self.set_value(*nv)
-        if from_where == "mcmc":
-            for key in REQUIRED_MCMC:
-                if key not in self.given:
-                    raise ParamError(f"ERROR: {key} is not given.")
+        for key in {"mcmc": REQUIRED_MCMC, "select": REQUIRED_SELECT}.get(from_where, []):
+            if key not in self.given:
+                raise ParamError(f"ERROR: {key} is not given.")
         base = os.path.dirname(os.path.abspath(param_file))
         sf = self.values["station_file"]
         self.read_station_file(sf if os.path.isabs(sf) or os.path.exists(sf) else os.path.join(base, sf))

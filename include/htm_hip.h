@@ -280,6 +280,17 @@ int htm_quantiles(int device, const double *samples, long n_mod, long n_par, con
 int htm_quantiles_dev(int device, const double *d_samples, long n_mod, long n_par, long ld,
                       const int ranks_1based[3], double *d_out, void *hip_stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Step 4, `hypo_tremor_select`   reference: src/cls_selector.f90:75-132, src/mod_regress.f90
+ * For every detected window: the station of largest amplitude is taken as the epicentre (depth z_guess), the
+ * amplitudes are corrected for geometrical spreading (+ ln d), and arrival time and amplitude are regressed
+ * against distance with weights 1/err^2.  t, t_err, a, a_err: (n_sta, n_win) column-major = the columns 4-7 of the
+ * opt_data.NNNNNN.dat files; out[n_win][6] = {vs, b, t0, a0, cc_t, cc_a}: the columns of a regress.dat row after
+ * the window id (src/hypo_tremor_select.f90:124-125).  Host pointers; synchronous. */
+int htm_select_regress(int device, int n_sta, int n_win, const double *sta_x, const double *sta_y,
+                       const double *sta_z, double z_guess, const double *t, const double *t_err,
+                       const double *a, const double *a_err, double *out);
+
 int htm_selftest(int device);
 
 /* mod_random's generator (reference src/mod_random.f90:60-74) is linear over GF(2): the state after n draws is

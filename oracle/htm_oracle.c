@@ -779,3 +779,71 @@ void orc_job_get_steplog(const orc_job *job, int32_t *irows, double *drows)
     memcpy(irows, job->slog_i, 8 * (size_t)job->slog_n * sizeof(int32_t));
     memcpy(drows, job->slog_d, 4 * (size_t)job->slog_n * sizeof(double));
 }
+
+/* ====================================================================================================
+ * Step 4 (`hypo_tremor_select`), SURVEY 8f-4: per detected window, weighted linear regressions of arrival
+ * time and geometrically corrected log-amplitude against the distance from the station of largest
+ * amplitude.  Restates src/cls_selector.f90:50-67 (distance table), :75-132 (eval_wave_propagation) and
+ * src/mod_regress.f90:5-38 (linear_regression), :40-58 (weighted_corr) in their own operation order.
+ * Arrays (n_sta, n_win) column-major like the step-5 observations.  out[i] = {vs, b, t0, a0, cc_t, cc_a}
+ * in the order of a regress.dat row (src/hypo_tremor_select.f90:124-125).
+ * ==================================================================================================== */
+static void orc_linear_regression(int n, const double *x, const double *y, const double *w, double *a, double *b)
+{
+    double sumx = 0.0, sumy = 0.0, sumw = 0.0, sumxy = 0.0, sumx2 = 0.0;      /* mod_regress.f90:12-24 */
+    for (int i = 0; i < n; ++i) {
+        sumx = sumx + x[i] * w[i];
+        sumy = sumy + y[i] * w[i];
+        sumw = sumw + w[i];
+        sumxy = sumxy + x[i] * y[i] * w[i];
+        sumx2 = sumx2 + x[i] * x[i] * w[i];
+    }
+    const double d = sumw * sumx2 - sumx * sumx;                              /* :26-29 */
+    *a = (sumw * sumxy - sumx * sumy) / d;
+    *b = (sumx2 * sumy - sumx * sumxy) / d;
+}
+
+static double orc_weighted_corr(int n, const double *x, const double *y, const double *w)
+{
+    double sum_w = 0.0, sx = 0.0, sy = 0.0;                                   /* mod_regress.f90:47-49 */
+    for (int i = 0; i < n; ++i) sum_w += w[i];
+    for (int i = 0; i < n; ++i) sx += x[i] * w[i];
+    for (int i = 0; i < n; ++i) sy += y[i] * w[i];
+    const double mean_x = sx / sum_w, mean_y = sy / sum_w;
+    double s_xx = 0.0, s_yy = 0.0, s_xy = 0.0;                                /* :51-53: sums WITHOUT the weights (sic) */
+    for (int i = 0; i < n; ++i) s_xx += (x[i] - mean_x) * (x[i] - mean_x);
+    for (int i = 0; i < n; ++i) s_yy += (y[i] - mean_y) * (y[i] - mean_y);
+    for (int i = 0; i < n; ++i) s_xy += (x[i] - mean_x) * (y[i] - mean_y);
+    return s_xy / sqrt(s_xx * s_yy);                                          /* :55 */
+}
+
+void orc_select_regress(int n_sta, int n_win, const double *sta_x, const double *sta_y, const double *sta_z,
+                        double z_guess, const double *t, const double *t_err, const double *a,
+                        const double *a_err, double *out)
+{
+    double *d = (double *)malloc(sizeof(double) * n_sta), *ac = (double *)malloc(sizeof(double) * n_sta);
+    double *w = (double *)malloc(sizeof(double) * n_sta);
+    for (int i = 0; i < n_win; ++i) {
+        const double *ti = t + (size_t)i * n_sta, *te = t_err + (size_t)i * n_sta;
+        const double *ai = a + (size_t)i * n_sta, *ae = a_err + (size_t)i * n_sta;
+        int near = 0;                                                         /* maxloc(a): first maximum, cls_selector.f90:99 */
+        for (int j = 1; j < n_sta; ++j) if (ai[j] > ai[near]) near = j;
+        for (int j = 0; j < n_sta; ++j) {                                     /* :62-64: source at the nearest station's x, y and depth z_guess */
+            const double dx = sta_x[j] - sta_x[near], dy = sta_y[j] - sta_y[near], dz = sta_z[j] - z_guess;
+            d[j] = sqrt(dx * dx + dy * dy + dz * dz);
+            ac[j] = ai[j] + log(d[j]);                                        /* :102-103 geometrical spreading */
+        }
+        double slope, intercept;
+        for (int j = 0; j < n_sta; ++j) w[j] = 1.0 / (te[j] * te[j]);         /* :114 */
+        orc_linear_regression(n_sta, d, ti, w, &slope, &intercept);
+        const double vs = 1.0 / slope, t0 = intercept;                        /* :117-118 */
+        const double cc_t = orc_weighted_corr(n_sta, d, ti, w);               /* :127-128 */
+        for (int j = 0; j < n_sta; ++j) w[j] = 1.0 / (ae[j] * ae[j]);         /* :120 */
+        orc_linear_regression(n_sta, d, ac, w, &slope, &intercept);
+        const double b = -1.0 * slope, a0 = intercept;                        /* :123-124 */
+        const double cc_a = orc_weighted_corr(n_sta, d, ac, w);               /* :129-130 */
+        double *o = out + (size_t)i * 6;
+        o[0] = vs; o[1] = b; o[2] = t0; o[3] = a0; o[4] = cc_t; o[5] = cc_a;
+    }
+    free(d); free(ac); free(w);
+}

@@ -112,6 +112,12 @@ void     orc_job_enable_steplog(orc_job *job, int cap);
 int      orc_job_steplog_n(const orc_job *job);
 void     orc_job_get_steplog(const orc_job *job, int32_t *irows /* n x 8 */, double *drows /* n x 4 */);
 
+/* step 4 (hypo_tremor_select): regressions of one window set, out[n_win][6] = {vs, b, t0, a0, cc_t, cc_a}
+ * (src/cls_selector.f90:75-132, src/mod_regress.f90) */
+void     orc_select_regress(int n_sta, int n_win, const double *sta_x, const double *sta_y, const double *sta_z,
+                            double z_guess, const double *t, const double *t_err, const double *a,
+                            const double *a_err, double *out);
+
 #ifdef __cplusplus
 }
 #endif

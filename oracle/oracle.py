@@ -69,6 +69,7 @@ def lib():
     L.orc_forward_loglik_full.argtypes = [vp, dp, dp, C.c_double, dp, C.c_double]
     L.orc_forward_loglik_partial.restype = C.c_double
     L.orc_forward_loglik_partial.argtypes = [vp, C.c_int, dp, C.c_double, dp, dp, C.c_double, dp, C.c_double]
+    L.orc_select_regress.argtypes = [C.c_int, C.c_int] + [dp] * 3 + [C.c_double] + [dp] * 5
     L.orc_job_create.restype = vp
     L.orc_job_create.argtypes = [C.POINTER(OrcParams), C.c_int, C.c_int] + [dp] * 7
     L.orc_job_destroy.argtypes = [vp]
@@ -292,3 +293,15 @@ class Job:
             lib().orc_job_get_steplog(self.h, ir.ctypes.data_as(C.POINTER(C.c_int32)),
                                       dr.ctypes.data_as(C.POINTER(C.c_double)))
         return ir, dr
+
+
+def select_regress(sta_x, sta_y, sta_z, z_guess, t, t_err, a, a_err):
+    """Step 4 of the reference per window: rows {vs, b, t0, a0, cc_t, cc_a} (src/cls_selector.f90:75-132).
+    t, t_err, a, a_err: shape (n_win, n_sta)."""
+    t = np.ascontiguousarray(t, dtype=np.float64)
+    n_win, n_sta = t.shape
+    out = np.empty((n_win, 6))
+    arrs = [np.ascontiguousarray(v, dtype=np.float64) for v in (sta_x, sta_y, sta_z)]
+    obs = [np.ascontiguousarray(v, dtype=np.float64) for v in (t, t_err, a, a_err)]
+    lib().orc_select_regress(n_sta, n_win, *[_d(v)[1] for v in arrs], float(z_guess), *[_d(v)[1] for v in obs], _d(out)[1])
+    return out

@@ -16,6 +16,7 @@ Cases
   fixedcorr 7 ev x  9 stn, seed 4, solve_t_corr = solve_vs = F, 2 ranks x 3 chains, n_cool = 2
   c3     1000 ev x 64 stn, seed 1, 1 rank x 8 chains, 600 it: inputs are NOT stored (2 MB) -- the seeded
          generator reproduces them; a checksum of the inputs is stored instead.
+  select, select_wide   step 4 (hypo_tremor_select): 60 windows x 12 stations under 2 ranks, 33 x 70 under 3 ranks
   c4     1000 ev x 64 stn, seed 1, 8 ranks x 8 chains = 64 tempered chains, temp_high = 200, 400 it (BASELINE
          configs[3], run under mpiexec -np 8); inputs as for c3.
 """
@@ -205,8 +206,48 @@ def run_case(name, spec):
         shutil.rmtree(work, ignore_errors=True)
 
 
+SELECT_BIN = os.path.join(ROOT, "oracle", "_ref", "hypo_tremor_select_ref")
+SELECT_CASES = {
+    # step 4 (hypo_tremor_select) of the reference on detected windows: regress.dat + selected_win.dat
+    "select": dict(n_events=60, n_sta=12, seed=21, n_procs=2, z_guess=8.0, vs_min=2.6, vs_max=3.4, b_min=0.0, b_max=0.05),
+    "select_wide": dict(n_events=33, n_sta=70, seed=22, n_procs=3, z_guess=5.0, vs_min=2.9, vs_max=3.1, b_min=0.01, b_max=0.03),
+}
+
+
+def run_select_case(name, spec):
+    """Reference step 4, unmodified, under mpiexec: inputs = the seeded synthetic opt_data files (the step-5 inputs),
+    outputs = regress.dat rows {id, vs, b, t0, a0, cc_t, cc_a} and the selected window ids."""
+    data = synth.make_synthetic(spec["n_events"], spec["n_sta"], spec["seed"], 0)
+    work = tempfile.mkdtemp(prefix="htm_golden_sel_")
+    try:
+        synth.write_dataset(work, data)
+        shutil.copy(os.path.join(work, "selected_win.dat"), os.path.join(work, "detected_win.dat"))
+        os.remove(os.path.join(work, "selected_win.dat"))
+        keys = ("z_guess", "vs_min", "vs_max", "b_min", "b_max")
+        with open(os.path.join(work, "select.in"), "w") as fh:
+            fh.write("n_procs = %d\nstation_file = station_xy.list\n" % spec["n_procs"])
+            for k in keys:
+                fh.write("%s = %r\n" % (k, spec[k]))
+        subprocess.check_call([MPIEXEC, "-np", str(spec["n_procs"]), SELECT_BIN, "select.in"], cwd=work,
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        # list-directed output wraps its records over lines: 7 numbers per window
+        reg = np.array([float(x) for x in open(os.path.join(work, "regress.dat")).read().split()]).reshape(-1, 7)
+        sel = [int(ln.split()[0]) for ln in open(os.path.join(work, "selected_win.dat")) if ln.strip()]
+        assert 0 < len(sel) < len(reg), (len(sel), len(reg))       # the thresholds split the set
+        fx = dict(regress=reg, selected=np.array(sel, dtype=np.int32), in_checksum=np.array(checksum(data)),
+                  in_seed=np.array(spec["seed"]), in_shape=np.array([spec["n_events"], spec["n_sta"]]),
+                  param_keys=np.array(list(keys)), param_vals=np.array([spec[k] for k in keys]))
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **fx)
+        print(name, "ok:", reg.shape, "selected", len(sel))
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 if __name__ == "__main__":
-    if not (os.path.exists(REF_BIN) and os.path.exists(PROBE_BIN) and os.path.exists(STATS_BIN)):
+    if not (os.path.exists(REF_BIN) and os.path.exists(PROBE_BIN) and os.path.exists(STATS_BIN) and os.path.exists(SELECT_BIN)):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
-    for nm in (sys.argv[1:] or list(CASES)):
-        run_case(nm, CASES[nm])
+    for nm in (sys.argv[1:] or list(CASES) + list(SELECT_CASES)):
+        if nm in SELECT_CASES:
+            run_select_case(nm, SELECT_CASES[nm])
+        else:
+            run_case(nm, CASES[nm])
