@@ -252,6 +252,14 @@ def main(argv=None):
         from hypotremormcmc_amd import driver
         from hypotremormcmc_amd.obs_data import ObsData
 
+        # Rehearsal on a box with fewer GPUs than ranks (HTM_BENCH_ONE_GPU=1): every rank on device 0, rendezvous over gloo
+        # (RCCL refuses two ranks on one device) -- the launcher, the inbox exchange between processes and the timing
+        # protocol are the real ones, the number is not a scaling measurement and the line says so.
+        one_gpu = os.environ.get("HTM_BENCH_ONE_GPU") == "1"
+        if one_gpu:
+            local_rank = 0
+            os.environ.setdefault("HTM_MAX_WORKERS", str(max(1, 240 // max(1, world) - 2)))   # the ranks' kernels must co-reside
+        backend = "gloo" if one_gpu else "nccl"
         torch.cuda.set_device(local_rank)
         if lockstep:
             import torch.distributed as dist
@@ -260,6 +268,8 @@ def main(argv=None):
                 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
                 os.environ.setdefault("MASTER_PORT", str(free_port()))
                 dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+            elif one_gpu:
+                dist.init_process_group(backend="gloo")
             else:
                 dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         obs = ObsData.from_arrays(data.sta_x, data.sta_y, data.t_obs, data.t_stdv, data.a_obs, data.a_stdv)
@@ -290,7 +300,7 @@ def main(argv=None):
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if test_engine else "cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if (test_engine or dist.get_backend() == "gloo") else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     done = eng.iterations_done if test_engine else cs.iterations_done
@@ -316,6 +326,8 @@ def main(argv=None):
         out["config"]["parallelism"] = "lock-step path (swap records exchanged every iteration), 1 rank"
     if lockstep and not test_engine:
         out["config"]["swap_transport"] = transport
+        if os.environ.get("HTM_BENCH_ONE_GPU") == "1" and world > 1:
+            out["data"] = "synthetic (rehearsal: all ranks share ONE GPU, not a scaling measurement)"
     if test_engine:
         out["engine"] = f"{test_engine} (test double on CPU: launcher/protocol check, NOT a measurement)"
         out["data"] = "synthetic (test double)"
