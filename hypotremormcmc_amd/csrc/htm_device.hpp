@@ -100,6 +100,7 @@ struct FwdDev {
     const double *sx, *sy, *sz;                        // [S]
     const double *t_obs, *t_prec, *a_obs, *a_prec;     // [E][S]  (station fastest)
     const double *psum_t, *psum_a;                     // [E]  sum_j prec(j,i), summed in station order
+    const double *rpsum_t, *rpsum_a;                   // [E]  their reciprocals (host-computed): the demean is a multiplication
     double const_sum;   // sum over used data types of sum_{j,i} (log_2pi_half + log_stdv(j,i))
     // fp32 forward / fp64 accept (BASELINE configs[4], htm_forward_set_precision): the four observation streams once
     // more as float (half the bytes of a full evaluation), and the flag that makes event_misfit compute the synthetic
@@ -132,7 +133,7 @@ struct StaRegs {
 template <int NCH>
 struct ObsRegs {
     double tob[NCH], tpr[NCH], aob[NCH], apr[NCH];
-    double pst, psa;     // sum_j precision(j, event), time and amplitude
+    double rpst, rpsa;   // 1 / sum_j precision(j, event), time and amplitude
 };
 
 template <int NCH, bool F32 = false, class FW>
@@ -154,8 +155,8 @@ __device__ __forceinline__ void load_obs_regs(ObsRegs<NCH> &ob, const FW &f, int
             }
         }
     }
-    ob.pst = f.use_time ? ld_const(f.psum_t + ev) : 1.0;      // wave-uniform: scalar loads
-    ob.psa = f.use_amp ? ld_const(f.psum_a + ev) : 1.0;
+    ob.rpst = f.use_time ? ld_const(f.rpsum_t + ev) : 1.0;    // wave-uniform: scalar loads
+    ob.rpsa = f.use_amp ? ld_const(f.rpsum_a + ev) : 1.0;
 }
 
 template <int NCH, int NPOS, bool F32 = false, class FW>
@@ -164,7 +165,13 @@ __device__ __forceinline__ void event_misfit(const FW &f, const ObsRegs<NCH> &ob
                                              const double (&py)[NPOS], const double (&pz)[NPOS], double beta,
                                              double q, double (&out)[NPOS])
 {
+    // Strength reduction (round 2): the reference divides per station -- d / beta, d * pi * freq / (q * beta)
+    // (cls_forward.f90:118, :204) -- and per event mean (:131, :217).  beta, q and the precision sums are the same for all
+    // stations of a call, so the divisions are done ONCE (two here, the sums' reciprocals on the host) and the per-station
+    // work is multiplications: the values differ from the reference's in the last bit at most (the same class as the
+    // libm `log` difference and the summation order), a third of the step's fp64 instructions go away.
     const double qbeta = q * beta;
+    const double rbeta = 1.0 / beta, katt = (kPi * kFreq) / qbeta;
     const double (&tob)[NCH] = ob.tob, (&tpr)[NCH] = ob.tpr, (&aob)[NCH] = ob.aob, (&apr)[NCH] = ob.apr;
     double ts[NPOS][NCH], as[NPOS][NCH];
     double red[2 * NPOS];
@@ -174,8 +181,7 @@ __device__ __forceinline__ void event_misfit(const FW &f, const ObsRegs<NCH> &ob
         // single-precision forward: the coordinate differences are formed in fp64 (they are what the model state is),
         // everything after them -- distance, travel time, amplitude -- is fp32 arithmetic on the hardware's own
         // sqrt / reciprocal / log2 (v_sqrt_f32, v_rcp_f32, v_log_f32: ~1 ulp), then promoted for the fp64 sums
-        const float rbeta = __builtin_amdgcn_rcpf((float)beta);
-        const float katt = (float)(kPi * kFreq) * __builtin_amdgcn_rcpf((float)qbeta);
+        const float rbeta32 = (float)rbeta, katt32 = (float)katt;
 #pragma unroll
         for (int p = 0; p < NPOS; ++p) {
 #pragma unroll
@@ -186,11 +192,11 @@ __device__ __forceinline__ void event_misfit(const FW &f, const ObsRegs<NCH> &ob
                 if (!valid) d = 1.0f;
                 ts[p][c] = 0.0; as[p][c] = 0.0;
                 if (f.use_time) {
-                    ts[p][c] = (double)(d * rbeta - (float)st.tc[c]);
+                    ts[p][c] = (double)(d * rbeta32 - (float)st.tc[c]);
                     red[2 * p] += valid ? tpr[c] * (ts[p][c] - tob[c]) : 0.0;
                 }
                 if (f.use_amp) {
-                    as[p][c] = (double)(-(d * katt) - __builtin_amdgcn_logf(d) * 0.69314718055994531f - (float)st.ac[c]);
+                    as[p][c] = (double)(-(d * katt32) - __builtin_amdgcn_logf(d) * 0.69314718055994531f - (float)st.ac[c]);
                     red[2 * p + 1] += valid ? apr[c] * (as[p][c] - aob[c]) : 0.0;
                 }
             }
@@ -206,22 +212,22 @@ __device__ __forceinline__ void event_misfit(const FW &f, const ObsRegs<NCH> &ob
             if (!valid) d = 1.0;
             ts[p][c] = 0.0; as[p][c] = 0.0;
             if (f.use_time) {
-                ts[p][c] = d / beta - st.tc[c];
+                ts[p][c] = d * rbeta - st.tc[c];
                 red[2 * p] += valid ? tpr[c] * (ts[p][c] - tob[c]) : 0.0;
             }
             if (f.use_amp) {
-                as[p][c] = -(d * kPi * kFreq / qbeta) - log(d) - st.ac[c];
+                as[p][c] = -(d * katt) - log(d) - st.ac[c];
                 red[2 * p + 1] += valid ? apr[c] * (as[p][c] - aob[c]) : 0.0;
             }
         }
     }
     }
     wave_sum<2 * NPOS>(red);
-    const double pst = ob.pst, psa = ob.psa;
+    const double rpst = ob.rpst, rpsa = ob.rpsa;
 #pragma unroll
     for (int p = 0; p < NPOS; ++p) {
-        const double t_mean = red[2 * p] / pst;
-        const double a_mean = red[2 * p + 1] / psa;
+        const double t_mean = red[2 * p] * rpst;
+        const double a_mean = red[2 * p + 1] * rpsa;
         double m = 0.0;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
@@ -252,6 +258,7 @@ __device__ __forceinline__ void event_misfit_generic(const FW &f, int ev, int la
 {
     const size_t base = (size_t)ev * (size_t)f.S;
     const double qbeta = q * beta;
+    const double rbeta = 1.0 / beta, katt = (kPi * kFreq) / qbeta;      // (as in event_misfit: divisions once per call)
     double red[2 * NPOS];
 #pragma unroll
     for (int k = 0; k < 2 * NPOS; ++k) red[k] = 0.0;
@@ -262,15 +269,15 @@ __device__ __forceinline__ void event_misfit_generic(const FW &f, int ev, int la
         for (int p = 0; p < NPOS; ++p) {
             const double dx = px[p] - s_sx[j], dy = py[p] - s_sy[j], dz = pz[p] - s_sz[j];
             const double d = sqrt(dx * dx + dy * dy + dz * dz);
-            if (f.use_time) red[2 * p] += f.t_prec[base + j] * ((d / beta - tcj) - f.t_obs[base + j]);
+            if (f.use_time) red[2 * p] += f.t_prec[base + j] * ((d * rbeta - tcj) - f.t_obs[base + j]);
             if (f.use_amp)
                 red[2 * p + 1] += f.a_prec[base + j] *
-                                  ((-(d * kPi * kFreq / qbeta) - log(d) - acj) - f.a_obs[base + j]);
+                                  ((-(d * katt) - log(d) - acj) - f.a_obs[base + j]);
         }
     }
     wave_sum<2 * NPOS>(red);
-    const double pst = f.use_time ? f.psum_t[ev] : 1.0;
-    const double psa = f.use_amp ? f.psum_a[ev] : 1.0;
+    const double rpst = f.use_time ? f.rpsum_t[ev] : 1.0;
+    const double rpsa = f.use_amp ? f.rpsum_a[ev] : 1.0;
 #pragma unroll
     for (int p = 0; p < NPOS; ++p) out[p] = 0.0;
     for (int j = lane; j < f.S; j += 64) {
@@ -281,12 +288,12 @@ __device__ __forceinline__ void event_misfit_generic(const FW &f, int ev, int la
             const double dx = px[p] - s_sx[j], dy = py[p] - s_sy[j], dz = pz[p] - s_sz[j];
             const double d = sqrt(dx * dx + dy * dy + dz * dz);
             if (f.use_time) {
-                const double r = f.t_obs[base + j] - ((d / beta - tcj) - red[2 * p] / pst);
+                const double r = f.t_obs[base + j] - ((d * rbeta - tcj) - red[2 * p] * rpst);
                 out[p] += r * r * (0.5 * f.t_prec[base + j]);
             }
             if (f.use_amp) {
                 const double r = f.a_obs[base + j] -
-                                 ((-(d * kPi * kFreq / qbeta) - log(d) - acj) - red[2 * p + 1] / psa);
+                                 ((-(d * katt) - log(d) - acj) - red[2 * p + 1] * rpsa);
                 out[p] += r * r * (0.5 * f.a_prec[base + j]);
             }
         }

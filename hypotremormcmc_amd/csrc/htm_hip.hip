@@ -406,6 +406,11 @@ int htm_forward_create(int n_sta, int n_events, const double *sta_x, const doubl
     UP(h->dev.t_obs, t_obs, n) UP(h->dev.t_prec, tpr.data(), n)
     UP(h->dev.a_obs, a_obs, n) UP(h->dev.a_prec, apr.data(), n)
     UP(h->dev.psum_t, pst.data(), n_events) UP(h->dev.psum_a, psa.data(), n_events)
+    {
+        std::vector<double> rt(n_events), ra(n_events);
+        for (int i = 0; i < n_events; ++i) { rt[i] = 1.0 / pst[i]; ra[i] = 1.0 / psa[i]; }
+        UP(h->dev.rpsum_t, rt.data(), n_events) UP(h->dev.rpsum_a, ra.data(), n_events)
+    }
 #undef UP
     h->dev.S = n_sta; h->dev.E = n_events; h->dev.use_time = use_time ? 1 : 0; h->dev.use_amp = use_amp ? 1 : 0;
     h->dev.const_sum = (use_time ? const_t : 0.0) + (use_amp ? const_a : 0.0);
