@@ -412,6 +412,7 @@ struct ChainsDev {
     // [vs | t_corr | qs | a_corr | hypo], so that the element a step perturbs is base + integer offset
     // (scalar arithmetic) instead of a five-way choice between pointers.
     double *xall, *muall, *sgall, *stall;
+    double *rs2all;                  // 1 / (2 sigma^2) of every element (what the log prior ratio multiplies by)
     int32_t *ptall;
     double *temp, *L;                // [n_chains]
     int32_t *n_propose, *n_accept;   // [n_chains][7]

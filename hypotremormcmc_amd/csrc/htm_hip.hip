@@ -696,6 +696,12 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
         if ((rc = upload_model(hc, d.qs, init->qs, 1, nc, n + n * S, "qs"))) return cleanup(rc);
         if ((rc = upload_model(hc, d.ac, init->a_corr, h->S, nc, 2 * n + n * S, "a_corr"))) return cleanup(rc);
         if ((rc = upload_model(hc, d.hypo, init->hypo, 3 * h->E, nc, 2 * n + 2 * n * S, "hypo"))) return cleanup(rc);
+        {
+            std::vector<double> sg(total), r2(total);
+            HIPCHK(hipMemcpy(sg.data(), d.sgall, total * sizeof(double), hipMemcpyDeviceToHost));
+            for (size_t k = 0; k < total; ++k) r2[k] = 1.0 / (2.0 * sg[k] * sg[k]);
+            if ((rc = dev_upload(hc->pool, &d.rs2all, r2.data(), total))) return cleanup(rc);
+        }
         d.rayleigh14 = 0;
         auto any_rayleigh = [](const htm_model_init &m, size_t cnt) {
             if (!m.prior_type) return false;

@@ -49,6 +49,7 @@ constexpr int kGathStage = 512;   // doubles of LDS for the gathered swap record
 struct StepShared {
     Proposal prop[kMaxChains];
     double temp[kMaxChains], L[kMaxChains];
+    double rtemp[kMaxChains];     // 1 / temperature (the Metropolis ratio multiplies by it), renewed wherever temp is written
     int start[kMaxChains];        // stream position (relative) at which each chain step started
     int start_fix[kMaxChains];    // corrected starts for a repeat pass (written by wave 0)
     int cnt[kMaxChains];          // draws the step consumed (judge draw included iff prior_ok)
@@ -248,7 +249,7 @@ __device__ __forceinline__ void void_slot(CsRef cs_, int c)
 __device__ __forceinline__ bool metropolis(double L_new, double L_cur, double T, double lpr, double r,
                                            double logr)
 {
-    double ratio = (L_new - L_cur) / T;     // cls_mcmc.f90:194-195
+    double ratio = (L_new - L_cur) * T;     // cls_mcmc.f90:194-195; T = 1 / temperature here (formed once per swap, not per step)
     ratio = ratio + lpr;
     return r >= kEps && logr <= ratio;      // :198-199
 }
@@ -305,7 +306,7 @@ __device__ __forceinline__ int chain_pass(FwRef f_, CsRef cs_, StepShared &sh, c
     goffs = lane == 1 ? o_h : goffs; goffs = lane == 2 ? o_h + 1 : goffs; goffs = lane == 3 ? o_h + 2 : goffs;
     goffs = lane == 4 ? c : goffs; goffs = lane == 5 ? off_qs + c : goffs;
     const double gathered_v = cs.xall[goffs];
-    const double mu = ld_const(cs.muall + o), sigma = ld_const(cs.sgall + o), step = ld_const(cs.stall + o);
+    const double mu = ld_const(cs.muall + o), rs2 = ld_const(cs.rs2all + o), step = ld_const(cs.stall + o);
     const int ptype = ld_const(cs.ptall + o);
     const double *tc = cs.xall + off_tc + c * S_, *ac = cs.xall + off_ac + c * S_;
     StaRegs<(NCH > 0 ? NCH : 1)> st;
@@ -341,7 +342,7 @@ __device__ __forceinline__ int chain_pass(FwRef f_, CsRef cs_, StepShared &sh, c
     const double hx = rl_f64(gathered_v, 1), hy = rl_f64(gathered_v, 2), hz = rl_f64(gathered_v, 3);
     const double beta = rl_f64(gathered_v, 4), q = rl_f64(gathered_v, 5);
     const double L_cur = sh.L[c];
-    double T = sh.temp[c];           // (LOCK: read again after the swap is known, below)
+    double T = sh.temp[c], rT = sh.rtemp[c];   // (LOCK: read again after the swap is known, below)
     // MODE_LOCKRUN runs the front of this step -- loads, proposal, misfit -- while the swap records of the iteration
     // before (xwait) are still travelling between the ranks.  Everything that needs the swap's outcome waits HERE, just
     // before the decision: the temperature, whether the job goes on, and where this rank's stream really stands (the
@@ -350,7 +351,7 @@ __device__ __forceinline__ int chain_pass(FwRef f_, CsRef cs_, StepShared &sh, c
     CSTAMP(0);   // decode + load issue
     const double x_new = x_old + g * step;                      // cls_model.f90:172
     const double da = x_new - mu, db = x_old - mu;
-    double lpr = -(da * da - db * db) / (2.0 * sigma * sigma);  // :175-177
+    double lpr = -(da * da - db * db) * rs2;                    // :175-177 (rs2 = 1 / (2 sigma^2), formed once on the host)
     int ok = 1;
     if (__builtin_expect(ptype == 1, 0)) {                      // :178-187
         if (x_new <= mu) { lpr = (double)-1.0e+30f; ok = 0; }
@@ -381,7 +382,7 @@ __device__ __forceinline__ int chain_pass(FwRef f_, CsRef cs_, StepShared &sh, c
             else event_misfit_generic<2>(f, ev, lane, s_sx, s_sy, s_sz, tc, ac, 0, -1, 0.0, px, py, pz, beta, q, out);
             CSTAMP(2);   // event_misfit
             L_new = L_cur + wave_sum1(out[0] - out[1]);
-            if constexpr (!LOCK) acc = metropolis(L_new, L_cur, T, lpr, r, logr) ? 1 : 0;      // (LOCK: decided below, once the swap is known)
+            if constexpr (!LOCK) acc = metropolis(L_new, L_cur, rT, lpr, r, logr) ? 1 : 0;      // (LOCK: decided below, once the swap is known)
             CSTAMP(3);   // final sum + decision
         } else {
             need_full = 1;
@@ -517,7 +518,7 @@ __device__ __forceinline__ int chain_pass(FwRef f_, CsRef cs_, StepShared &sh, c
                         }
                     }
                 }
-                if constexpr (!LOCK) acc = metropolis(L_new, L_cur, T, lpr, r, logr) ? 1 : 0;
+                if constexpr (!LOCK) acc = metropolis(L_new, L_cur, rT, lpr, r, logr) ? 1 : 0;
 #ifdef HTM_STAMPS
                 if (lane == 0 && cs.stamps) atomicAdd(&cs.stamps[25], __builtin_amdgcn_s_memrealtime());
 #endif
@@ -528,9 +529,9 @@ __device__ __forceinline__ int chain_pass(FwRef f_, CsRef cs_, StepShared &sh, c
         while (__hip_atomic_load(&sh.xdone, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < xwait) __builtin_amdgcn_s_sleep(1);
         if (sh.c.stop || sh.c.err) return kPassAbort;
         if (sh.base != base_used) return kPassRestart;
-        T = sh.temp[c];
+        T = sh.temp[c]; rT = sh.rtemp[c];
     }
-    if constexpr (LOCK) { if (ok != 0) acc = metropolis(L_new, L_cur, T, lpr, r, logr) ? 1 : 0; }   // cls_mcmc.f90:193-203
+    if constexpr (LOCK) { if (ok != 0) acc = metropolis(L_new, L_cur, rT, lpr, r, logr) ? 1 : 0; }   // cls_mcmc.f90:193-203
     if (lane == 0) {
         const int cool = (T < 1.0 + kEps) ? 1 : 0;
         Proposal &pr = sh.prop[c];
@@ -819,8 +820,8 @@ __device__ __forceinline__ void post_chain(CsRef cs_, StepShared &sh, int c, int
     const int sl = sh.slot_l[c], ss = sh.slot_s[c];
     if (lane == 0) {
         if (sh.sw_do) {     // cls_parallel.f90:131-136
-            if (c == sh.sw_c1) { sh.temp[c] = sh.sw_T1; cs.temp[c] = sh.sw_T1; }
-            if (c == sh.sw_c2) { sh.temp[c] = sh.sw_T2; cs.temp[c] = sh.sw_T2; }
+            if (c == sh.sw_c1) { sh.temp[c] = sh.sw_T1; sh.rtemp[c] = 1.0 / sh.sw_T1; cs.temp[c] = sh.sw_T1; }
+            if (c == sh.sw_c2) { sh.temp[c] = sh.sw_T2; sh.rtemp[c] = 1.0 / sh.sw_T2; cs.temp[c] = sh.sw_T2; }
         }
         if (sl >= 0) { cs.lik_iter[sl] = iter; cs.lik_chain[sl] = c; cs.lik_val[sl] = sh.L[c]; }
     }
@@ -864,8 +865,8 @@ __device__ __forceinline__ void apply_swap(CsRef cs_, StepShared &sh, const doub
         bool acc = false;
         if (r >= kEps) { if (log(r) <= del_s) acc = true; }
         if (acc) {
-            if (cs.rank == rank1) { cs.temp[chain1] = T2; sh.temp[chain1] = T2; }
-            if (cs.rank == rank2) { cs.temp[chain2] = T1; sh.temp[chain2] = T1; }
+            if (cs.rank == rank1) { cs.temp[chain1] = T2; sh.temp[chain1] = T2; sh.rtemp[chain1] = 1.0 / T2; }
+            if (cs.rank == rank2) { cs.temp[chain2] = T1; sh.temp[chain2] = T1; sh.rtemp[chain2] = 1.0 / T1; }
         }
         if (cs.rank == rank1) sh.c.spos += 1;       // judge_swap's rand_u() came from rank1's stream
     }
@@ -1045,7 +1046,7 @@ __device__ __forceinline__ void step_body(FwRef f_, CsRef cs_, int mode, int tar
         if (tid == kCtrlWords) sh.hop_end = cs.stream.hop_end[vz0];
     }
     for (int j = tid; j < f.S; j += blockDim.x) { s_sx[j] = f.sx[j]; s_sy[j] = f.sy[j]; s_sz[j] = f.sz[j]; }
-    for (int c = tid; c < nc; c += blockDim.x) { sh.temp[c] = cs.temp[c]; sh.L[c] = cs.L[c]; }
+    for (int c = tid; c < nc; c += blockDim.x) { sh.temp[c] = cs.temp[c]; sh.rtemp[c] = 1.0 / cs.temp[c]; sh.L[c] = cs.L[c]; }
     for (int k = tid; k < 7 * nc; k += blockDim.x) { sh.np[k] = 0; sh.na[k] = 0; }
 #ifdef HTM_STAMPS
     for (int k = tid; k < 96; k += blockDim.x) sh.stamp_acc[k] = 0ull;
@@ -1102,7 +1103,7 @@ __device__ __forceinline__ void step_body(FwRef f_, CsRef cs_, int mode, int tar
                 double acc = 0.0;
                 for (int k = lane; k < cs.n_wg; k += 64) acc += cs.partial[(size_t)c * cs.n_wg + k];
                 pr.L_new = -wave_sum1(acc) - f.const_sum;      // cls_forward.f90:277-300
-                pr.accepted = metropolis(pr.L_new, sh.L[c], sh.temp[c], pr.lpr, pr.r_judge, pr.logr_judge) ? 1 : 0;
+                pr.accepted = metropolis(pr.L_new, sh.L[c], sh.rtemp[c], pr.lpr, pr.r_judge, pr.logr_judge) ? 1 : 0;
                 if (lane == 0 && pr.accepted) {                // cls_mcmc.f90:207-219
                     st_agent(cs.xall + elem_offset(cs, pr.type, c, pr.idx), pr.x_new);
                     sh.L[c] = pr.L_new;
