@@ -435,8 +435,6 @@ struct ChainsDev {
     unsigned long long *pgran;       // partial sums, tagged granules: chain c, worker k at [(c*n_workers + k)*pgran_stride + {0,1}]
     int pgran_stride;                // words between the granule pairs of two workers (>= 2)
     int npoll;                       // worker polls kept in flight (1..3)
-    unsigned long long *vused;       // [n_chains][2] tagged granules: the value a two-ahead order's evaluation saw for the
-                                     //   element the step in between perturbs (k_mcmc, role P)
     int mirror_n;                    // doubles of the LDS mirror of xall (vs, t_corr, qs, a_corr of all chains), 0 = none
     int mirror_steps;                // the step sizes of those elements are mirrored too (else role P reads them from memory)
     int rayleigh14;                  // some element of those four groups has a Rayleigh prior (prior_type 1)

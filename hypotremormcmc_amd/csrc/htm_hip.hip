@@ -743,8 +743,6 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
         d.pgran_stride = env_int("HTM_PGRAN_STRIDE", 16, 16, 4096) / 8;
         d.npoll = env_int("HTM_NPOLL", 1, 1, 3);
     }
-    if ((rc = dev_alloc(hc->pool, &d.vused, 2 * (size_t)nc))) return cleanup(rc);
-    HIPCHK(hipMemset(d.vused, 0, 2 * (size_t)nc * sizeof(unsigned long long)));
     if ((rc = dev_alloc(hc->pool, &d.slots, (size_t)d.slot_rep * d.slot_stride))) return cleanup(rc);
     HIPCHK(hipMemset(d.slots, 0, (size_t)d.slot_rep * d.slot_stride * sizeof(unsigned long long)));
     if ((rc = dev_alloc(hc->pool, &d.pgran, (size_t)nc * d.n_workers * d.pgran_stride))) return cleanup(rc);
@@ -1638,7 +1636,6 @@ int htm_chains_checkpoint_load(htm_chains *hc, const void *blob, size_t bytes)
         const ChainsDev &d = hc->dev;
         HIPCHK(hipMemset(d.slots, 0, (size_t)d.slot_rep * d.slot_stride * sizeof(unsigned long long)));
         HIPCHK(hipMemset(d.pgran, 0, (size_t)d.n_chains * d.n_workers * d.pgran_stride * sizeof(unsigned long long)));
-        HIPCHK(hipMemset(d.vused, 0, 2 * (size_t)d.n_chains * sizeof(unsigned long long)));
     }
     hc->lik_iter.clear(); hc->lik_chain.clear(); hc->lik_val.clear();
     hc->smp_iter.clear(); hc->smp_chain.clear(); hc->smp_data.clear();

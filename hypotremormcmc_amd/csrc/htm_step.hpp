@@ -327,7 +327,7 @@ __device__ __forceinline__ int chain_pass(FwRef f_, CsRef cs_, StepShared &sh, c
     if constexpr (PERSIST && NCH > 0) {
         if (__builtin_expect(!partial && wait_rolep, 0)) {
             const Proposal &pv = sh.prop[c];
-            if (first_pass && sh.pre_p[iter & 1][c] == p && sh.pre_mode[iter & 1][c] == 2 && pv.accepted && pv.type >= 5) {
+            if (first_pass && sh.pre_p[iter & 1][c] == p && sh.pre_mode[iter & 1][c] == 2 && pv.type >= 5) {
                 dhint = true;
                 d_e = __builtin_amdgcn_readfirstlane(pv.evt) - 1;
                 const int vzd = opaque_zero();
@@ -397,9 +397,7 @@ __device__ __forceinline__ int chain_pass(FwRef f_, CsRef cs_, StepShared &sh, c
 #ifdef HTM_STAMPS
                 if (lane == 0 && cs.stamps) atomicAdd(&sh.stamp_acc[80 + (c & 7) + (pre_mode == 2 ? 8 : 0)], 1ull);
 #endif
-                const int prev_acc = sh.prop[c].accepted, prev_type = sh.prop[c].type, prev_evt = sh.prop[c].evt;
-                const int prev_idx = sh.prop[c].idx;
-                const double prev_xold = sh.prop[c].x_old, prev_xnew = sh.prop[c].x_new;
+                const int prev_type = sh.prop[c].type, prev_evt = sh.prop[c].evt;     // the step in between (two-ahead orders)
                 unsigned long long tk = 0;
                 if (lane == 0) {
                     tk = pre ? (unsigned long long)sh.pre_tag[par][c] : ((atomicAdd(&sh.c.jobs_total, 1ull) + 1ull) & 0x7fffffffull);
@@ -425,6 +423,33 @@ __device__ __forceinline__ int chain_pass(FwRef f_, CsRef cs_, StepShared &sh, c
 #ifdef HTM_STAMPS
                 if (lane == 0 && cs.stamps) { atomicAdd(&cs.stamps[20], __builtin_amdgcn_s_memrealtime()); atomicAdd(&cs.stamps[26], 1ull); if (pre) atomicAdd(&cs.stamps[28], 1ull); }
 #endif
+                // An order sent TWO iterations ahead is evaluated while the step in between (a hypocentre step of this
+                // chain) may or may not have committed: the workers LEAVE THAT EVENT OUT, and this wave adds its misfit
+                // -- at the position the event has now, under this step's proposed parameters -- itself, while it waits
+                // for the workers' sums.  The result does not depend on when the workers looked.
+                double own_lane = 0.0;
+                if constexpr (NCH > 0) {
+                    if (pre_mode == 2 && prev_type >= 5) {
+                        const int e = prev_evt - 1;
+                        if (!(dhint && d_e == e)) {            // the hint missed: request the inputs now
+                            const int vzd = opaque_zero();
+                            const double *hyp = cs.xall + off_hy + c * nh + 3 * e;
+                            d_ex = ld_state(hyp, vzd); d_ey = ld_state(hyp + 1, vzd); d_ez = ld_state(hyp + 2, vzd);
+                            load_sta_regs<NCH>(st, f.S, lane, s_sx, s_sy, s_sz, tc, ac, 0, -1, 0.0);
+                            load_obs_regs<NCH, F32>(ob, f, e, lane);
+                        }
+                        if (type == 2 || type == 4) {          // this step's proposed correction, on the lane of its station
+#pragma unroll
+                            for (int k = 0; k < NCH; ++k) {
+                                if (lane + 64 * k == idx) { if (type == 2) st.tc[k] = x_new; else st.ac[k] = x_new; }
+                            }
+                        }
+                        const double pxd[1] = {d_ex}, pyd[1] = {d_ey}, pzd[1] = {d_ez};
+                        double outd[1];
+                        event_misfit<NCH, 1, F32>(f, ob, lane, st, pxd, pyd, pzd, type == 1 ? x_new : beta, type == 3 ? x_new : q, outd);
+                        own_lane = outd[0];
+                    }
+                }
                 // ---- the workers' partial sums: tagged granules, fixed summation order; two rounds of loads are
                 // ---- kept in flight so that a granule is seen at most half a round trip after it lands ----------
                 const unsigned long long *pg = cs.pgran + (size_t)c * cs.n_wg * cs.pgran_stride;
@@ -471,53 +496,7 @@ __device__ __forceinline__ int chain_pass(FwRef f_, CsRef cs_, StepShared &sh, c
                 for (int j = 0; j < kSweep; ++j)            // fixed order: worker lane, lane + 64, ...
                     if (j * 64 < cs.n_wg)
                         part += (j * 64 + lane < cs.n_wg) ? (which == 0 ? gran_f64(hi[0][j], lo[0][j]) : gran_f64(hi[1][j], lo[1][j])) : 0.0;
-                L_new = -wave_sum1(part) - f.const_sum;                  // cls_forward.f90:277-300
-                if constexpr (NCH > 0) {
-                    // An order sent TWO iterations ahead was evaluated while the step in between (a hypocentre step of
-                    // this chain) may or may not have committed yet; the worker that evaluated that event says which
-                    // value it saw.  If it saw the old one and the step was accepted:
-                    //   L(state now) = L(evaluated) + misfit(event, old position) - misfit(event, new position),
-                    // both under THIS step's proposed parameters.
-                    if (pre_mode == 2 && prev_acc && prev_type >= 5) {
-                        unsigned long long vh = 0, vl = 0;
-                        const unsigned long long t0v = __builtin_amdgcn_s_memrealtime();
-                        for (;;) {
-                            vh = ld_agent(cs.vused + 2 * c); vl = ld_agent(cs.vused + 2 * c + 1);
-                            if ((unsigned)(vh >> 32) == tag && (unsigned)(vl >> 32) == tag) break;
-                            if (__builtin_amdgcn_s_memrealtime() - t0v > 500000000ull) {
-                                if (lane == 0) sh.c.err = -8;
-#ifdef HTM_STAMPS
-                                if (lane == 0 && cs.stamps) { cs.stamps[100] = 2; cs.stamps[101] = c; cs.stamps[102] = tag; cs.stamps[105] = iter; cs.stamps[109] = vh; cs.stamps[110] = vl; }
-#endif
-                                break;
-                            }
-                        }
-                        const bool saw_new = (unsigned long long)__double_as_longlong(gran_f64(vh, vl)) ==
-                                             (unsigned long long)__double_as_longlong(prev_xnew);
-                        if (__builtin_expect(!saw_new, 0)) {
-                            const int e = prev_evt - 1, pcmp = prev_idx - 3 * e;
-                            if (!(dhint && d_e == e)) {        // the hint missed: request the inputs now
-                                const int vzd = opaque_zero();
-                                const double *hyp = cs.xall + off_hy + c * nh + 3 * e;
-                                d_ex = ld_state(hyp, vzd); d_ey = ld_state(hyp + 1, vzd); d_ez = ld_state(hyp + 2, vzd);
-                                load_sta_regs<NCH>(st, f.S, lane, s_sx, s_sy, s_sz, tc, ac, 0, -1, 0.0);
-                                load_obs_regs<NCH, F32>(ob, f, e, lane);
-                            }
-                            if (type == 2 || type == 4) {      // this step's proposed correction, on the lane of its station
-#pragma unroll
-                                for (int k = 0; k < NCH; ++k) {
-                                    if (lane + 64 * k == idx) { if (type == 2) st.tc[k] = x_new; else st.ac[k] = x_new; }
-                                }
-                            }
-                            const double pxd[2] = {pcmp == 0 ? prev_xold : d_ex, d_ex};
-                            const double pyd[2] = {pcmp == 1 ? prev_xold : d_ey, d_ey};
-                            const double pzd[2] = {pcmp == 2 ? prev_xold : d_ez, d_ez};
-                            double outd[2];
-                            event_misfit<NCH, 2, F32>(f, ob, lane, st, pxd, pyd, pzd, type == 1 ? x_new : beta, type == 3 ? x_new : q, outd);
-                            L_new = L_new + wave_sum1(outd[0] - outd[1]);
-                        }
-                    }
-                }
+                L_new = -wave_sum1(part + own_lane) - f.const_sum;       // cls_forward.f90:277-300
                 if constexpr (!LOCK) acc = metropolis(L_new, L_cur, rT, lpr, r, logr) ? 1 : 0;
 #ifdef HTM_STAMPS
                 if (lane == 0 && cs.stamps) atomicAdd(&cs.stamps[25], __builtin_amdgcn_s_memrealtime());
@@ -697,7 +676,8 @@ struct PreOrder {            // per lane (<-> chain)
 // else -- that step being a hypocentre step -- the order of its step of iteration iter + 2 if THAT one does (mode 2):
 // sent two iterations ahead, the workers' round trip disappears behind a whole iteration.  A mode-2 order is
 // evaluated on the state that memory holds when the workers get to it, before or after the step in between commits;
-// the order names that step's element and the worker of that event reports the value it saw (ChainsDev::vused).
+// the order names that step's element: the workers leave that event out of their sums and the chain's own wave adds it
+// (chain_pass), so the result does not depend on when the workers looked.
 __device__ __forceinline__ PreOrder role_prepublish_plan(CsRef cs_, StepShared &sh, const Ring &rg, int iter,
                                                          int pos, int lane, bool allow2, bool lockstep)
 {
@@ -1522,7 +1502,7 @@ __device__ __forceinline__ void worker_body(FwRef f_, CsRef cs_, unsigned long l
             const double beta = type == 1 ? ov_val : beta_c, q = type == 3 ? ov_val : q_c;
             int ov_kind = 0, ov_idx = -1, ov_evt = -1, ov_cmp = 0;
             const int r_off = (int)s_job[6] - 1 - (go.hy + m * go.nh);
-            const int r_evt = s_job[6] ? r_off / 3 : -1, r_cmp = s_job[6] ? r_off - 3 * (r_off / 3) : 0;
+            const int r_evt = s_job[6] ? r_off / 3 : -1;       // two-ahead orders: the event left to the chain's own wave
             if (type == 2 || type == 4) { ov_kind = type; ov_idx = idx; }
             else if (type >= 5) { ov_evt = idx / 3; ov_cmp = idx - 3 * ov_evt; }
             const double *hyp = cs.xall + go.hy + (size_t)m * go.nh;
@@ -1550,14 +1530,13 @@ __device__ __forceinline__ void worker_body(FwRef f_, CsRef cs_, unsigned long l
                         nx = ld_agent(hyp + 3 * evn); ny = ld_agent(hyp + 3 * evn + 1); nz = ld_agent(hyp + 3 * evn + 2);
                     }
                     const bool ov = ev == ov_evt;
-                    if (ev == r_evt && lane == 0)        // two-ahead order: which value of that coordinate went into this sum
-                        st_gran_f64(cs.vused + 2 * m, tag, r_cmp == 0 ? cx : r_cmp == 1 ? cy : cz);
                     const double px[1] = {(ov && ov_cmp == 0) ? ov_val : cx};
                     const double py[1] = {(ov && ov_cmp == 1) ? ov_val : cy};
                     const double pz[1] = {(ov && ov_cmp == 2) ? ov_val : cz};
                     double out[1];
                     event_misfit<NCH, 1, F32>(f, ob_cur, lane, st, px, py, pz, beta, q, out);
-                    lane_acc += out[0];
+                    // two-ahead order: the event of the step in between is left to the chain's own wave (it may be mid-commit)
+                    lane_acc += (ev == r_evt) ? 0.0 : out[0];
                     ob_cur = ob_nxt; cx = nx; cy = ny; cz = nz;
                 }
             } else {
