@@ -402,9 +402,14 @@ def _gloo_device_worker(rank, world, port, name, q, transport="staged"):
 
     sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      HTM_XCHG="1" if transport == "direct" else "0")
-    if transport == "direct" and name == "c4":
-        os.environ["HTM_MAX_WORKERS"] = "24"       # 8 persistent kernels share one GPU here: leave them room to co-reside
+                      HTM_XCHG="1" if transport.startswith("direct") else "0")
+    caps = {}
+    if transport == "direct-stops":
+        # the ranks leave a launch only TOGETHER: tiny record buffers and a short random-stream ring make some rank ask
+        # everybody to stop every few iterations (its buffers) / few thousand (its stream), at different times per rank
+        os.environ["HTM_STREAM_CAP"] = "131072"
+        caps = dict(lik_capacity=24, sample_capacity=24)
+        transport = "direct"
     import torch.distributed as dist
 
     from hypotremormcmc_amd import driver
@@ -415,7 +420,7 @@ def _gloo_device_worker(rank, world, port, name, q, transport="staged"):
     try:
         fx, data, params = load_case(name)
         obs = ObsData.from_arrays(data.sta_x, data.sta_y, data.t_obs, data.t_stdv, data.a_obs, data.a_stdv)
-        fwd, cs = driver.build_rank(params, data.sta_x, data.sta_y, data.sta_z, obs, rank, n_procs=world, device=0)
+        fwd, cs = driver.build_rank(params, data.sta_x, data.sta_y, data.sta_z, obs, rank, n_procs=world, device=0, **caps)
         tw = TorchWorld(cs)
         if transport == "direct":
             assert tw.direct, "peer mapping of the inboxes failed"
@@ -434,12 +439,15 @@ def _gloo_device_worker(rank, world, port, name, q, transport="staged"):
 
 
 @pytest.mark.parametrize("name,world,transport", [("c1", 2, "staged"), ("timeonly", 3, "staged"), ("c1", 2, "direct"),
-                                                  ("timeonly", 3, "direct"), ("rejects", 2, "direct"), ("fixedcorr", 2, "direct")])
+                                                  ("timeonly", 3, "direct"), ("rejects", 2, "direct"), ("fixedcorr", 2, "direct"),
+                                                  ("rejects", 2, "direct-stops"), ("timeonly", 3, "direct-stops")])
 def test_torchworld_across_processes_sharing_the_gpu(name, world, transport):
     """TorchWorld + device-resident chains in 2-3 separate processes sharing the one GPU: per-rank traces and the
     reduced counters against the reference's MPI run.  "staged": gloo with host-staged records per iteration;
     "direct": persistent lock-step -- each process's kernel writes its swap records into the other processes'
-    inboxes (IPC-mapped device memory, the mapping a multi-GPU node uses over xGMI) and stays resident."""
+    inboxes (IPC-mapped device memory, the mapping a multi-GPU node uses over xGMI) and stays resident;
+    "direct-stops": the same with record buffers of 24 entries and the shortest random-stream ring, so that launches
+    end by a rank's request every few iterations and every rank must leave after the same iteration."""
     import socket
 
     import torch.multiprocessing as mp
