@@ -481,3 +481,24 @@ def test_lockstep_on_the_two_kernel_fallback(monkeypatch):
         n = len(it)
         assert n > 0 and np.array_equal(it, fx[f"lik_iter_{r}"][:n])
         np.testing.assert_allclose(lk, fx[f"lik_{r}"][:n], rtol=RTOL_TRACE, atol=0)
+
+
+@pytest.mark.parametrize("E,S,nc,n_iter,prec", [(1000, 64, 8, 30000, "fp64"), (10000, 128, 16, 1500, "fp64"), (10000, 128, 16, 1500, "fp32")])
+def test_running_loglik_equals_full_evaluation_of_the_final_state(E, S, nc, n_iter, prec):
+    """Size-independent property at BASELINE's full sizes (configs[2] and the configs[4] per-GPU shape): the chain's
+    log-likelihood is carried incrementally (one-event updates, src/cls_forward.f90:307-362, refreshed only by accepted full
+    evaluations) over thousands of steps; evaluated afresh on the final state (calc_log_likelihood, :268-303) it must be
+    the same number -- to 1e-9 relative in fp64, and to the fp32 mode's stated tolerance (3e-6) with the fp32 forward."""
+    from hypotremormcmc_amd import driver, synth
+
+    data = synth.make_synthetic(E, S, 1 if E == 1000 else 5)
+    params = dict(synth.DEFAULT_PARAMS, n_procs=1, n_chains=nc, n_cool=2, n_iter=n_iter, n_burn=n_iter, n_interval=1000,
+                  forward_precision=prec)
+    fwd, cs = driver.build_rank(params, data.sta_x, data.sta_y, data.sta_z, _obs(data), 0, n_procs=1)
+    cs.run(n_iter)
+    assert cs.iterations_done == n_iter
+    tol = 1e-9 if prec == "fp64" else 3e-6
+    for c in (0, 1, nc // 2, nc - 1):
+        s = cs.state(c)
+        L = fwd.calc_log_likelihood(s.hypo, s.t_corr, s.vs, s.a_corr, s.qs)
+        assert abs(L - s.log_likelihood) <= tol * abs(L), (c, L, s.log_likelihood)
