@@ -439,7 +439,7 @@ struct ChainsDev {
     int mirror_steps;                // the step sizes of those elements are mirrored too (else role P reads them from memory)
     int rayleigh14;                  // some element of those four groups has a Rayleigh prior (prior_type 1)
     int n_workers;                   // worker blocks of a k_mcmc launch
-    // in-kernel exchange of the swap records (MODE_LOCKRUN, htm_step.hpp exchange_records)
+    // in-kernel exchange of the swap records (MODE_LOCKRUN, htm_step.hpp exchange_post / exchange_finish)
     unsigned long long *inbox;       // [2][n_procs][xg] tagged granules, this rank's own (fine-grained memory: peers write it)
     unsigned long long *const *outbox;   // [n_procs] where rank q's inbox is mapped in this process (q = rank: inbox itself)
     int xg;                          // granules per record = 2 * (4 + 2 n_chains) + 2

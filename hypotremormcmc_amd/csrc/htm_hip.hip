@@ -1226,7 +1226,7 @@ int htm_chains_run_lockstep(htm_chains *hc, int n_iter, htm_allgather_fn allgath
     return HTM_OK;
 }
 
-// ---- persistent lock-step: swap records exchanged inside the launch (exchange_records in htm_step.hpp) --------
+// ---- persistent lock-step: swap records exchanged inside the launch (exchange_post / exchange_finish in htm_step.hpp) --------
 static int xchg_alloc(htm_chains *hc)
 {
     if (hc->d_inbox) return HTM_OK;

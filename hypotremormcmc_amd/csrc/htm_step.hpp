@@ -1001,7 +1001,7 @@ __device__ __forceinline__ void step_body(FwRef f_, CsRef cs_, int mode, int tar
     // (MODE_ADVANCE / _FINISH / _APPLY), 2 persistent lock-step (MODE_LOCKRUN), -1 decided at run time (k_step)
     constexpr bool LOCK = MK == 2;
     const bool lockstep = MK < 0 ? (mode != MODE_RUN) : (MK != 0);
-    // MODE_LOCKRUN: lock-step with the swap records exchanged inside the launch (exchange_records) -- the kernel stays
+    // MODE_LOCKRUN: lock-step with the swap records exchanged inside the launch (exchange_post / exchange_finish) -- the kernel stays
     // resident over the iterations, so the orders of role P and the LDS state carry over as in the single-rank loop
     constexpr bool lockrun = PERSIST && LOCK;          // (the host launches the LOCK instantiation with MODE_LOCKRUN only)
     const bool rolep_on = PERSIST && (!lockstep || lockrun);
@@ -1573,7 +1573,7 @@ __device__ __forceinline__ void worker_body(FwRef f_, CsRef cs_, unsigned long l
 
 // Probe of the peer-mapped inboxes (htm_chains_xchg_probe): one wave writes a token record into every rank's inbox and
 // waits (bounded, `ticks` of the 100 MHz clock) until the tokens of all ranks have arrived in its own -- the same
-// stores, loads and scopes exchange_records uses, so a mapping whose writes are not visible to a polling kernel is
+// stores, loads and scopes exchange_post / exchange_finish use, so a mapping whose writes are not visible to a polling kernel is
 // found at set-up, not inside a run.  Token tags have the top bit set: no iteration number ever matches them.
 __global__ __launch_bounds__(64) void k_xchg_probe(ChainsDev cs, unsigned token, unsigned long long ticks, int *result)
 {
