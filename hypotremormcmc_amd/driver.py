@@ -127,17 +127,30 @@ def build_rank(params, sta_x, sta_y, sta_z, obs, rank, n_procs=None, device=0, f
 # ---------------------------------------------------------------------------------------------------
 # output files, src/hypo_tremor_mcmc.f90:216-233,:270-280 (stream access, unformatted: packed records)
 # ---------------------------------------------------------------------------------------------------
-def write_outputs(directory, rank, cs: ChainSet):
+def sample_byte_order(endian=None):
+    """'<' or '>' for the unformatted output files.  The reference's stock gfortran Makefile builds with
+    -fconvert=big-endian (src/Makefile:7-9), so a step 6 built that way expects big-endian sample files; any other
+    build reads native little-endian.  HTM_SAMPLE_ENDIAN=big|little (default little) picks the writer's order."""
+    e = (endian or os.environ.get("HTM_SAMPLE_ENDIAN") or "little").strip().lower()
+    if e in ("big", "big_endian", "big-endian", ">"):
+        return ">"
+    if e in ("little", "little_endian", "little-endian", "native", "<"):
+        return "<"
+    raise ValueError("HTM_SAMPLE_ENDIAN must be big or little, got %r" % e)
+
+
+def write_outputs(directory, rank, cs: ChainSet, endian=None):
+    bo = sample_byte_order(endian)
     it, _, lk = cs.likelihood_trace()
     with open(os.path.join(directory, "likelihood%02d.out" % rank), "wb") as f:
         for i, v in zip(it.tolist(), lk.tolist()):
-            f.write(struct.pack("<id", i, v))
+            f.write(struct.pack(bo + "id", i, v))
     smp = cs.samples()
     for name, key in (("vs", "vs"), ("qs", "qs"), ("t_corr", "t_corr"), ("a_corr", "a_corr"), ("hypo", "hypo")):
         with open(os.path.join(directory, "%s.%02d.out" % (name, rank)), "wb") as f:
             for k in range(len(smp["iter"])):
-                f.write(struct.pack("<i", int(smp["iter"][k])))
-                f.write(np.atleast_1d(smp[key][k]).astype("<f8").tobytes())
+                f.write(struct.pack(bo + "i", int(smp["iter"][k])))
+                f.write(np.atleast_1d(smp[key][k]).astype(bo + "f8").tobytes())
 
 
 def write_proposal_count(path, n_propose, n_accept):

@@ -7,7 +7,7 @@
 module htm_param
   implicit none
   private
-  public :: param, line_max
+  public :: param, line_max, sample_convert
 
   integer, parameter :: line_max = 200
 
@@ -45,6 +45,26 @@ module htm_param
        & "t_step_corr", "n_pair_thred", "alpha", "vs_min", "vs_max", "b_min", "b_max", "z_guess"]
 
 contains
+
+  !> CONVERT= value of the unformatted sample / likelihood files.  The reference's stock gfortran Makefile builds
+  !> with -fconvert=big-endian (src/Makefile:7-9): a step 5 / step 6 built that way writes / expects big-endian
+  !> records, any other build native little-endian.  HTM_SAMPLE_ENDIAN=big|little (default little).
+  function sample_convert() result(cv)
+    character(:), allocatable :: cv
+    character(32) :: e
+    integer :: n, st
+    call get_environment_variable("HTM_SAMPLE_ENDIAN", e, n, st)
+    if (st /= 0 .or. n == 0) then
+       cv = "little_endian"
+    else if (e(1:n) == "big" .or. e(1:n) == "big_endian" .or. e(1:n) == "big-endian") then
+       cv = "big_endian"
+    else if (e(1:n) == "little" .or. e(1:n) == "little_endian" .or. e(1:n) == "little-endian" .or. e(1:n) == "native") then
+       cv = "little_endian"
+    else
+       write(0, *) "ERROR: HTM_SAMPLE_ENDIAN must be big or little, got ", e(1:n)
+       error stop
+    end if
+  end function sample_convert
 
   subroutine load(self, file, verb)
     class(param), intent(inout) :: self

@@ -19,7 +19,7 @@ program hypo_tremor_mcmc_hip
   use, intrinsic :: iso_fortran_env, only: iostat_end
   use htm_c_api
   use htm_random
-  use htm_param, only: param, line_max
+  use htm_param, only: param, line_max, sample_convert
   use cls_model, only: model
   use cls_obs_data, only: obs_data
   use cls_forward, only: forward, htm_default_device
@@ -320,7 +320,7 @@ contains
     character(32) :: f
 
     write(f, '(A,I2.2,A)') "likelihood", rank, ".out"
-    open(newunit=io_l, file=trim(f), status="replace", access="stream", form="unformatted")
+    open(newunit=io_l, file=trim(f), status="replace", access="stream", form="unformatted", convert=sample_convert())
     call check(htm_chains_lik_count(chains, n), "htm_chains_lik_count")
     allocate(it(n), ch(n), lk(n))
     if (n > 0) call check(htm_chains_lik_read(chains, it, ch, lk), "htm_chains_lik_read")
@@ -329,11 +329,11 @@ contains
     end do
     close(io_l)
 
-    write(f, '(A,I2.2,A)') "hypo.", rank, ".out";   open(newunit=io_h, file=trim(f), status="replace", access="stream", form="unformatted")
-    write(f, '(A,I2.2,A)') "t_corr.", rank, ".out"; open(newunit=io_t, file=trim(f), status="replace", access="stream", form="unformatted")
-    write(f, '(A,I2.2,A)') "vs.", rank, ".out";     open(newunit=io_v, file=trim(f), status="replace", access="stream", form="unformatted")
-    write(f, '(A,I2.2,A)') "a_corr.", rank, ".out"; open(newunit=io_a, file=trim(f), status="replace", access="stream", form="unformatted")
-    write(f, '(A,I2.2,A)') "qs.", rank, ".out";     open(newunit=io_q, file=trim(f), status="replace", access="stream", form="unformatted")
+    write(f, '(A,I2.2,A)') "hypo.", rank, ".out";   open(newunit=io_h, file=trim(f), status="replace", access="stream", form="unformatted", convert=sample_convert())
+    write(f, '(A,I2.2,A)') "t_corr.", rank, ".out"; open(newunit=io_t, file=trim(f), status="replace", access="stream", form="unformatted", convert=sample_convert())
+    write(f, '(A,I2.2,A)') "vs.", rank, ".out";     open(newunit=io_v, file=trim(f), status="replace", access="stream", form="unformatted", convert=sample_convert())
+    write(f, '(A,I2.2,A)') "a_corr.", rank, ".out"; open(newunit=io_a, file=trim(f), status="replace", access="stream", form="unformatted", convert=sample_convert())
+    write(f, '(A,I2.2,A)') "qs.", rank, ".out";     open(newunit=io_q, file=trim(f), status="replace", access="stream", form="unformatted", convert=sample_convert())
     call check(htm_chains_sample_count(chains, n), "htm_chains_sample_count")
     do k = 0, n - 1
        call check(htm_chains_sample_read(chains, k, it1, ch1, v, q, h, tc, ac), "htm_chains_sample_read")

@@ -10,7 +10,7 @@ program hypo_tremor_statistics_hip
   use, intrinsic :: iso_c_binding
   use, intrinsic :: iso_fortran_env, only: iostat_end
   use htm_c_api
-  use htm_param, only: param, line_max
+  use htm_param, only: param, line_max, sample_convert
   implicit none
 
   type(param) :: para
@@ -70,7 +70,7 @@ contains
     do r = 0, para%n_procs - 1
        write(f, '(A,A,I2.2,A)') name, ".", r, ".out"
        write(*, '(A)') "<< Now reading " // trim(f) // " >>"
-       open(newunit=u, file=trim(f), status="old", access="stream", form="unformatted", iostat=ierr)
+       open(newunit=u, file=trim(f), status="old", access="stream", form="unformatted", convert=sample_convert(), iostat=ierr)
        if (ierr /= 0) then
           write(0, *) "ERROR: cannot open ", trim(f)
           error stop

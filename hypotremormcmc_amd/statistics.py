@@ -55,11 +55,15 @@ def quantiles(samples: np.ndarray, n_mod: int | None = None, device: int = 0) ->
     return out          # columns: il (2.5 %), im (50 %), iu (97.5 %)
 
 
-def read_sample_file(path: str, n_val: int):
-    """stream-unformatted records [int32 iteration][n_val float64] (src/hypo_tremor_mcmc.f90:216-233)"""
-    rec = np.dtype([("it", "<i4"), ("v", "<f8", (n_val,))])
+def read_sample_file(path: str, n_val: int, endian=None):
+    """stream-unformatted records [int32 iteration][n_val float64] (src/hypo_tremor_mcmc.f90:216-233);
+    byte order: HTM_SAMPLE_ENDIAN=big|little (driver.sample_byte_order; big = written by a stock-gfortran build of
+    the reference, src/Makefile:7-9)"""
+    from .driver import sample_byte_order
+    bo = sample_byte_order(endian)
+    rec = np.dtype([("it", bo + "i4"), ("v", bo + "f8", (n_val,))])
     a = np.fromfile(path, dtype=rec)
-    return a["it"].copy(), a["v"].reshape(len(a), n_val).copy()
+    return a["it"].astype(np.int32), a["v"].reshape(len(a), n_val).astype(np.float64)
 
 
 def remove_double_counts(win_id, q):

@@ -51,28 +51,30 @@ def test_fortran_forward_shim_known_answers(name, tmp_path):
     np.testing.assert_allclose(single[:, 1], fx["probe_a_syn_single"], rtol=0, atol=1e-12)
 
 
-def _records(path, n_val):
-    dt = np.dtype([("iter", "<i4"), ("val", "<f8", (n_val,))])
+def _records(path, n_val, bo="<"):
+    dt = np.dtype([("iter", bo + "i4"), ("val", bo + "f8", (n_val,))])
     if os.path.getsize(path) == 0:
         return np.zeros(0, np.int32), np.zeros((0, n_val))
     a = np.fromfile(path, dtype=dt)
-    return a["iter"].copy(), a["val"].reshape(-1, n_val).copy()
+    return a["iter"].astype(np.int32), a["val"].reshape(-1, n_val).astype(np.float64)
 
 
-@pytest.mark.parametrize("name", ["c2", "missing"])
-def test_fortran_driver_reproduces_reference_outputs(name, tmp_path):
-    """same CLI, parameter file, inputs and output files as the reference's hypo_tremor_mcmc"""
+@pytest.mark.parametrize("name,endian", [("c2", "little"), ("missing", "little"), ("c2", "big")])
+def test_fortran_driver_reproduces_reference_outputs(name, endian, tmp_path):
+    """same CLI, parameter file, inputs and output files as the reference's hypo_tremor_mcmc; endian = big: the
+    records of a stock-gfortran build of the reference (-fconvert=big-endian, src/Makefile:7-9), HTM_SAMPLE_ENDIAN"""
     fx, data, params = load_case(name)
     synth.write_dataset(str(tmp_path), data)
     synth.write_param_file(str(tmp_path / "run.in"), **{k: v for k, v in params.items()})
     subprocess.run([_need("hypo_tremor_mcmc_hip"), "run.in"], cwd=tmp_path, check=True, timeout=600,
-                   stdout=subprocess.DEVNULL)
+                   stdout=subprocess.DEVNULL, env=dict(os.environ, HTM_SAMPLE_ENDIAN=endian))
     E, S = data.n_events, data.n_sta
-    it, v = _records(tmp_path / "likelihood00.out", 1)
+    bo = ">" if endian == "big" else "<"
+    it, v = _records(tmp_path / "likelihood00.out", 1, bo)
     assert np.array_equal(it, fx["lik_iter_0"])
     np.testing.assert_allclose(v[:, 0], fx["lik_0"], rtol=1e-9, atol=0)
     for nm, nv in (("vs", 1), ("qs", 1), ("t_corr", S), ("a_corr", S), ("hypo", 3 * E)):
-        it, v = _records(tmp_path / f"{nm}.00.out", nv)
+        it, v = _records(tmp_path / f"{nm}.00.out", nv, bo)
         assert np.array_equal(it, fx[f"{nm}_iter_0"])
         np.testing.assert_allclose(v, fx[f"{nm}_0"], rtol=1e-11, atol=1e-12)
     rows = [ln.split('"') for ln in open(tmp_path / "proposal_count.txt")]
@@ -160,10 +162,12 @@ def test_fortran_mpi_driver_over_rccl(tmp_path):
     assert [int(r_[2].split()[1]) for r_ in rows] == fx["n_accept"].tolist()
 
 
-@pytest.mark.parametrize("name", ["c1", "timeonly", "fixedcorr"])
-def test_fortran_statistics_program_writes_the_reference_stat_files(name, tmp_path):
+@pytest.mark.parametrize("name,endian", [("c1", "little"), ("timeonly", "little"), ("fixedcorr", "little"), ("c1", "big")])
+def test_fortran_statistics_program_writes_the_reference_stat_files(name, endian, tmp_path):
     """hypo_tremor_statistics_hip on the sample files the reference's step 5 wrote (rebuilt from the fixture):
-    the four .stat files must be the reference step 6's, character for character."""
+    the four .stat files must be the reference step 6's, character for character.  endian = big: sample files as a
+    stock-gfortran build of the reference's step 5 writes them (HTM_SAMPLE_ENDIAN=big)."""
+    bo = ">" if endian == "big" else "<"
     fx, data, params = load_case(name)
     n_procs = int(params["n_procs"])
     synth.write_dataset(str(tmp_path), data)
@@ -172,11 +176,11 @@ def test_fortran_statistics_program_writes_the_reference_stat_files(name, tmp_pa
     for r in range(n_procs):
         for nm, nv in (("vs", 1), ("qs", 1), ("t_corr", S), ("a_corr", S), ("hypo", 3 * E)):
             it, v = fx[f"{nm}_iter_{r}"], fx[f"{nm}_{r}"].reshape(len(fx[f"{nm}_iter_{r}"]), nv)
-            rec = np.zeros(len(it), dtype=np.dtype([("iter", "<i4"), ("val", "<f8", (nv,))]))
+            rec = np.zeros(len(it), dtype=np.dtype([("iter", bo + "i4"), ("val", bo + "f8", (nv,))]))
             rec["iter"] = it; rec["val"] = v
             rec.tofile(tmp_path / ("%s.%02d.out" % (nm, r)))
     res = subprocess.run([_need("hypo_tremor_statistics_hip"), "run.in"], cwd=tmp_path, timeout=600, capture_output=True,
-                         text=True)
+                         text=True, env=dict(os.environ, HTM_SAMPLE_ENDIAN=endian))
     assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-1500:])
     for fn in ("uniform_structure.stat", "station_corrections.stat", "hypo.stat", "hypo.stat.removed"):
         assert open(tmp_path / fn).read() == str(fx["stat_" + fn.replace(".", "_")]), fn

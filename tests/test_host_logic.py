@@ -146,3 +146,36 @@ def test_rng_jump_ahead_equals_serial_stream():
     sa, sab, sd = (C.c_uint32 * 4)(), (C.c_uint32 * 4)(), (C.c_uint32 * 4)()
     _lib.check(lib.htm_rng_jump(s0, a, sa)); _lib.check(lib.htm_rng_jump(sa, b, sab)); _lib.check(lib.htm_rng_jump(s0, a + b, sd))
     assert tuple(sab) == tuple(sd)
+
+
+def test_sample_files_in_either_byte_order(tmp_path, monkeypatch):
+    """HTM_SAMPLE_ENDIAN: records [int32 iteration][n float64] (src/hypo_tremor_mcmc.f90:216-233) as a stock-gfortran
+    build of the reference writes them (-fconvert=big-endian, src/Makefile:7-9) or native"""
+    from hypotremormcmc_amd.statistics import read_sample_file
+
+    class FakeChains:                       # what write_outputs reads from a ChainSet
+        def likelihood_trace(self):
+            return np.array([1, 2, 3]), None, np.array([-1.5, -2.25, 1e300])
+
+        def samples(self):
+            return {"iter": np.array([10, 20]), "vs": np.array([3.5, 3.25]), "qs": np.array([100.0, 101.0]),
+                    "t_corr": np.arange(8.0).reshape(2, 4), "a_corr": -np.arange(8.0).reshape(2, 4),
+                    "hypo": np.linspace(0, 1, 12).reshape(2, 6)}
+
+    for endian, bo in (("little", "<"), ("big", ">")):
+        d = tmp_path / endian
+        d.mkdir()
+        monkeypatch.setenv("HTM_SAMPLE_ENDIAN", endian)
+        driver.write_outputs(str(d), 0, FakeChains())
+        raw = open(d / "likelihood00.out", "rb").read()
+        assert raw[:12] == struct.pack(bo + "id", 1, -1.5) and len(raw) == 36
+        it, v = read_sample_file(str(d / "t_corr.00.out"), 4)
+        assert it.tolist() == [10, 20] and np.array_equal(v, np.arange(8.0).reshape(2, 4))
+        it, v = read_sample_file(str(d / "hypo.00.out"), 6)
+        assert np.array_equal(v, np.linspace(0, 1, 12).reshape(2, 6))
+    # the two orders differ on disk, and reading with the wrong one does not silently give the same numbers
+    assert open(tmp_path / "big" / "vs.00.out", "rb").read() != open(tmp_path / "little" / "vs.00.out", "rb").read()
+    assert read_sample_file(str(tmp_path / "little" / "vs.00.out"), 1, endian="big")[0].tolist() != [10, 20]
+    monkeypatch.setenv("HTM_SAMPLE_ENDIAN", "middle")
+    with pytest.raises(ValueError):
+        driver.sample_byte_order()
