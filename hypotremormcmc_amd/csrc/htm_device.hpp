@@ -70,6 +70,44 @@ __device__ __forceinline__ double wave_sum1(double a)
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Natural logarithm of the forward model's amplitude term (cls_forward.f90:204, `log(d)`), fp64.
+// The device library's `log` keeps its intermediate sums in double-double form (~88 VALU instructions, half of one
+// station's evaluation); this one is 31: x = m * 2^e with m in [sqrt(1/2), sqrt(2)), f = m - 1, s = f / (2 + f),
+// log(m) = f - (f^2/2 - s * (f^2/2 + R(s^2))), R = z * P(z) with P a degree-6 near-minimax fit of
+// (log((1+s)/(1-s)) - 2s) / s^3 on [0, (3 - 2 sqrt 2)^2] (coefficients: tools/log_coefficients.py, |error| 3.1e-16),
+// result = e * ln2_hi - ((f^2/2 - (s * (f^2/2 + R) + e * ln2_lo)) - f) with a 32-bit ln2_hi so that e * ln2_hi is
+// exact.  Leading term f is exact, s enters only through a term <= 4 % of the result: measured error < 0.82 ulp
+// (tests/test_gpu_forward.py against a 50-digit logarithm; htm_selftest_log).  x = 0 -> -inf, NaN -> NaN, subnormals
+// are handled by v_frexp; x < 0 and +inf (never produced by a distance) give NaN.  Every operation is an explicit
+// fma / mul / add: nothing is left to the compiler's contraction rules, the value is the same in every kernel.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double htm_log(double x)
+{
+    const double m0 = __builtin_amdgcn_frexp_mant(x);                 // [0.5, 1)
+    const int lo = m0 < 0.70710678118654752 ? 1 : 0;
+    const double f = __builtin_fma(m0, lo ? 2.0 : 1.0, -1.0);         // m - 1, exact
+    const double k = (double)(__builtin_amdgcn_frexp_exp(x) - lo);
+    const double D = f + 2.0;
+    double r = __builtin_amdgcn_rcp(D);
+    r = __builtin_fma(__builtin_fma(-D, r, 1.0), r, r);
+    double s = f * r;
+    s = __builtin_fma(__builtin_fma(-s, D, f), r, s);                 // f / D, correctly rounded but for rare cases
+    const double z = s * s;
+    double p = __builtin_fma(z, 0x1.2b5900de53b32p-3, 0x1.39fe51a7c18f9p-3);
+    p = __builtin_fma(z, p, 0x1.7462b51cb66b1p-3);
+    p = __builtin_fma(z, p, 0x1.c71c62e3f11e6p-3);
+    p = __builtin_fma(z, p, 0x1.2492492df281ap-2);
+    p = __builtin_fma(z, p, 0x1.99999999952d7p-2);
+    p = __builtin_fma(z, p, 0x1.5555555555558p-1);
+    const double hf = 0.5 * f;
+    const double a = __builtin_fma(f, hf, z * p);                     // f^2/2 + R
+    const double t = __builtin_fma(s, a, k * 0x1.a39ef35793c76p-33);  // + e * ln2_lo
+    const double b = __builtin_fma(f, hf, -t);
+    const double y = __builtin_fma(k, 0x1.62e42fee00000p-1, -(b - f));
+    return x == 0.0 ? -__builtin_inf() : y;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // mod_random on the device (reference src/mod_random.f90:60-112)
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t xs128_next(uint32_t &x, uint32_t &y, uint32_t &z, uint32_t &w)
@@ -216,7 +254,7 @@ __device__ __forceinline__ void event_misfit(const FW &f, const ObsRegs<NCH> &ob
                 red[2 * p] += valid ? tpr[c] * (ts[p][c] - tob[c]) : 0.0;
             }
             if (f.use_amp) {
-                as[p][c] = -(d * katt) - log(d) - st.ac[c];
+                as[p][c] = -(d * katt) - htm_log(d) - st.ac[c];
                 red[2 * p + 1] += valid ? apr[c] * (as[p][c] - aob[c]) : 0.0;
             }
         }
@@ -272,7 +310,7 @@ __device__ __forceinline__ void event_misfit_generic(const FW &f, int ev, int la
             if (f.use_time) red[2 * p] += f.t_prec[base + j] * ((d * rbeta - tcj) - f.t_obs[base + j]);
             if (f.use_amp)
                 red[2 * p + 1] += f.a_prec[base + j] *
-                                  ((-(d * katt) - log(d) - acj) - f.a_obs[base + j]);
+                                  ((-(d * katt) - htm_log(d) - acj) - f.a_obs[base + j]);
         }
     }
     wave_sum<2 * NPOS>(red);
@@ -293,7 +331,7 @@ __device__ __forceinline__ void event_misfit_generic(const FW &f, int ev, int la
             }
             if (f.use_amp) {
                 const double r = f.a_obs[base + j] -
-                                 ((-(d * katt) - log(d) - acj) - red[2 * p + 1] * rpsa);
+                                 ((-(d * katt) - htm_log(d) - acj) - red[2 * p + 1] * rpsa);
                 out[p] += r * r * (0.5 * f.a_prec[base + j]);
             }
         }

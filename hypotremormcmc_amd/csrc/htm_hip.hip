@@ -1929,6 +1929,22 @@ static int selftest_rawgen(const uint32_t seed[4], int n, long long start, long 
     return done(HTM_OK);
 }
 
+int htm_selftest_log(int device, const double *x, double *y, int n)
+{
+    int rc = use_device(device);
+    if (rc) return rc;
+    if (!x || !y || n < 0) return fail(HTM_EINVAL, "htm_selftest_log: null pointer or negative count");
+    if (n == 0) return HTM_OK;
+    double *d = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&d), 2 * (size_t)n * sizeof(double)));
+    auto done = [&](int code) { (void)hipFree(d); return code; };
+    if (hipMemcpy(d, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return done(fail(HTM_EHIP, "htm_selftest_log: copy in"));
+    hipLaunchKernelGGL(k_logtest, dim3((n + 255) / 256), dim3(256), 0, 0, d, d + n, n);
+    if (hipGetLastError() != hipSuccess || hipMemcpy(y, d + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+        return done(fail(HTM_EHIP, "htm_selftest_log: kernel or copy out failed"));
+    return done(HTM_OK);
+}
+
 int htm_selftest(int device)
 {
     int rc = use_device(device);

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void k_syn(FwdDev f, const double *hypo, const
     for (int j = lane; j < f.S; j += 64) {
         const double dx = x - f.sx[j], dy = y - f.sy[j], dz = z - f.sz[j];
         const double d = sqrt(dx * dx + dy * dy + dz * dz);
-        const double s = which == 0 ? d / beta - corr[j] : -(d * kPi * kFreq / qbeta) - log(d) - corr[j];
+        const double s = which == 0 ? d / beta - corr[j] : -(d * kPi * kFreq / qbeta) - htm_log(d) - corr[j];
         acc += prec[base + j] * (s - obs[base + j]);
     }
     const double mean = wave_sum1(acc) / psum;
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void k_syn(FwdDev f, const double *hypo, const
     for (int j = lane; j < f.S; j += 64) {
         const double dx = x - f.sx[j], dy = y - f.sy[j], dz = z - f.sz[j];
         const double d = sqrt(dx * dx + dy * dy + dz * dz);
-        const double s = which == 0 ? d / beta - corr[j] : -(d * kPi * kFreq / qbeta) - log(d) - corr[j];
+        const double s = which == 0 ? d / beta - corr[j] : -(d * kPi * kFreq / qbeta) - htm_log(d) - corr[j];
         o[j] = s - mean;
     }
 }
@@ -196,6 +196,13 @@ namespace htm {
 // ---------------------------------------------------------------------------------------------------
 // self-test: DPP wave_sum against a serial loop of the same tree order; device RNG against host values
 // ---------------------------------------------------------------------------------------------------
+// htm_selftest_log: the forward model's logarithm (htm_device.hpp htm_log) on n arbitrary arguments
+__global__ void k_logtest(const double *x, double *y, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = htm_log(x[i]);
+}
+
 __global__ void k_selftest(const double *in, double *out_dpp, double *out_ref, uint32_t *rng_out,
                            double *rng_d)
 {

@@ -293,6 +293,10 @@ int htm_select_regress(int device, int n_sta, int n_win, const double *sta_x, co
 
 int htm_selftest(int device);
 
+/* y[i] = the device's logarithm of the amplitude term (reference src/cls_forward.f90:204, `log(d)`) for n host values:
+ * lets a test measure its error against a multi-precision logarithm (stated bound: < 1 ulp).  Synchronous. */
+int htm_selftest_log(int device, const double *x, double *y, int n);
+
 /* mod_random's generator (reference src/mod_random.f90:60-74) is linear over GF(2): the state after n draws is
  * T^n * state.  Host-only (no device needed): used to seek in a rank's stream and by the tests that pin the
  * jump tables of the device generator.  state = {x, y, z, w} as in mod_random.f90:30. */

@@ -39,6 +39,39 @@ def test_selftest_dpp_reduction_and_device_rng():
     _lib.check(_lib.load().htm_selftest(0))
 
 
+def test_device_logarithm_is_within_one_ulp():
+    """the amplitude term's log(d) (cls_forward.f90:204) is a 31-instruction routine of this build (htm_device.hpp
+    htm_log), not the device library's: its error against an 80-bit logarithm stays below 1 ulp -- the reference's
+    libm is within 1 ulp too, so the two differ by the last bit or two at most"""
+    import ctypes as C
+
+    from hypotremormcmc_amd import _lib
+
+    rng = np.random.default_rng(5)
+    x = np.concatenate([
+        np.exp(rng.uniform(-40, 40, 400_000)),                 # wide range
+        rng.uniform(0.5, 2.0, 400_000),                        # around the range-reduction seam and 1
+        1.0 + rng.uniform(-1e-3, 1e-3, 100_000),               # cancellation region
+        rng.uniform(1e-3, 1e3, 400_000),                       # distances in km
+        np.array([1.0, 2.0, 0.5, np.sqrt(0.5), np.nextafter(np.sqrt(0.5), 0), np.sqrt(2.0), 4.9e-324, 1e-310, 2.2250738585072014e-308,
+                  1.7976931348623157e308, np.nextafter(1.0, 0), np.nextafter(1.0, 2)]),
+    ])
+    y = np.empty_like(x)
+    _lib.check(_lib.load().htm_selftest_log(0, x.ctypes.data_as(_lib.dp), y.ctypes.data_as(_lib.dp), C.c_int(len(x))))
+    want = np.log(x.astype(np.longdouble))
+    ulp = np.spacing(np.abs(want.astype(np.float64)))
+    err = np.abs((y.astype(np.longdouble) - want).astype(np.float64))
+    nz = want != 0
+    worst = float(np.max(err[nz] / ulp[nz]))
+    assert worst < 1.0, (worst, x[nz][np.argmax(err[nz] / ulp[nz])])
+    assert y[x == 1.0][0] == 0.0
+    # special values: log(0) = -inf as the reference's libm gives, NaN stays NaN
+    xs = np.array([0.0, np.nan]); ys = np.empty(2)
+    _lib.check(_lib.load().htm_selftest_log(0, xs.ctypes.data_as(_lib.dp), ys.ctypes.data_as(_lib.dp), C.c_int(2)))
+    assert ys[0] == -np.inf and np.isnan(ys[1])
+    print("htm_log: worst error %.3f ulp over %d arguments" % (worst, len(x)))
+
+
 @pytest.mark.parametrize("name", ["c1", "c2", "missing", "timeonly", "fixedcorr"])
 def test_reference_known_answers(name):
     fx, data, params = load_case(name)
