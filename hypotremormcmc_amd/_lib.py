@@ -97,7 +97,7 @@ SIGNATURES = {
                                      C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "htm_select_regress": (C.c_int, [C.c_int, C.c_int, C.c_int, dp, dp, dp, C.c_double, dp, dp, dp, dp, dp]),
     "htm_selftest": (C.c_int, [C.c_int]),
-    "htm_selftest_log": (C.c_int, [C.c_int, dp, dp, C.c_int]),
+    "htm_selftest_math": (C.c_int, [C.c_int, C.c_int, dp, dp, C.c_int]),
     "htm_rng_jump": (C.c_int, [up, C.c_ulonglong, up]),
 }
 

@@ -77,7 +77,7 @@ __device__ __forceinline__ double wave_sum1(double a)
 // (log((1+s)/(1-s)) - 2s) / s^3 on [0, (3 - 2 sqrt 2)^2] (coefficients: tools/log_coefficients.py, |error| 3.1e-16),
 // result = e * ln2_hi - ((f^2/2 - (s * (f^2/2 + R) + e * ln2_lo)) - f) with a 32-bit ln2_hi so that e * ln2_hi is
 // exact.  Leading term f is exact, s enters only through a term <= 4 % of the result: measured error < 0.82 ulp
-// (tests/test_gpu_forward.py against a 50-digit logarithm; htm_selftest_log).  x = 0 -> -inf, NaN -> NaN, subnormals
+// (tests/test_gpu_forward.py against an 80-bit logarithm; htm_selftest_math).  x = 0 -> -inf, NaN -> NaN, subnormals
 // are handled by v_frexp; x < 0 and +inf (never produced by a distance) give NaN.  Every operation is an explicit
 // fma / mul / add: nothing is left to the compiler's contraction rules, the value is the same in every kernel.
 // ---------------------------------------------------------------------------------------------------
@@ -105,6 +105,22 @@ __device__ __forceinline__ double htm_log(double x)
     const double b = __builtin_fma(f, hf, -t);
     const double y = __builtin_fma(k, 0x1.62e42fee00000p-1, -(b - f));
     return x == 0.0 ? -__builtin_inf() : y;
+}
+
+// Square root of the squared distance (cls_forward.f90:115-117, :201-203), fp64: the device library's iteration
+// (v_rsq_f64 seed, one coupled Goldschmidt step, two residual corrections) without its rescaling of arguments below
+// 2^-767 and its class test -- a squared distance in km^2 is never there.  Same value as `sqrt` for every argument in
+// [2^-767, inf) (tests/test_gpu_forward.py); 0 -> 0.
+__device__ __forceinline__ double htm_sqrt(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+    g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+    return x == 0.0 ? 0.0 : g;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -231,11 +247,11 @@ __device__ __forceinline__ void event_misfit(const FW &f, const ObsRegs<NCH> &ob
                 ts[p][c] = 0.0; as[p][c] = 0.0;
                 if (f.use_time) {
                     ts[p][c] = (double)(d * rbeta32 - (float)st.tc[c]);
-                    red[2 * p] += valid ? tpr[c] * (ts[p][c] - tob[c]) : 0.0;
+                    red[2 * p] += tpr[c] * (ts[p][c] - tob[c]);
                 }
                 if (f.use_amp) {
                     as[p][c] = (double)(-(d * katt32) - __builtin_amdgcn_logf(d) * 0.69314718055994531f - (float)st.ac[c]);
-                    red[2 * p + 1] += valid ? apr[c] * (as[p][c] - aob[c]) : 0.0;
+                    red[2 * p + 1] += apr[c] * (as[p][c] - aob[c]);
                 }
             }
         }
@@ -246,16 +262,16 @@ __device__ __forceinline__ void event_misfit(const FW &f, const ObsRegs<NCH> &ob
         for (int c = 0; c < NCH; ++c) {
             const bool valid = (lane + 64 * c) < f.S;
             const double dx = px[p] - st.sx[c], dy = py[p] - st.sy[c], dz = pz[p] - st.sz[c];
-            double d = sqrt(dx * dx + dy * dy + dz * dz);
-            if (!valid) d = 1.0;
+            double d = htm_sqrt(dx * dx + dy * dy + dz * dz);
+            if (!valid) d = 1.0;     // a lane without a station: finite synthetics, and its precisions are 0 (load_obs_regs)
             ts[p][c] = 0.0; as[p][c] = 0.0;
             if (f.use_time) {
                 ts[p][c] = d * rbeta - st.tc[c];
-                red[2 * p] += valid ? tpr[c] * (ts[p][c] - tob[c]) : 0.0;
+                red[2 * p] += tpr[c] * (ts[p][c] - tob[c]);
             }
             if (f.use_amp) {
                 as[p][c] = -(d * katt) - htm_log(d) - st.ac[c];
-                red[2 * p + 1] += valid ? apr[c] * (as[p][c] - aob[c]) : 0.0;
+                red[2 * p + 1] += apr[c] * (as[p][c] - aob[c]);
             }
         }
     }
@@ -268,15 +284,14 @@ __device__ __forceinline__ void event_misfit(const FW &f, const ObsRegs<NCH> &ob
         const double a_mean = red[2 * p + 1] * rpsa;
         double m = 0.0;
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const bool valid = (lane + 64 * c) < f.S;
+        for (int c = 0; c < NCH; ++c) {       // (a lane without a station adds r * r * 0)
             if (f.use_time) {
                 const double r = tob[c] - (ts[p][c] - t_mean);
-                m += valid ? r * r * (0.5 * tpr[c]) : 0.0;
+                m += r * r * (0.5 * tpr[c]);
             }
             if (f.use_amp) {
                 const double r = aob[c] - (as[p][c] - a_mean);
-                m += valid ? r * r * (0.5 * apr[c]) : 0.0;
+                m += r * r * (0.5 * apr[c]);
             }
         }
         out[p] = m;
@@ -306,7 +321,7 @@ __device__ __forceinline__ void event_misfit_generic(const FW &f, int ev, int la
 #pragma unroll
         for (int p = 0; p < NPOS; ++p) {
             const double dx = px[p] - s_sx[j], dy = py[p] - s_sy[j], dz = pz[p] - s_sz[j];
-            const double d = sqrt(dx * dx + dy * dy + dz * dz);
+            const double d = htm_sqrt(dx * dx + dy * dy + dz * dz);
             if (f.use_time) red[2 * p] += f.t_prec[base + j] * ((d * rbeta - tcj) - f.t_obs[base + j]);
             if (f.use_amp)
                 red[2 * p + 1] += f.a_prec[base + j] *
@@ -324,7 +339,7 @@ __device__ __forceinline__ void event_misfit_generic(const FW &f, int ev, int la
 #pragma unroll
         for (int p = 0; p < NPOS; ++p) {
             const double dx = px[p] - s_sx[j], dy = py[p] - s_sy[j], dz = pz[p] - s_sz[j];
-            const double d = sqrt(dx * dx + dy * dy + dz * dz);
+            const double d = htm_sqrt(dx * dx + dy * dy + dz * dz);
             if (f.use_time) {
                 const double r = f.t_obs[base + j] - ((d * rbeta - tcj) - red[2 * p] * rpst);
                 out[p] += r * r * (0.5 * f.t_prec[base + j]);

@@ -1929,19 +1929,19 @@ static int selftest_rawgen(const uint32_t seed[4], int n, long long start, long 
     return done(HTM_OK);
 }
 
-int htm_selftest_log(int device, const double *x, double *y, int n)
+int htm_selftest_math(int device, int which, const double *x, double *y, int n)
 {
     int rc = use_device(device);
     if (rc) return rc;
-    if (!x || !y || n < 0) return fail(HTM_EINVAL, "htm_selftest_log: null pointer or negative count");
+    if (!x || !y || n < 0 || which < 0 || which > 2) return fail(HTM_EINVAL, "htm_selftest_math: null pointer, negative count or unknown function");
     if (n == 0) return HTM_OK;
     double *d = nullptr;
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&d), 2 * (size_t)n * sizeof(double)));
     auto done = [&](int code) { (void)hipFree(d); return code; };
-    if (hipMemcpy(d, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return done(fail(HTM_EHIP, "htm_selftest_log: copy in"));
-    hipLaunchKernelGGL(k_logtest, dim3((n + 255) / 256), dim3(256), 0, 0, d, d + n, n);
+    if (hipMemcpy(d, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return done(fail(HTM_EHIP, "htm_selftest_math: copy in"));
+    hipLaunchKernelGGL(k_mathtest, dim3((n + 255) / 256), dim3(256), 0, 0, which, d, d + n, n);
     if (hipGetLastError() != hipSuccess || hipMemcpy(y, d + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
-        return done(fail(HTM_EHIP, "htm_selftest_log: kernel or copy out failed"));
+        return done(fail(HTM_EHIP, "htm_selftest_math: kernel or copy out failed"));
     return done(HTM_OK);
 }
 

@@ -196,11 +196,11 @@ namespace htm {
 // ---------------------------------------------------------------------------------------------------
 // self-test: DPP wave_sum against a serial loop of the same tree order; device RNG against host values
 // ---------------------------------------------------------------------------------------------------
-// htm_selftest_log: the forward model's logarithm (htm_device.hpp htm_log) on n arbitrary arguments
-__global__ void k_logtest(const double *x, double *y, int n)
+// htm_selftest_math: the forward model's own logarithm / square root (htm_device.hpp) on n arbitrary arguments
+__global__ void k_mathtest(int which, const double *x, double *y, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) y[i] = htm_log(x[i]);
+    if (i < n) y[i] = which == 0 ? htm_log(x[i]) : which == 1 ? htm_sqrt(x[i]) : sqrt(x[i]);
 }
 
 __global__ void k_selftest(const double *in, double *out_dpp, double *out_ref, uint32_t *rng_out,

@@ -293,9 +293,11 @@ int htm_select_regress(int device, int n_sta, int n_win, const double *sta_x, co
 
 int htm_selftest(int device);
 
-/* y[i] = the device's logarithm of the amplitude term (reference src/cls_forward.f90:204, `log(d)`) for n host values:
- * lets a test measure its error against a multi-precision logarithm (stated bound: < 1 ulp).  Synchronous. */
-int htm_selftest_log(int device, const double *x, double *y, int n);
+/* y[i] = fn(x[i]) for n host values, fn = the forward model's own fp64 routines: which = 0 the logarithm of the amplitude
+ * term (reference src/cls_forward.f90:204, `log(d)`), 1 the square root of the squared distance (:115-117), 2 the device
+ * library's sqrt (what 1 must equal).  Lets a test measure them against a wider-precision result (stated bound of the
+ * logarithm: < 1 ulp).  Synchronous. */
+int htm_selftest_math(int device, int which, const double *x, double *y, int n);
 
 /* mod_random's generator (reference src/mod_random.f90:60-74) is linear over GF(2): the state after n draws is
  * T^n * state.  Host-only (no device needed): used to seek in a rank's stream and by the tests that pin the

@@ -57,7 +57,7 @@ def test_device_logarithm_is_within_one_ulp():
                   1.7976931348623157e308, np.nextafter(1.0, 0), np.nextafter(1.0, 2)]),
     ])
     y = np.empty_like(x)
-    _lib.check(_lib.load().htm_selftest_log(0, x.ctypes.data_as(_lib.dp), y.ctypes.data_as(_lib.dp), C.c_int(len(x))))
+    _lib.check(_lib.load().htm_selftest_math(0, 0, x.ctypes.data_as(_lib.dp), y.ctypes.data_as(_lib.dp), C.c_int(len(x))))
     want = np.log(x.astype(np.longdouble))
     ulp = np.spacing(np.abs(want.astype(np.float64)))
     err = np.abs((y.astype(np.longdouble) - want).astype(np.float64))
@@ -67,9 +67,27 @@ def test_device_logarithm_is_within_one_ulp():
     assert y[x == 1.0][0] == 0.0
     # special values: log(0) = -inf as the reference's libm gives, NaN stays NaN
     xs = np.array([0.0, np.nan]); ys = np.empty(2)
-    _lib.check(_lib.load().htm_selftest_log(0, xs.ctypes.data_as(_lib.dp), ys.ctypes.data_as(_lib.dp), C.c_int(2)))
+    _lib.check(_lib.load().htm_selftest_math(0, 0, xs.ctypes.data_as(_lib.dp), ys.ctypes.data_as(_lib.dp), C.c_int(2)))
     assert ys[0] == -np.inf and np.isnan(ys[1])
     print("htm_log: worst error %.3f ulp over %d arguments" % (worst, len(x)))
+
+
+def test_device_square_root_equals_the_correctly_rounded_one():
+    """htm_sqrt (the device library's iteration without its rescaling of tiny arguments) on squared distances: the same
+    value as the device library's sqrt and as numpy's correctly rounded one"""
+    import ctypes as C
+
+    from hypotremormcmc_amd import _lib
+
+    rng = np.random.default_rng(6)
+    x = np.concatenate([rng.uniform(0, 1e6, 500_000), np.exp(rng.uniform(-60, 60, 500_000)), rng.uniform(0, 4, 200_000),
+                        np.array([0.0, 1.0, 2.0, 4.0, 1e-300, 1e300, 2.0 ** -700, np.nextafter(1.0, 0)])])
+    y, y_lib = np.empty_like(x), np.empty_like(x)
+    lib = _lib.load()
+    _lib.check(lib.htm_selftest_math(0, 1, x.ctypes.data_as(_lib.dp), y.ctypes.data_as(_lib.dp), C.c_int(len(x))))
+    _lib.check(lib.htm_selftest_math(0, 2, x.ctypes.data_as(_lib.dp), y_lib.ctypes.data_as(_lib.dp), C.c_int(len(x))))
+    assert np.array_equal(y, y_lib)
+    assert np.array_equal(y, np.sqrt(x))
 
 
 @pytest.mark.parametrize("name", ["c1", "c2", "missing", "timeonly", "fixedcorr"])
