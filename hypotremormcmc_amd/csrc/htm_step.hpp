@@ -285,7 +285,6 @@ __device__ __forceinline__ int chain_pass(FwRef f_, CsRef cs_, StepShared &sh, c
     unsigned long long t_last = __builtin_amdgcn_s_memtime();
 #endif
     p = __builtin_amdgcn_readfirstlane(p);
-    if constexpr (PERSIST) drain_vmem();            // this wave's commits of earlier iterations have landed (role P relies on it)
     const int4 dec = rg.dec[p & M];                 // decoded ahead of time (htm_stream.hpp)
     // wave-uniform by construction: keep them in scalar registers (addresses and selects become SALU work)
     const int type = __builtin_amdgcn_readfirstlane(dec.x), idx = __builtin_amdgcn_readfirstlane(dec.y);
@@ -511,6 +510,11 @@ __device__ __forceinline__ int chain_pass(FwRef f_, CsRef cs_, StepShared &sh, c
         T = sh.temp[c]; rT = sh.rtemp[c];
     }
     if constexpr (LOCK) { if (ok != 0) acc = metropolis(L_new, L_cur, rT, lpr, r, logr) ? 1 : 0; }   // cls_mcmc.f90:193-203
+    // This wave's chain-state stores of EARLIER iterations have landed before it reaches barrier A of this one: role P
+    // relies on it (role_prepublish_plan).  Waited for here, at the end of the pass -- every load of the step has been
+    // consumed by now and those stores are a whole pass old, so the wait is free; at the top of the pass it waited for
+    // the acknowledgements of the post phase's stores.
+    if constexpr (PERSIST) drain_vmem();
     if (lane == 0) {
         const int cool = (T < 1.0 + kEps) ? 1 : 0;
         Proposal &pr = sh.prop[c];
@@ -656,7 +660,7 @@ __device__ __forceinline__ bool swap_plan(CsRef cs_, const StepShared &sh, const
 // role P (k_mcmc), lanes <-> chains: the next iteration's steps are already decoded in the stream window, so a
 // chain whose NEXT step needs the full evaluation (types 1..4) can have its order out now -- one roles phase,
 // one post phase and one step front (~2 us) before its own wave would send it.  Only for chains that did not
-// commit in this iteration: their state stores have provably landed (every wave drains at the top of its pass).
+// commit in this iteration: their state stores have provably landed (every wave drains before the commit of its pass).
 // The chain wave recognises the order by its start position and goes straight to collecting the partial sums.
 // start of the chain step n steps after the one that starts at pos (hop tables cover kHops steps at a time)
 __device__ __forceinline__ int hop_ahead(const Ring &rg, int pos, int n)
