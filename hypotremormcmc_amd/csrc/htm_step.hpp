@@ -285,13 +285,18 @@ __device__ __forceinline__ int chain_pass(FwRef f_, CsRef cs_, StepShared &sh, c
     unsigned long long t_last = __builtin_amdgcn_s_memtime();
 #endif
     p = __builtin_amdgcn_readfirstlane(p);
+    // the kernel arguments of the step's front, requested in ONE batch before the stream window is read (left to the
+    // compiler they are loaded one dependent round trip after the other, next to their uses, behind the window's data)
+    const double *xall_ = cs.xall, *muall_ = cs.muall, *rs2all_ = cs.rs2all, *stall_ = cs.stall;
+    const int *ptall_ = cs.ptall;
+    const int nc_ = cs.n_chains, S_ = cs.S, nh = 3 * cs.E;
     const int4 dec = rg.dec[p & M];                 // decoded ahead of time (htm_stream.hpp)
+    asm volatile("" : "+s"(xall_), "+s"(muall_), "+s"(rs2all_), "+s"(stall_), "+s"(ptall_));
     // wave-uniform by construction: keep them in scalar registers (addresses and selects become SALU work)
     const int type = __builtin_amdgcn_readfirstlane(dec.x), idx = __builtin_amdgcn_readfirstlane(dec.y);
     const int evt = __builtin_amdgcn_readfirstlane(dec.z), dec_w = __builtin_amdgcn_readfirstlane(dec.w);
     const double g = rg.pg[p & M], r_ring = rg.pr[p & M], logr_ring = rg.plogr[p & M];
     const bool partial = evt > 0 && iter > 1;       // hypo_tremor_mcmc.f90:246
-    const int nc_ = cs.n_chains, S_ = cs.S, nh = 3 * cs.E;
     const int off_tc = nc_, off_qs = nc_ + nc_ * S_, off_ac = 2 * nc_ + nc_ * S_, off_hy = 2 * nc_ + 2 * nc_ * S_;
     const int goff = type == 1 ? 0 : type == 2 ? off_tc : type == 3 ? off_qs : type == 4 ? off_ac : off_hy;
     const int gnx = (type == 1 || type == 3) ? 1 : (type == 2 || type == 4) ? S_ : nh;
@@ -304,10 +309,10 @@ __device__ __forceinline__ int chain_pass(FwRef f_, CsRef cs_, StepShared &sh, c
     int goffs = o;
     goffs = lane == 1 ? o_h : goffs; goffs = lane == 2 ? o_h + 1 : goffs; goffs = lane == 3 ? o_h + 2 : goffs;
     goffs = lane == 4 ? c : goffs; goffs = lane == 5 ? off_qs + c : goffs;
-    const double gathered_v = cs.xall[goffs];
-    const double mu = ld_const(cs.muall + o), rs2 = ld_const(cs.rs2all + o), step = ld_const(cs.stall + o);
-    const int ptype = ld_const(cs.ptall + o);
-    const double *tc = cs.xall + off_tc + c * S_, *ac = cs.xall + off_ac + c * S_;
+    const double gathered_v = xall_[goffs];
+    const double mu = ld_const(muall_ + o), rs2 = ld_const(rs2all_ + o), step = ld_const(stall_ + o);
+    const int ptype = ld_const(ptall_ + o);
+    const double *tc = xall_ + off_tc + c * S_, *ac = xall_ + off_ac + c * S_;
     StaRegs<(NCH > 0 ? NCH : 1)> st;
     ObsRegs<(NCH > 0 ? NCH : 1)> ob;
     if (partial) {
@@ -330,7 +335,7 @@ __device__ __forceinline__ int chain_pass(FwRef f_, CsRef cs_, StepShared &sh, c
                 dhint = true;
                 d_e = __builtin_amdgcn_readfirstlane(pv.evt) - 1;
                 const int vzd = opaque_zero();
-                const double *hypd = cs.xall + off_hy + c * nh + 3 * d_e;
+                const double *hypd = xall_ + off_hy + c * nh + 3 * d_e;
                 d_ex = ld_state(hypd, vzd); d_ey = ld_state(hypd + 1, vzd); d_ez = ld_state(hypd + 2, vzd);
                 load_sta_regs<NCH>(st, f.S, lane, s_sx, s_sy, s_sz, tc, ac, 0, -1, 0.0);
                 load_obs_regs<NCH, F32>(ob, f, d_e, lane);
