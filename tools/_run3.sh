@@ -1,7 +1,7 @@
 set -e
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-A=hypotremormcmc_amd/lib/${BASE:-libhtm_hip_drain.so}
+A=hypotremormcmc_amd/lib/${BASE:-libhtm_hip_karg.so}
 B=hypotremormcmc_amd/lib/libhtm_hip.so
 timeout -k 10 600 python -m pytest tests/test_gpu_chains.py -x -q > gpurun_out/log_gputests.txt 2>&1 || { tail -30 gpurun_out/log_gputests.txt; exit 1; }
 tail -2 gpurun_out/log_gputests.txt
