@@ -30,7 +30,7 @@ thread_local std::string g_err;
 
 int fail(int code, const char *fmt, ...)
 {
-    char buf[512];
+    char buf[1024];
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(buf, sizeof(buf), fmt, ap);
@@ -767,6 +767,8 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
     if ((rc = dev_alloc(hc->pool, &d.smp_chain, d.cap_smp))) return cleanup(rc);
     if ((rc = dev_alloc(hc->pool, &d.smp_data, (size_t)d.cap_smp * hc->rec_len))) return cleanup(rc);
     d.slog_i = nullptr; d.slog_d = nullptr;
+    if ((rc = dev_alloc(hc->pool, &d.diag, 32))) return cleanup(rc);
+    HIPCHK(hipMemset(d.diag, 0, 32 * sizeof(unsigned long long)));
     d.stamps = nullptr;
 #ifdef HTM_STAMPS
     if ((rc = dev_alloc(hc->pool, &d.stamps, 128))) return cleanup(rc);
@@ -956,7 +958,37 @@ static int ctrl_error(const htm_chains *hc)
     case -4: return fail(HTM_ESTATE, "device RNG window exhausted (iteration %d)", hc->h_ctrl.iter_done + 1);
     case -5: return fail(HTM_EOVERFLOW, "record buffer overflow in lock-step mode: call htm_chains_drain more often");
     case -6: return fail(HTM_EDESYNC, "swap records of the ranks carry different iteration numbers");
-    case -8: return fail(HTM_ESTATE, "persistent workers did not answer within 5 s (iteration %d)", hc->h_ctrl.iter_done + 1);
+    case -8: {
+        // what the chain wave that gave up was waiting for (ChainsDev::diag), the chain's order slot and how many workers answered
+        const ChainsDev &d = hc->dev;
+        unsigned long long dg[32] = {0}, slot[kGranPerSlot] = {0};
+        char extra[900] = "";
+        if (hipMemcpy(dg, d.diag, sizeof(dg), hipMemcpyDeviceToHost) == hipSuccess && dg[0] == 1 && (int)dg[1] < d.n_chains) {
+            const int c = (int)dg[1];
+            int answered = 0;
+            std::vector<unsigned long long> pg((size_t)d.n_workers * d.pgran_stride);
+            if (hipMemcpy(slot, d.slots + (size_t)c * kGranPerSlot, sizeof(slot), hipMemcpyDeviceToHost) == hipSuccess &&
+                hipMemcpy(pg.data(), d.pgran + (size_t)c * d.n_workers * d.pgran_stride, pg.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+                for (int k = 0; k < d.n_workers; ++k)
+                    if ((unsigned)(pg[(size_t)k * d.pgran_stride] >> 32) == (unsigned)dg[2]) ++answered;
+                snprintf(extra, sizeof(extra),
+                         "; chain %d waited for the sums of order %08llx (%s, step type %llu index %llu at stream position %llu, %s pass); "
+                         "%d of %d workers answered; the chain's order slot holds tags %08llx %08llx %08llx %08llx %08llx %08llx %08llx %08llx, launch word %llu",
+                         c, dg[2], dg[3] ? (dg[4] == 2 ? "sent two iterations ahead" : "sent one iteration ahead") : "sent by the chain's own wave",
+                         dg[7], dg[8], dg[6], dg[11] ? "first" : "repeated", answered, d.n_workers,
+                         slot[0] >> 32, slot[1] >> 32, slot[2] >> 32, slot[3] >> 32, slot[4] >> 32, slot[5] >> 32, slot[6] >> 32, slot[7] >> 32,
+                         slot[0] & 0xffffffffull);
+            }
+            if (dg[16] == 1) {
+                const size_t n = strlen(extra);
+                snprintf(extra + n, sizeof(extra) - n,
+                         "; worker 0 has been waiting for more than a second for the commit named by order %08llx of chain %llu: element %llu "
+                         "should read %016llx, reads %016llx (order word %llx, element left out %llu)",
+                         dg[18], dg[17], dg[19], dg[20], dg[21], dg[22], dg[23]);
+            }
+        }
+        return fail(HTM_ESTATE, "persistent workers did not answer within 5 s (iteration %d)%s", hc->h_ctrl.iter_done + 1, extra);
+    }
     case -7: return fail(HTM_ESTATE, "random stream underrun in lock-step mode (iteration %d)", hc->h_ctrl.iter_done + 1);
     case -10: return fail(HTM_ESTATE, "swap records of the other ranks did not arrive within 20 s (iteration %d)", hc->h_ctrl.iter_done + 1);
     case -11: return fail(HTM_ESTATE, "another rank reported a failure (iteration %d)", hc->h_ctrl.iter_done + 1);
@@ -1776,6 +1808,19 @@ int htm_chains_read_stamps(htm_chains *hc, unsigned long long out[128])
 {
     HIPCHK(hipStreamSynchronize(hc->fwd->stream));
     HIPCHK(hipMemcpy(out, hc->dev.stamps, 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return HTM_OK;
+}
+/* diagnostics of a wedged hand-off: out[0..7] = the order slot of `chain` (replica 0), out[8..8+2*n) = the first n workers'
+ * partial-sum granules of that chain (n <= 28) */
+int htm_chains_read_handoff(htm_chains *hc, int chain, unsigned long long out[64])
+{
+    (void)hipStreamSynchronize(hc->fwd->stream);
+    const ChainsDev &d = hc->dev;
+    if (chain < 0 || chain >= d.n_chains) return fail(HTM_EINVAL, "chain out of range");
+    HIPCHK(hipMemcpy(out, d.slots + (size_t)chain * kGranPerSlot, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    const int n = std::min(28, d.n_workers);
+    for (int k = 0; k < n; ++k)
+        HIPCHK(hipMemcpy(out + 8 + 2 * k, d.pgran + ((size_t)chain * d.n_workers + k) * d.pgran_stride, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return HTM_OK;
 }
 #endif

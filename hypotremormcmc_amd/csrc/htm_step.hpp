@@ -260,6 +260,28 @@ __device__ __forceinline__ bool metropolis(double L_new, double L_cur, double T,
 #define CSTAMP(k) do { } while (0)
 #endif
 
+// Orders of role P that a step's ACTUAL start position proves wrong are taken back before the step runs (k_mcmc, chain
+// wave, after role P of this iteration is through).  A wave's first chain starts exactly where role P predicted (same
+// base, same hop table); with more chains than waves the later ones start where the wave's previous chain really ended,
+// and in the lock-step kernel every step restarts elsewhere when a swap's judge draw turns out to be this rank's.  Then
+// (a) an order addressed to this iteration but to another start position will never be used, and (b) a two-ahead order
+// for the next iteration was written around ANOTHER step in between: it names the chain's latest commit for the workers
+// to wait for, and this step may overwrite that very element (role P ruled that out for the step it predicted only).
+// Workers waiting for a value that never shows serve no other order -- every chain would end up waiting for them -- and
+// role P's own stale checks run one iteration too late for that.  The slot holds one order: whatever is on the books goes.
+__device__ __forceinline__ void drop_disproved_orders(CsRef cs, StepShared &sh, int c, int p, int iter, int lane)
+{
+    const int book_a = sh.pre_p[iter & 1][c], book_b = sh.pre_p[(iter + 1) & 1][c];
+    if (__builtin_expect((book_a != -1 && book_a != p) || book_b != -1, 0)) {
+        const bool dead_a = book_a != -1 && book_a != p;
+        const bool dead_b = book_b != -1 && sh.pre_mode[(iter + 1) & 1][c] == 2 && sh.pre_pa[(iter + 1) & 1][c] != p;
+        if ((dead_a || dead_b) && lane == 0) {
+            void_slot(cs, c);
+            sh.pre_p[0][c] = -1; sh.pre_p[1][c] = -1;
+        }
+    }
+}
+
 // One chain step: proposal, single-event partial update, Metropolis decision and -- speculatively -- its
 // commit (cls_mcmc.f90:186-189,:207-219).  The commit is final unless the validation finds that an earlier
 // chain's Rayleigh prior rejected (then the step is undone and repeated one draw earlier, see undo_chain).
@@ -485,7 +507,12 @@ __device__ __forceinline__ int chain_pass(FwRef f_, CsRef cs_, StepShared &sh, c
                     issue(0);
                     if (complete(1)) { which = 1; break; }
                     if (__builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) {
-                        if (lane == 0) sh.c.err = -8;
+                        if (lane == 0) {
+                            sh.c.err = -8;
+                            unsigned long long *dg = cs.diag;          // what was waited for: the host puts it into its message
+                            dg[1] = c; dg[2] = tag; dg[3] = pre; dg[4] = pre_mode; dg[5] = iter; dg[6] = p; dg[7] = type; dg[8] = idx;
+                            dg[9] = hi[0][0]; dg[10] = lo[0][0]; dg[11] = first_pass; dg[12] = sh.start[c]; dg[0] = 1;
+                        }
 #ifdef HTM_STAMPS
                         if (lane == 0 && cs.stamps) {          // what was waited for (tools/diag_wait.py)
                             cs.stamps[100] = 1; cs.stamps[101] = c; cs.stamps[102] = tag; cs.stamps[103] = pre; cs.stamps[104] = pre_mode;
@@ -1170,6 +1197,9 @@ __device__ __forceinline__ void step_body(FwRef f_, CsRef cs_, int mode, int tar
                     }                                                       // else: optimistic start, c steps after base (below)
                     int base_used = sh.base;
                     if (first && !have_p) p = c == 0 ? base_used : base_used + rg.hop[(base_used & rg.mask) * kHops + c - 1];
+                    // a later round of this wave: the step starts where the previous chain ended (role P is through: the
+                    // wave's first step waited for it)
+                    if constexpr (PERSIST) { if (first && have_p && have_prev && rolep_on) drop_disproved_orders(cs, sh, c, p, iter, lane); }
                     [[maybe_unused]] int xw = (lockrun && xpend && first && !have_p) ? iter - 1 : -1;       // the wave's first step of the iteration waits for the swap
                     if constexpr (lockrun) {
                         int r;
@@ -1181,6 +1211,7 @@ __device__ __forceinline__ void step_body(FwRef f_, CsRef cs_, int mode, int tar
                             base_used = sh.base;
                             p = hop_ahead(rg, base_used, c);
                             xw = -1;
+                            if (have_prev && rolep_on) drop_disproved_orders(cs, sh, c, p, iter, lane);   // (the pass left after its wait for role P)
                         }
                         if (r == kPassAbort) break;                             // the job stops after the iteration before
                         p = r;
@@ -1480,6 +1511,13 @@ __device__ __forceinline__ void worker_body(FwRef f_, CsRef cs_, unsigned long l
                                 break;
                             }
                             if ((spins & 63u) == 63u) {          // fail-stops only
+                                if (w == 0 && lane == 0 && cs.diag[16] == 0 && __builtin_amdgcn_s_memrealtime() - t0 > 100000000ull) {
+                                    // a second in this wait: leave a note for the host's error message (once)
+                                    unsigned long long *dg = cs.diag;
+                                    dg[17] = chain; dg[18] = tag; dg[19] = s_job[3]; dg[20] = want;
+                                    dg[21] = (unsigned long long)__double_as_longlong(ld_agent(cs.xall + s_job[3])); dg[22] = s_job[0]; dg[23] = s_job[6];
+                                    dg[16] = 1;
+                                }
                                 if (ld_agent(&cs.ps->quit) > launch) { r = -1; tag = 0; chain = -1; break; }
                                 if (__builtin_amdgcn_s_memrealtime() - t0 > 3000000000ull) { r = -1; tag = 0; chain = -1; break; }
                             }

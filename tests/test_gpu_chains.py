@@ -342,19 +342,21 @@ def test_assorted_shapes_against_oracle(shape):
         assert s.temp == o["temp"]
 
 
-@pytest.mark.parametrize("E,S,nc,seed,sz", [(64, 64, 8, 1, 4.0), (64, 64, 8, 3, 12.0), (1000, 64, 8, 2, 8.0),
-                                           (1000, 64, 8, 4, 20.0), (30, 20, 7, 3, 12.0)])
-def test_rejection_heavy_runs_against_oracle(E, S, nc, seed, sz):
+@pytest.mark.parametrize("E,S,nc,seed,sz,n_iter", [(64, 64, 8, 1, 4.0, 3000), (64, 64, 8, 3, 12.0, 3000), (1000, 64, 8, 2, 8.0, 3000),
+                                                  (1000, 64, 8, 4, 20.0, 3000), (30, 20, 7, 3, 12.0, 3000),
+                                                  (64, 32, 27, 3, 20.0, 4000), (64, 32, 27, 4, 20.0, 9000)])
+def test_rejection_heavy_runs_against_oracle(E, S, nc, seed, sz, n_iter):
     """Depth steps several times the prior width: the Rayleigh prior rejects every few steps, each rejection shifts the
     stream positions of the chains behind it, passes are repeated, and the orders role P sent one and two iterations
     ahead miss their steps, are voided or come back into position.  (Each of these configurations exposed a fault of
     the two-ahead orders once: sums overwritten by the chain's own order, a step coming back to the position an order
-    was written for after a repeated pass, workers reading a step that was taken back.  tools/stress_rejections.py
-    runs the longer version.)"""
+    was written for after a repeated pass, workers reading a step that was taken back; the two 27-chain runs: with more
+    chains than waves a step starts where the wave's previous chain really ended, not where role P predicted, and
+    overwrote the very element a two-ahead order told the workers to wait for -- iterations 3139 and 8614 of these
+    runs stopped with "workers did not answer" on some boxes.  tools/stress_rejections.py runs the longer version.)"""
     from hypotremormcmc_amd import synth
     from oracle import oracle
 
-    n_iter = 3000
     data = synth.make_synthetic(E, S, 100 + seed)
     params = dict(synth.DEFAULT_PARAMS, n_procs=1, n_chains=nc, n_cool=2, n_iter=n_iter, n_burn=n_iter // 2,
                   n_interval=3, step_size_z=sz, step_size_vs=0.4)
@@ -363,7 +365,7 @@ def test_rejection_heavy_runs_against_oracle(E, S, nc, seed, sz):
     sets[0].run(n_iter)
     it, lk = job.likelihood_trace(0)
     gi, _, gl = sets[0].likelihood_trace()
-    assert len(gi) == 2000 and np.array_equal(gi, it)
+    assert len(gi) == len(it) > n_iter // 2 and np.array_equal(gi, it)
     np.testing.assert_allclose(gl, lk, rtol=RTOL_TRACE)
     assert sets[0].rng_state() == job.rng_state(0)
     a, b = sets[0].counts(); oa, ob = job.counts()

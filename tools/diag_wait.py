@@ -29,3 +29,9 @@ lib.htm_chains_read_stamps(cs.handle, a)
 names = ["wait (1 sums, 2 seen value)", "chain", "tag", "pre", "pre_mode", "iter", "p", "type", "idx", "granule hi", "granule lo", "start[c]"]
 print("master:", {n: hex(v) for n, v in zip(names, a[100:112])})
 print("worker 0 (commit wait timed out):", [hex(x) for x in a[112:120]])
+if a[100]:
+    lib.htm_chains_read_handoff.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
+    h = (C.c_uint64 * 64)()
+    lib.htm_chains_read_handoff(cs.handle, int(a[101]), h)
+    print("order slot of the chain (tag:payload):", ["%x:%x" % (v >> 32, v & 0xffffffff) for v in h[0:8]])
+    print("tags of the first workers' sums:", ["%x" % (v >> 32) for v in h[8:64:2]])
