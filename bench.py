@@ -337,6 +337,10 @@ def main(argv=None):
         # Its launches ARE the timed region; duration from the HIP events the library records on the kernels'
         # stream around them, algorithmic bytes from the evaluations they performed.
         st = cs.last_run_stats()
+        try:
+            out["config"]["orders_put_aside_by_worker_0"] = cs.handoff_stats()["orders_put_aside"]   # health of the hand-off: 0
+        except Exception:      # an older build of the library (tools/ab.sh)
+            pass
         persistent = os.environ.get("HTM_PERSIST", "1") != "0"
         n_launch = max(1, st["graph_launches"])
         bytes_region = st["full_evals"] * b_full + st["partial_evals"] * b_part

@@ -239,6 +239,12 @@ class ChainSet:
         return dict(step_us=su.value, step_launches=sn.value, full_us=fu.value, full_launches=fn.value,
                     full_evals=fe.value, partial_evals=pe.value)
 
+    def handoff_stats(self):
+        """orders worker block 0 put aside (named commit not visible within 20 us); 0 in a healthy run"""
+        n = C.c_int64()
+        check(self._lib.htm_chains_handoff_stats(self.handle, C.byref(n)))
+        return dict(orders_put_aside=n.value)
+
     def last_run_stats(self):
         us = C.c_double(); g = C.c_int(); f = C.c_int64(); p = C.c_int64()
         check(self._lib.htm_chains_last_run_stats(self.handle, C.byref(us), C.byref(g), C.byref(f), C.byref(p)))

@@ -501,6 +501,7 @@ struct ChainsDev {
     int xg;                          // granules per record = 2 * (4 + 2 n_chains) + 2
     StreamDev stream;
     unsigned long long *stamps;      // diagnostic builds (-DHTM_STAMPS) only, else nullptr
+    int dbg;                         // test switches (bit 0: HTM_DEBUG_NO_DROP, chain waves do not take disproved orders back)
     unsigned long long *diag;        // [32] what a wait that gave up was waiting for (written once, on the failure path; the host reports it)
 };
 

@@ -767,6 +767,7 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
     if ((rc = dev_alloc(hc->pool, &d.smp_chain, d.cap_smp))) return cleanup(rc);
     if ((rc = dev_alloc(hc->pool, &d.smp_data, (size_t)d.cap_smp * hc->rec_len))) return cleanup(rc);
     d.slog_i = nullptr; d.slog_d = nullptr;
+    { const char *e = getenv("HTM_DEBUG_NO_DROP"); d.dbg = (e && atoi(e) != 0) ? 1 : 0; }
     if ((rc = dev_alloc(hc->pool, &d.diag, 32))) return cleanup(rc);
     HIPCHK(hipMemset(d.diag, 0, 32 * sizeof(unsigned long long)));
     d.stamps = nullptr;
@@ -978,6 +979,10 @@ static int ctrl_error(const htm_chains *hc)
                          dg[7], dg[8], dg[6], dg[11] ? "first" : "repeated", answered, d.n_workers,
                          slot[0] >> 32, slot[1] >> 32, slot[2] >> 32, slot[3] >> 32, slot[4] >> 32, slot[5] >> 32, slot[6] >> 32, slot[7] >> 32,
                          slot[0] & 0xffffffffull);
+            }
+            if (dg[24]) {
+                const size_t n = strlen(extra);
+                snprintf(extra + n, sizeof(extra) - n, "; worker 0 put %llu orders aside (named commit not visible within 20 us)", dg[24]);
             }
             if (dg[16] == 1) {
                 const size_t n = strlen(extra);
@@ -1800,6 +1805,16 @@ int htm_chains_last_run_stats(htm_chains *hc, double *device_us, int *graph_laun
     if (graph_launches) *graph_launches = hc->last_graph_launches;
     if (full_evals) *full_evals = hc->last_full;
     if (partial_evals) *partial_evals = hc->last_part;
+    return HTM_OK;
+}
+
+int htm_chains_handoff_stats(htm_chains *hc, int64_t *orders_put_aside)
+{
+    if (!hc || !orders_put_aside) return fail(HTM_EINVAL, "NULL argument");
+    HIPCHK(hipStreamSynchronize(hc->fwd->stream));
+    unsigned long long v = 0;
+    HIPCHK(hipMemcpy(&v, hc->dev.diag + 24, sizeof(v), hipMemcpyDeviceToHost));
+    *orders_put_aside = (int64_t)v;
     return HTM_OK;
 }
 

@@ -271,6 +271,7 @@ __device__ __forceinline__ bool metropolis(double L_new, double L_cur, double T,
 // role P's own stale checks run one iteration too late for that.  The slot holds one order: whatever is on the books goes.
 __device__ __forceinline__ void drop_disproved_orders(CsRef cs, StepShared &sh, int c, int p, int iter, int lane)
 {
+    if (__builtin_expect(cs.dbg & 1, 0)) return;     // HTM_DEBUG_NO_DROP=1 (tests: the workers' deferral alone must keep the job alive)
     const int book_a = sh.pre_p[iter & 1][c], book_b = sh.pre_p[(iter + 1) & 1][c];
     if (__builtin_expect((book_a != -1 && book_a != p) || book_b != -1, 0)) {
         const bool dead_a = book_a != -1 && book_a != p;
@@ -1427,6 +1428,14 @@ __device__ __forceinline__ void worker_body(FwRef f_, CsRef cs_, unsigned long l
     unsigned last_tag[kGroups];
 #pragma unroll
     for (int j = 0; j < kGroups; ++j) last_tag[j] = 0;
+    // An order whose named commit does not show within kDeferTicks is put aside -- its tag stays in last_tag, so the polls
+    // skip it -- and becomes eligible again kDeferTicks later (if the slot still holds it): a wait that the master's
+    // signals should have ended (void_slot) must never keep the worker from the other chains' orders.
+    constexpr unsigned long long kDeferTicks = 2000ull;       // 20 us of the 100 MHz clock; legitimate waits are a few us
+    // (kept in LDS, wave 0 only: scalar registers are what this kernel is short of)
+    int *s_defer_chain = reinterpret_cast<int *>(smem + 192);
+    unsigned long long *s_defer_until = reinterpret_cast<unsigned long long *>(smem + 200);
+    if (threadIdx.x == 0) { *s_defer_chain = -1; *s_defer_until = 0ull; }
     // [0] type | idx << 3, [1] x_new high, [2] x_new low, [3] committed element or ~0, [4] its value high, [5] low,
     // [6] element (+1) whose value, as seen by this evaluation, is to be reported (two-ahead orders), 0 = none
     unsigned *s_job = reinterpret_cast<unsigned *>(smem + 160);
@@ -1482,7 +1491,17 @@ __device__ __forceinline__ void worker_body(FwRef f_, CsRef cs_, unsigned long l
             };
 #pragma unroll
             for (int b = 0; b < kPolls; ++b) if (b < npoll) issue(b);
+            auto rearm = [&](int dc) __attribute__((always_inline)) {       // the order put aside may be taken again
+#pragma unroll
+                for (int j = 0; j < kGroups; ++j)
+                    if (j == (dc >> 3) && lane == 8 * (dc & 7)) last_tag[j] = 0;
+                if (lane == 0) *s_defer_chain = -1;
+            };
             for (bool spin = true; spin;) {
+                {
+                    const int dc = *s_defer_chain;
+                    if (__builtin_expect(dc >= 0, 0)) { if (__builtin_amdgcn_s_memrealtime() > *s_defer_until) rearm(dc); }
+                }
 #pragma unroll
                 for (int b = 0; b < kPolls; ++b) {
                     if (b >= npoll) continue;
@@ -1495,8 +1514,11 @@ __device__ __forceinline__ void worker_body(FwRef f_, CsRef cs_, unsigned long l
                         // (the other waves read the chain's state only after this wave has seen it).  If the master takes the
                         // order back meanwhile -- the chain repeated a pass and rewrote the element, so the value never shows --
                         // it says so by rewriting the slot (void_slot, or a newer order): the order is dropped and the worker
-                        // keeps polling.  No clock decides here; the bounds below are fail-stops (master gone, 30 s).
+                        // keeps polling.  A wait that lasts longer than any commit takes to land puts the order ASIDE for a while
+                        // (kDeferTicks): it is neither dropped nor answered on the clock's say-so, the worker merely serves the other
+                        // chains' orders meanwhile and looks again later.  The further bounds are fail-stops (master gone, 30 s).
                         const unsigned long long want = ((unsigned long long)s_job[4] << 32) | s_job[5];
+                        const unsigned long long tw0 = __builtin_amdgcn_s_memrealtime();
                         for (unsigned spins = 0;; ++spins) {
                             if ((unsigned long long)__double_as_longlong(ld_agent(cs.xall + s_job[3])) == want) break;
                             const unsigned now_tag = (unsigned)(ld_agent(slots + (size_t)chain * kGranPerSlot) >> 32);
@@ -1508,6 +1530,14 @@ __device__ __forceinline__ void worker_body(FwRef f_, CsRef cs_, unsigned long l
                                 }
 #endif
                                 r = 0; tag = 0; chain = -1;      // taken back: keep polling
+                                break;
+                            }
+                            if ((spins & 7u) == 7u && __builtin_amdgcn_s_memrealtime() - tw0 > kDeferTicks) {
+                                // not now: back to the polls, this order aside (it stays in last_tag until it is re-armed)
+                                if (w == 0 && lane == 0) cs.diag[24] += 1;          // (reported with error -8)
+                                { const int dc = *s_defer_chain; if (dc >= 0) rearm(dc); }
+                                if (lane == 0) { *s_defer_chain = chain; *s_defer_until = __builtin_amdgcn_s_memrealtime() + kDeferTicks; }
+                                r = 0; tag = 0; chain = -1;
                                 break;
                             }
                             if ((spins & 63u) == 63u) {          // fail-stops only

@@ -257,6 +257,11 @@ int htm_chains_steplog_read(htm_chains *hc, int *n, int32_t *irows, double *drow
 int htm_chains_last_run_stats(htm_chains *hc, double *device_us, int *graph_launches,
                               int64_t *full_evals, int64_t *partial_evals);
 
+/* Health of the in-kernel hand-off since the chain set was created: *orders_put_aside = how many times worker block 0 put an
+ * order aside because the commit it names did not show within 20 us (0 in a healthy run: the chain waves take such orders
+ * back themselves; the other worker blocks behave alike).  Synchronises with the handle's stream. */
+int htm_chains_handoff_stats(htm_chains *hc, int64_t *orders_put_aside);
+
 /* Same work as htm_chains_run, but every kernel is launched eagerly and bracketed by its own pair of HIP
  * events on the handle's stream, so that the average duration of each kernel comes from the run itself:
  * k_step (proposals + partial updates + judge + swap; may cover several iterations per launch) and k_full

@@ -372,6 +372,29 @@ def test_rejection_heavy_runs_against_oracle(E, S, nc, seed, sz, n_iter):
     assert np.array_equal(a, oa) and np.array_equal(b, ob)
 
 
+@pytest.mark.parametrize("seed,n_iter", [(3, 4000), (4, 9000)])
+def test_workers_put_an_unsatisfiable_wait_aside(seed, n_iter, monkeypatch):
+    """Second line of defence of the hand-off: with the chain waves' take-back of disproved orders switched off
+    (HTM_DEBUG_NO_DROP=1) the two 27-chain runs above meet the order whose named commit never shows.  The workers put it
+    aside after 20 us and serve the other chains; role P's stale check voids it an iteration later: the run ends, equal
+    to the oracle, instead of stopping with error -8."""
+    from hypotremormcmc_amd import synth
+    from oracle import oracle
+
+    monkeypatch.setenv("HTM_DEBUG_NO_DROP", "1")
+    data = synth.make_synthetic(64, 32, 100 + seed)
+    params = dict(synth.DEFAULT_PARAMS, n_procs=1, n_chains=27, n_cool=2, n_iter=n_iter, n_burn=n_iter // 2,
+                  n_interval=3, step_size_z=20.0, step_size_vs=0.4)
+    job = oracle.Job(params, data); job.run(n_iter)
+    _, sets = _build_world(data, params)
+    sets[0].run(n_iter)
+    it, lk = job.likelihood_trace(0)
+    gi, _, gl = sets[0].likelihood_trace()
+    assert np.array_equal(gi, it)
+    np.testing.assert_allclose(gl, lk, rtol=RTOL_TRACE)
+    assert sets[0].rng_state() == job.rng_state(0)
+
+
 @pytest.mark.parametrize("lockstep", [False, True])
 def test_random_stream_ring_wraps_around(lockstep, monkeypatch):
     """The rank's random stream lives in rings over the absolute position (2^20 by default, i.e. one wrap every

@@ -19,7 +19,7 @@ obs = ObsData.from_arrays(data.sta_x, data.sta_y, data.t_obs, data.t_stdv, data.
 fwd, cs = driver.build_rank(params, data.sta_x, data.sta_y, data.sta_z, obs, 0, n_procs=1)
 try:
     cs.run(n_iter)
-    print("ran fine")
+    print("ran fine", cs.handoff_stats())
 except Exception as e:      # noqa: BLE001
     print("ERR", e)
 lib = _lib.load()
