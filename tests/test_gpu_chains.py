@@ -433,7 +433,8 @@ def _gloo_device_worker(rank, world, port, name, q, transport="staged"):
         # the ranks leave a launch only TOGETHER: tiny record buffers and a short random-stream ring make some rank ask
         # everybody to stop every few iterations (its buffers) / few thousand (its stream), at different times per rank
         os.environ["HTM_STREAM_CAP"] = "131072"
-        caps = dict(lik_capacity=24, sample_capacity=24)
+        n_ch = int(name.split(":")[3]) if name.startswith("synth:") else 8
+        caps = dict(lik_capacity=max(24, 3 * n_ch), sample_capacity=max(24, 3 * n_ch))
         transport = "direct"
     import torch.distributed as dist
 
@@ -443,7 +444,21 @@ def _gloo_device_worker(rank, world, port, name, q, transport="staged"):
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        fx, data, params = load_case(name)
+        if name.startswith("synth:"):
+            # rejection-heavy synthetic job, more chains per rank than chain waves: checked against the oracle's lock-step run
+            from hypotremormcmc_amd import synth
+            from oracle import oracle
+
+            E, S, nc, seed, n_iter = (int(x) for x in name.split(":")[1:6])
+            data = synth.make_synthetic(E, S, 100 + seed)
+            params = dict(synth.DEFAULT_PARAMS, n_procs=world, n_chains=nc, n_cool=2, n_iter=n_iter, n_burn=n_iter // 2,
+                          n_interval=3, step_size_z=20.0, step_size_vs=0.4)
+            job = oracle.Job(params, data); job.run(n_iter)
+            oa, ob = job.counts()
+            fx = {f"lik_iter_{rank}": job.likelihood_trace(rank)[0], f"lik_{rank}": job.likelihood_trace(rank)[1],
+                  "n_propose": oa, "n_accept": ob}
+        else:
+            fx, data, params = load_case(name)
         obs = ObsData.from_arrays(data.sta_x, data.sta_y, data.t_obs, data.t_stdv, data.a_obs, data.a_stdv)
         fwd, cs = driver.build_rank(params, data.sta_x, data.sta_y, data.sta_z, obs, rank, n_procs=world, device=0, **caps)
         tw = TorchWorld(cs)
@@ -465,7 +480,8 @@ def _gloo_device_worker(rank, world, port, name, q, transport="staged"):
 
 @pytest.mark.parametrize("name,world,transport", [("c1", 2, "staged"), ("timeonly", 3, "staged"), ("c1", 2, "direct"),
                                                   ("timeonly", 3, "direct"), ("rejects", 2, "direct"), ("fixedcorr", 2, "direct"),
-                                                  ("rejects", 2, "direct-stops"), ("timeonly", 3, "direct-stops")])
+                                                  ("rejects", 2, "direct-stops"), ("timeonly", 3, "direct-stops"),
+                                                  ("synth:64:32:12:4:6000", 2, "direct"), ("synth:64:32:19:2:4000", 2, "direct-stops")])
 def test_torchworld_across_processes_sharing_the_gpu(name, world, transport):
     """TorchWorld + device-resident chains in 2-3 separate processes sharing the one GPU: per-rank traces and the
     reduced counters against the reference's MPI run.  "staged": gloo with host-staged records per iteration;
@@ -485,9 +501,20 @@ def test_torchworld_across_processes_sharing_the_gpu(name, world, transport):
     procs = [ctx.Process(target=_gloo_device_worker, args=(r, world, port, name, q, transport)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=400) for _ in range(world)]
+    import queue
+    import time
+
+    res, t_end = [], time.time() + 400
+    while len(res) < world and time.time() < t_end:
+        try:
+            res.append(q.get(timeout=2))
+        except queue.Empty:
+            if any(p.exitcode not in (None, 0) for p in procs):      # a rank died: do not wait for its answer
+                break
     for p in procs:
         p.join(timeout=60)
+        if p.is_alive():
+            p.kill()
         assert p.exitcode == 0
     assert sorted(r[0] for r in res) == list(range(world)) and all(r[1] for r in res), res
 
