@@ -1,3 +1,5 @@
+# Run ON THE GPU BOX (through gpurun): everything profiles/<tag>_* of a round comes from -- make_profiles.sh, the lock-step bench line,
+# the shape table and the stress runs.  Edit T below.
 set -e
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
