@@ -213,6 +213,29 @@ __device__ __forceinline__ void load_obs_regs(ObsRegs<NCH> &ob, const FW &f, int
     ob.rpsa = f.use_amp ? ld_const(f.rpsum_a + ev) : 1.0;
 }
 
+// The same rows, requested without a branch: every lane issues all four loads (a lane without a station reads the row's last
+// entry and discards it; the arrays exist whatever use_time / use_amp say), so the number of loads per call is fixed and the
+// compiler can leave several calls' worth in flight (s_waitcnt vmcnt(N > 0)) -- the worker blocks' event pipeline.
+template <int NCH, bool F32 = false, class FW>
+__device__ __forceinline__ void load_obs_regs_nobranch(ObsRegs<NCH> &ob, const FW &f, int ev, int lane)
+{
+    const size_t base = (size_t)ev * (size_t)f.S;
+    const bool ut = f.use_time != 0, ua = f.use_amp != 0;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int j = lane + 64 * c;
+        const bool valid = j < f.S;
+        const size_t k = base + (size_t)(valid ? j : f.S - 1);
+        double t, tp, a, ap;
+        if constexpr (F32) { t = (double)f.t_obs32[k]; tp = (double)f.t_prec32[k]; a = (double)f.a_obs32[k]; ap = (double)f.a_prec32[k]; }
+        else { t = f.t_obs[k]; tp = f.t_prec[k]; a = f.a_obs[k]; ap = f.a_prec[k]; }
+        ob.tob[c] = (valid && ut) ? t : 0.0; ob.tpr[c] = (valid && ut) ? tp : 0.0;
+        ob.aob[c] = (valid && ua) ? a : 0.0; ob.apr[c] = (valid && ua) ? ap : 0.0;
+    }
+    ob.rpst = ut ? ld_const(f.rpsum_t + ev) : 1.0;
+    ob.rpsa = ua ? ld_const(f.rpsum_a + ev) : 1.0;
+}
+
 template <int NCH, int NPOS, bool F32 = false, class FW>
 __device__ __forceinline__ void event_misfit(const FW &f, const ObsRegs<NCH> &ob, int lane,
                                              const StaRegs<NCH> &st, const double (&px)[NPOS],

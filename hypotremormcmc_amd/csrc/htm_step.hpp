@@ -1594,27 +1594,69 @@ __device__ __forceinline__ void worker_body(FwRef f_, CsRef cs_, unsigned long l
                     st.ac[c] = valid ? ld_agent(ac + j) : 0.0;
                     if (valid && ov_idx == j) { if (ov_kind == 2) st.tc[c] = ov_val; if (ov_kind == 4) st.ac[c] = ov_val; }
                 }
-                // Events ev0, ev0 + 8W, ...: the first one's observation rows are resident (ob0); every further event's
-                // rows and coordinates are requested BEFORE the current event is evaluated (software pipeline, one
-                // event of look-ahead), so that at E >> 8W the loads of event k+1 fly under the arithmetic of k.
-                ObsRegs<NCH> ob_cur = ob0, ob_nxt = ob0;
-                double cx = 0.0, cy = 0.0, cz = 0.0, nx = 0.0, ny = 0.0, nz = 0.0;
-                if (ev0 < f.E) { cx = ld_agent(hyp + 3 * ev0); cy = ld_agent(hyp + 3 * ev0 + 1); cz = ld_agent(hyp + 3 * ev0 + 2); }
-                for (int ev = ev0; ev < f.E; ev += 8 * W) {
-                    const int evn = ev + 8 * W;
-                    if (evn < f.E) {
-                        load_obs_regs<NCH, F32>(ob_nxt, f, evn, lane);
-                        nx = ld_agent(hyp + 3 * evn); ny = ld_agent(hyp + 3 * evn + 1); nz = ld_agent(hyp + 3 * evn + 2);
+                if constexpr (!F32) {
+                    // Events ev0, ev0 + 8W, ...: the first one's observation rows are resident (ob0); every further event's
+                    // rows and coordinates are requested BEFORE the current event is evaluated (software pipeline, one
+                    // event of look-ahead).  fp64: an event's arithmetic covers the next one's loads, the deeper form below
+                    // measured -1 % at 1 000 and 10 000 events x 64 stations, and two stations per lane do not fit the 256
+                    // registers of a wave with three buffers.
+                    ObsRegs<NCH> ob_cur = ob0, ob_nxt = ob0;
+                    double cx = 0.0, cy = 0.0, cz = 0.0, nx = 0.0, ny = 0.0, nz = 0.0;
+                    if (ev0 < f.E) { cx = ld_agent(hyp + 3 * ev0); cy = ld_agent(hyp + 3 * ev0 + 1); cz = ld_agent(hyp + 3 * ev0 + 2); }
+                    for (int ev = ev0; ev < f.E; ev += 8 * W) {
+                        const int evn = ev + 8 * W;
+                        if (evn < f.E) {
+                            load_obs_regs<NCH, F32>(ob_nxt, f, evn, lane);
+                            nx = ld_agent(hyp + 3 * evn); ny = ld_agent(hyp + 3 * evn + 1); nz = ld_agent(hyp + 3 * evn + 2);
+                        }
+                        const bool ov = ev == ov_evt;
+                        const double px[1] = {(ov && ov_cmp == 0) ? ov_val : cx};
+                        const double py[1] = {(ov && ov_cmp == 1) ? ov_val : cy};
+                        const double pz[1] = {(ov && ov_cmp == 2) ? ov_val : cz};
+                        double out[1];
+                        event_misfit<NCH, 1, F32>(f, ob_cur, lane, st, px, py, pz, beta, q, out);
+                        // two-ahead order: the event of the step in between is left to the chain's own wave (it may be mid-commit)
+                        lane_acc += (ev == r_evt) ? 0.0 : out[0];
+                        ob_cur = ob_nxt; cx = nx; cy = ny; cz = nz;
                     }
-                    const bool ov = ev == ov_evt;
-                    const double px[1] = {(ov && ov_cmp == 0) ? ov_val : cx};
-                    const double py[1] = {(ov && ov_cmp == 1) ? ov_val : cy};
-                    const double pz[1] = {(ov && ov_cmp == 2) ? ov_val : cz};
-                    double out[1];
-                    event_misfit<NCH, 1, F32>(f, ob_cur, lane, st, px, py, pz, beta, q, out);
-                    // two-ahead order: the event of the step in between is left to the chain's own wave (it may be mid-commit)
-                    lane_acc += (ev == r_evt) ? 0.0 : out[0];
-                    ob_cur = ob_nxt; cx = nx; cy = ny; cz = nz;
+                } else {
+                    // Events ev0, ev0 + 8W, ...: the first one's observation rows are resident (ob0).  Three register buffers in
+                    // rotation: the rows and coordinates of the event TWO places ahead are requested before the current event is
+                    // evaluated, with a fixed number of loads per request (load_obs_regs_nobranch), so that at E >> 8W two
+                    // events' loads fly under the arithmetic of a third: the fp32 forward's arithmetic is too short to cover an
+                    // event's loads (configs[4] shape: 837 -> 902 k steps/s).  The last <= 4 events of a wave take the plain path.
+                    const int s8 = 8 * W;
+                    ObsRegs<NCH> b0 = ob0, b1 = ob0, b2 = ob0;
+                    double x0 = 0.0, y0 = 0.0, z0 = 0.0, x1 = 0.0, y1 = 0.0, z1 = 0.0, x2 = 0.0, y2 = 0.0, z2 = 0.0;
+                    auto fetch = [&](ObsRegs<NCH> &b, double &x, double &y, double &z, int e) __attribute__((always_inline)) {
+                        load_obs_regs_nobranch<NCH, F32>(b, f, e, lane);
+                        x = ld_agent(hyp + 3 * e); y = ld_agent(hyp + 3 * e + 1); z = ld_agent(hyp + 3 * e + 2);
+                    };
+                    auto eval = [&](const ObsRegs<NCH> &b, double x, double y, double z, int e) __attribute__((always_inline)) {
+                        const bool ov = e == ov_evt;
+                        const double px[1] = {(ov && ov_cmp == 0) ? ov_val : x};
+                        const double py[1] = {(ov && ov_cmp == 1) ? ov_val : y};
+                        const double pz[1] = {(ov && ov_cmp == 2) ? ov_val : z};
+                        double out[1];
+                        event_misfit<NCH, 1, F32>(f, b, lane, st, px, py, pz, beta, q, out);
+                        // two-ahead order: the event of the step in between is left to the chain's own wave (it may be mid-commit)
+                        lane_acc += (e == r_evt) ? 0.0 : out[0];
+                    };
+                    int ev = ev0;
+                    if (ev < f.E) {
+                        x0 = ld_agent(hyp + 3 * ev); y0 = ld_agent(hyp + 3 * ev + 1); z0 = ld_agent(hyp + 3 * ev + 2);
+                        if (ev + s8 < f.E) fetch(b1, x1, y1, z1, ev + s8);
+                    }
+                    while (ev + 4 * s8 < f.E) {            // b0 <- event ev, b1 <- ev + s8 on entry and again after the trip
+                        fetch(b2, x2, y2, z2, ev + 2 * s8); eval(b0, x0, y0, z0, ev);
+                        fetch(b0, x0, y0, z0, ev + 3 * s8); eval(b1, x1, y1, z1, ev + s8);
+                        fetch(b1, x1, y1, z1, ev + 4 * s8); eval(b2, x2, y2, z2, ev + 2 * s8);
+                        ev += 3 * s8;
+                    }
+                    if (ev < f.E) { if (ev + 2 * s8 < f.E) fetch(b2, x2, y2, z2, ev + 2 * s8); eval(b0, x0, y0, z0, ev); }
+                    if (ev + s8 < f.E) { if (ev + 3 * s8 < f.E) fetch(b0, x0, y0, z0, ev + 3 * s8); eval(b1, x1, y1, z1, ev + s8); }
+                    if (ev + 2 * s8 < f.E) eval(b2, x2, y2, z2, ev + 2 * s8);
+                    if (ev + 3 * s8 < f.E) eval(b0, x0, y0, z0, ev + 3 * s8);
                 }
             } else {
                 // generic station count: corrections are read through plain loads after an agent acquire
