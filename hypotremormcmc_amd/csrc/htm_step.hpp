@@ -437,8 +437,9 @@ __device__ __forceinline__ int chain_pass(FwRef f_, CsRef cs_, StepShared &sh, c
                 const unsigned tag = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)tk);
                 // every chain-state store of this wave (earlier commits, undo) must have landed before a worker
                 // can see the order: write-through stores, drained here; the order itself is one store
-                // instruction (lane -> replica, granule), and its granules carry the tag, so no flag follows
-                drain_vmem();
+                // instruction (lane -> replica, granule), and its granules carry the tag, so no flag follows.  (An order role P
+                // sent needs none of this -- and the wait would be for the loads of the wave's own event, issued a moment ago.)
+                if (!pre) drain_vmem();
                 if (!pre && lane < cs.slot_rep * kGranPerSlot) {
                     const int gi = lane & 7;
                     const unsigned long long xb = (unsigned long long)__double_as_longlong(x_new);
@@ -450,33 +451,6 @@ __device__ __forceinline__ int chain_pass(FwRef f_, CsRef cs_, StepShared &sh, c
 #ifdef HTM_STAMPS
                 if (lane == 0 && cs.stamps) { atomicAdd(&cs.stamps[20], __builtin_amdgcn_s_memrealtime()); atomicAdd(&cs.stamps[26], 1ull); if (pre) atomicAdd(&cs.stamps[28], 1ull); }
 #endif
-                // An order sent TWO iterations ahead is evaluated while the step in between (a hypocentre step of this
-                // chain) may or may not have committed: the workers LEAVE THAT EVENT OUT, and this wave adds its misfit
-                // -- at the position the event has now, under this step's proposed parameters -- itself, while it waits
-                // for the workers' sums.  The result does not depend on when the workers looked.
-                double own_lane = 0.0;
-                if constexpr (NCH > 0) {
-                    if (pre_mode == 2 && prev_type >= 5) {
-                        const int e = prev_evt - 1;
-                        if (!(dhint && d_e == e)) {            // the hint missed: request the inputs now
-                            const int vzd = opaque_zero();
-                            const double *hyp = cs.xall + off_hy + c * nh + 3 * e;
-                            d_ex = ld_state(hyp, vzd); d_ey = ld_state(hyp + 1, vzd); d_ez = ld_state(hyp + 2, vzd);
-                            load_sta_regs<NCH>(st, f.S, lane, s_sx, s_sy, s_sz, tc, ac, 0, -1, 0.0);
-                            load_obs_regs<NCH, F32>(ob, f, e, lane);
-                        }
-                        if (type == 2 || type == 4) {          // this step's proposed correction, on the lane of its station
-#pragma unroll
-                            for (int k = 0; k < NCH; ++k) {
-                                if (lane + 64 * k == idx) { if (type == 2) st.tc[k] = x_new; else st.ac[k] = x_new; }
-                            }
-                        }
-                        const double pxd[1] = {d_ex}, pyd[1] = {d_ey}, pzd[1] = {d_ez};
-                        double outd[1];
-                        event_misfit<NCH, 1, F32>(f, ob, lane, st, pxd, pyd, pzd, type == 1 ? x_new : beta, type == 3 ? x_new : q, outd);
-                        own_lane = outd[0];
-                    }
-                }
                 // ---- the workers' partial sums: tagged granules, fixed summation order; two rounds of loads are
                 // ---- kept in flight so that a granule is seen at most half a round trip after it lands ----------
                 const unsigned long long *pg = cs.pgran + (size_t)c * cs.n_wg * cs.pgran_stride;
@@ -501,36 +475,91 @@ __device__ __forceinline__ int chain_pass(FwRef f_, CsRef cs_, StepShared &sh, c
                         if (j * 64 + lane < cs.n_wg) got = got && (unsigned)(hi[b][j] >> 32) == tag && (unsigned)(lo[b][j] >> 32) == tag;
                     return __all(got);
                 };
-                issue(0);
-                for (;;) {
-                    issue(1);
-                    if (complete(0)) { which = 0; break; }
-                    issue(0);
-                    if (complete(1)) { which = 1; break; }
-                    if (__builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) {
-                        if (lane == 0) {
-                            sh.c.err = -8;
-                            unsigned long long *dg = cs.diag;          // what was waited for: the host puts it into its message
-                            dg[1] = c; dg[2] = tag; dg[3] = pre; dg[4] = pre_mode; dg[5] = iter; dg[6] = p; dg[7] = type; dg[8] = idx;
-                            dg[9] = hi[0][0]; dg[10] = lo[0][0]; dg[11] = first_pass; dg[12] = sh.start[c]; dg[0] = 1;
-                        }
 #ifdef HTM_STAMPS
-                        if (lane == 0 && cs.stamps) {          // what was waited for (tools/diag_wait.py)
-                            cs.stamps[100] = 1; cs.stamps[101] = c; cs.stamps[102] = tag; cs.stamps[103] = pre; cs.stamps[104] = pre_mode;
-                            cs.stamps[105] = iter; cs.stamps[106] = p; cs.stamps[107] = type; cs.stamps[108] = idx;
-                            cs.stamps[109] = hi[0][0]; cs.stamps[110] = lo[0][0]; cs.stamps[111] = sh.start[c];
-                        }
+                unsigned long long rounds_ = 0;
 #endif
-                        break;
+                // A two-ahead order was answered an iteration ago: its granules are requested NOW, so that their round trip (the
+                // workers sit on other XCDs: ~0.9 us through the fabric) runs under the evaluation of the wave's own event, and
+                // looked at before anything else is requested.  Only if they are not all there -- or for the other kinds of
+                // order, whose answers are still being worked out -- does the polling loop with two rounds in flight start.
+                const bool early = pre_mode == 2;
+                if (early) issue(0);
+                // An order sent TWO iterations ahead is evaluated while the step in between (a hypocentre step of this
+                // chain) may or may not have committed: the workers LEAVE THAT EVENT OUT, and this wave adds its misfit
+                // -- at the position the event has now, under this step's proposed parameters -- itself, while it waits
+                // for the workers' sums.  The result does not depend on when the workers looked.
+                CSTAMP(5);   // with-job step: order recognised / sent
+                double own_lane = 0.0;
+                if constexpr (NCH > 0) {
+                    if (pre_mode == 2 && prev_type >= 5) {
+                        const int e = prev_evt - 1;
+                        if (!(dhint && d_e == e)) {            // the hint missed: request the inputs now
+                            const int vzd = opaque_zero();
+                            const double *hyp = cs.xall + off_hy + c * nh + 3 * e;
+                            d_ex = ld_state(hyp, vzd); d_ey = ld_state(hyp + 1, vzd); d_ez = ld_state(hyp + 2, vzd);
+                            load_sta_regs<NCH>(st, f.S, lane, s_sx, s_sy, s_sz, tc, ac, 0, -1, 0.0);
+                            load_obs_regs<NCH, F32>(ob, f, e, lane);
+                        }
+                        if (type == 2 || type == 4) {          // this step's proposed correction, on the lane of its station
+#pragma unroll
+                            for (int k = 0; k < NCH; ++k) {
+                                if (lane + 64 * k == idx) { if (type == 2) st.tc[k] = x_new; else st.ac[k] = x_new; }
+                            }
+                        }
+                        const double pxd[1] = {d_ex}, pyd[1] = {d_ey}, pzd[1] = {d_ez};
+                        double outd[1];
+                        event_misfit<NCH, 1, F32>(f, ob, lane, st, pxd, pyd, pzd, type == 1 ? x_new : beta, type == 3 ? x_new : q, outd);
+                        own_lane = outd[0];
                     }
                 }
+                CSTAMP(6);   // with-job step: own event (two-ahead orders)
+                bool have = false;
+                if (early) have = complete(0);
+                if (!have) {
+                    issue(0);
+                    for (;;) {
+#ifdef HTM_STAMPS
+                        rounds_ += 1;
+#endif
+                        issue(1);
+                        if (complete(0)) { which = 0; break; }
+                        issue(0);
+                        if (complete(1)) { which = 1; break; }
+                        if (__builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) {
+                            if (lane == 0) {
+                                sh.c.err = -8;
+                                unsigned long long *dg = cs.diag;          // what was waited for: the host puts it into its message
+                                dg[1] = c; dg[2] = tag; dg[3] = pre; dg[4] = pre_mode; dg[5] = iter; dg[6] = p; dg[7] = type; dg[8] = idx;
+                                dg[9] = hi[0][0]; dg[10] = lo[0][0]; dg[11] = first_pass; dg[12] = sh.start[c]; dg[0] = 1;
+                            }
+#ifdef HTM_STAMPS
+                            if (lane == 0 && cs.stamps) {          // what was waited for (tools/diag_wait.py)
+                                cs.stamps[100] = 1; cs.stamps[101] = c; cs.stamps[102] = tag; cs.stamps[103] = pre; cs.stamps[104] = pre_mode;
+                                cs.stamps[105] = iter; cs.stamps[106] = p; cs.stamps[107] = type; cs.stamps[108] = idx;
+                                cs.stamps[109] = hi[0][0]; cs.stamps[110] = lo[0][0]; cs.stamps[111] = sh.start[c];
+                            }
+#endif
+                            break;
+                        }
+                    }
+                }
+#ifdef HTM_STAMPS
+                if (stamp_me) {      // the wait by kind of order: [10..12] two-ahead {ticks, jobs, poll rounds}, [13..15] others
+                    const unsigned long long n_ = __builtin_amdgcn_s_memtime();
+                    const int b_ = pre_mode == 2 ? 10 : 13;
+                    sh.stamp_acc[32 + b_] += n_ - t_last; sh.stamp_acc[32 + b_ + 1] += 1ull; sh.stamp_acc[32 + b_ + 2] += rounds_;
+                }
+#endif
+                CSTAMP(7);   // with-job step: all granules there
 #pragma unroll
                 for (int j = 0; j < kSweep; ++j)            // fixed order: worker lane, lane + 64, ...
                     if (j * 64 < cs.n_wg)
                         part += (j * 64 + lane < cs.n_wg) ? (which == 0 ? gran_f64(hi[0][j], lo[0][j]) : gran_f64(hi[1][j], lo[1][j])) : 0.0;
                 L_new = -wave_sum1(part + own_lane) - f.const_sum;       // cls_forward.f90:277-300
                 if constexpr (!LOCK) acc = metropolis(L_new, L_cur, rT, lpr, r, logr) ? 1 : 0;
+                CSTAMP(8);   // with-job step: sum + decision
 #ifdef HTM_STAMPS
+                if (stamp_me) sh.stamp_acc[32 + 9] += 1ull;
                 if (lane == 0 && cs.stamps) atomicAdd(&cs.stamps[25], __builtin_amdgcn_s_memrealtime());
 #endif
             }

@@ -47,6 +47,15 @@ for k, nm in enumerate(names):
 cn = ["decode+load issue", "proposal arith (load wait)", "event_misfit", "final sum+decision", "commit+LDS write-back"]
 for k, nm in enumerate(cn):
     print("  chain_pass[chain 0] %-28s %8.0f ticks/iter" % (nm, (a[32 + k] - base[32 + k]) / n))
+nj = a[32 + 9] - base[32 + 9]
+if nj:
+    for k, nm in ((5, "order recognised / sent"), (6, "own event (two-ahead)"), (7, "wait for all granules"), (8, "sum + decision")):
+        print("  chain_pass[chain 0] with job: %-24s %8.0f ticks/job  (%d jobs)" % (nm, (a[32 + k] - base[32 + k]) / nj, nj))
+for b, nm in ((10, "two-ahead orders"), (13, "one-ahead / own orders")):
+    cnt = a[32 + b + 1] - base[32 + b + 1]
+    if cnt:
+        print("  chain_pass[chain 0] wait for granules, %-24s %8.0f ticks/job, %.2f poll rounds  (%d jobs)" %
+              (nm, (a[32 + b] - base[32 + b]) / cnt, (a[32 + b + 2] - base[32 + b + 2]) / cnt, cnt))
 for wv in range(8):
     for job in (0, 1):
         cnt = a[64 + wv + 8 * job] - base[64 + wv + 8 * job]
