@@ -1265,6 +1265,12 @@ __device__ __forceinline__ void step_body(FwRef f_, CsRef cs_, int mode, int tar
 #endif
                 __syncthreads();                                            // ---- barrier A
                 STAMP(2);   // passes
+#ifdef HTM_STAMPS
+                const unsigned long long t_roles0 = __builtin_amdgcn_s_memtime();
+#define RSTAMP(k) do { if (lane == 0 && cs.stamps) atomicAdd(&cs.stamps[120 + (k)], __builtin_amdgcn_s_memtime() - t_roles0); } while (0)
+#else
+#define RSTAMP(k) do { } while (0)
+#endif
                 if (lockrun && xpend) {
                     // every wave has heard about the swap of the iteration before; if that iteration was the last one
                     // (a rank asked for a stop, or failed) no step of this one was taken: leave
@@ -1278,6 +1284,7 @@ __device__ __forceinline__ void step_body(FwRef f_, CsRef cs_, int mode, int tar
                     pf_load(pf, cs, sh, sh.fill + lane, pf_limit);
                     pf_store(pf, rg);
                     fill_next = max(sh.fill, min(sh.fill + 64, pf_limit));
+                    RSTAMP(3);   // window extension
                 }
                 if (wave == 0 || wave == wave_R || wave == wave_W) {
                     CsRef cs = rebase(cs_);
@@ -1335,8 +1342,9 @@ __device__ __forceinline__ void step_body(FwRef f_, CsRef cs_, int mode, int tar
                             }
                         }
                     }
-                    if (wave == wave_R && done) role_records(cs, sh, iter, lockstep, lane, rec);
-                    if (wave == wave_W && done) role_swap(cs, sh, iter, lockstep, lane, i1, i2, sr, slr, rec);
+                    if (wave == 0) RSTAMP(0);   // role V
+                    if (wave == wave_R && done) { role_records(cs, sh, iter, lockstep, lane, rec); RSTAMP(1); }
+                    if (wave == wave_W && done) { role_swap(cs, sh, iter, lockstep, lane, i1, i2, sr, slr, rec); RSTAMP(2); }
                 }
                 __syncthreads();                                            // ---- barrier B
                 STAMP(3);   // validation + plan + records + swap

@@ -56,6 +56,8 @@ for b, nm in ((10, "two-ahead orders"), (13, "one-ahead / own orders")):
     if cnt:
         print("  chain_pass[chain 0] wait for granules, %-24s %8.0f ticks/job, %.2f poll rounds  (%d jobs)" %
               (nm, (a[32 + b] - base[32 + b]) / cnt, (a[32 + b + 2] - base[32 + b + 2]) / cnt, cnt))
+for k, nm in enumerate(("role V (validate, plan, bookkeeping)", "role R (records)", "role W (swap)", "window extension")):
+    print("  roles phase, barrier A -> end of %-38s %7.0f ticks/iter" % (nm, (a[120 + k] - base[120 + k]) / n))
 for wv in range(8):
     for job in (0, 1):
         cnt = a[64 + wv + 8 * job] - base[64 + wv + 8 * job]
