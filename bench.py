@@ -258,7 +258,7 @@ def main(argv=None):
         one_gpu = os.environ.get("HTM_BENCH_ONE_GPU") == "1"
         if one_gpu:
             local_rank = 0
-            os.environ.setdefault("HTM_MAX_WORKERS", str(max(1, 240 // max(1, world) - 2)))   # the ranks' kernels must co-reside
+            os.environ.setdefault("HTM_RANKS_PER_GPU", str(world))   # the ranks' kernels must co-reside: each takes its share of the CUs
         backend = "gloo" if one_gpu else "nccl"
         torch.cuda.set_device(local_rank)
         if lockstep:

@@ -879,7 +879,10 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
         int per_cu = 0, n_cu = 0;
         HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 512, hc->step_smem));
         HIPCHK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
-        const long room = (long)per_cu * n_cu - 1;
+        long room = (long)per_cu * n_cu - 1;
+        // Several ranks on one GPU (more masters instead of more rounds per master: 4 ranks x 8 chains run 2.7 M steps/s where one
+        // rank x 32 chains runs 1.7 M): every rank's blocks must be resident at once, so each takes its share of the CUs
+        if (const char *e = getenv("HTM_RANKS_PER_GPU")) { const int k = atoi(e); if (k > 1) room = (long)per_cu * n_cu / k - 1; }
         if (room < 1) hc->persist = false;      // not even one worker fits next to the master: two-kernel path
         else hc->dev.n_workers = (int)std::min<long>(hc->dev.n_workers, room);
     }
