@@ -10,10 +10,10 @@ sample/hypo_tremor.in.  N > 1: one rank per GPU, 8 chains each (weak scaling, BA
 temperature swap between ANY two chains of the job every iteration (reference src/cls_parallel.f90:100-216).
 
 A bench "step" (--steps / --warmup) is a fixed BLOCK of main-loop iterations of every rank (reference
-src/hypo_tremor_mcmc.f90:236-284), ITERS_PER_STEP = 8 192 by default: one iteration = n_chains proposal steps
+src/hypo_tremor_mcmc.f90:236-284), ITERS_PER_STEP = 65 536 by default: one iteration = n_chains proposal steps
 (propose -> forward -> judge for every chain, then swap_temperature).  So the driver's `--steps 20 --warmup 5`
-times 163 840 iterations = 1.3 M proposal steps per GPU: a region of about a second of the persistent kernel,
-not a launch prologue.  `value` = proposal steps per second over all ranks; inputs are resident in HBM before
+times 1 310 720 iterations = 10.5 M proposal steps per GPU: several seconds of the persistent kernel, not a
+launch prologue.  `value` = proposal steps per second over all ranks; inputs are resident in HBM before
 the timed region starts; the region is bracketed by a barrier + device synchronisation on both sides.
 
 Besides the driver contract the JSON line carries
@@ -38,7 +38,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 N_EVENTS, N_STA, N_CHAINS, SEED = 1000, 64, 8, 1
-ITERS_PER_STEP = 8192
+ITERS_PER_STEP = 65536     # 20 timed steps = 1.3 M iterations: several seconds of the persistent kernel (the driver's GPU sampler sees it)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -282,9 +282,6 @@ def main(argv=None):
 
             tw = TorchWorld(cs)
             run = tw.run
-            transport = ("persistent lock-step: swap records written into the peers' inboxes from inside the kernel (xGMI peer memory)"
-                         if tw.direct else "one k_mcmc launch + one RCCL all-gather per iteration, enqueued from C" if tw.fast
-                         else "torch.distributed all-gather per iteration")
         sync, device_sync = cs.sync, torch.cuda.synchronize
 
     def fence():
@@ -299,10 +296,15 @@ def main(argv=None):
     run(n_timed)
     fence()
     dt = time.perf_counter() - t0
+    rank_dts = [dt]
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if (test_engine or dist.get_backend() == "gloo") else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        # every rank's own time of the region: the line's time is the MAX over ranks, config carries them all
+        tdev = "cpu" if (test_engine or dist.get_backend() == "gloo") else "cuda"
+        t = torch.tensor([dt], dtype=torch.float64, device=tdev)
+        tall = torch.zeros(world, dtype=torch.float64, device=tdev)
+        dist.all_gather_into_tensor(tall, t)
+        rank_dts = [float(x) for x in tall.cpu().tolist()]
+        dt = max(rank_dts)
     done = eng.iterations_done if test_engine else cs.iterations_done
     assert done == n_warm + n_timed, (done, n_warm + n_timed)
 
@@ -324,8 +326,13 @@ def main(argv=None):
     }
     if args.force_lockstep:
         out["config"]["parallelism"] = "lock-step path (swap records exchanged every iteration), 1 rank"
+    if world > 1:
+        out["config"]["us_per_iteration_by_rank"] = [1e6 * x / n_timed for x in rank_dts]
+        out["config"]["max_skew_us_per_iteration"] = 1e6 * (max(rank_dts) - min(rank_dts)) / n_timed
     if lockstep and not test_engine:
-        out["config"]["swap_transport"] = transport
+        out["config"]["swap_transport"] = tw.transport_name()      # the transport the timed region really ran on
+        if tw.fell_back:
+            out["config"]["swap_transport_note"] = tw.fell_back
         if os.environ.get("HTM_BENCH_ONE_GPU") == "1" and world > 1:
             out["data"] = "synthetic (rehearsal: all ranks share ONE GPU, not a scaling measurement)"
     if test_engine:
@@ -418,8 +425,13 @@ def main(argv=None):
                                    "avg_launch_us": us, "evals_per_s": nb / (us * 1e-6),
                                    "note": "200 back-to-back launches of k_full<1,true> + k_sum_partials bracketed by "
                                            "HIP events; inputs resident in HBM"}
+    # The process group is taken down BEFORE the CPU baseline: the other ranks leave (no collective waits on a watchdog
+    # while rank 0 runs mpiexec for a minute, no idle rank processes competing with the baseline's MPI ranks for cores);
+    # the measurement is in `out` by now.
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
     if rank == 0 and not args.no_cpu_baseline and not test_engine:
-        # the other ranks wait at the barrier below; their GPUs are idle by now
         try:
             out["cpu_baseline"] = cpu_baseline(params, data, world * nc)
         except Exception as exc:           # the baseline is a side figure: never lose the measurement over it
@@ -427,9 +439,6 @@ def main(argv=None):
                                    "sample": f"not measured: {exc}"}
     if rank == 0:
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -1676,6 +1676,11 @@ int htm_chains_checkpoint_load(htm_chains *hc, const void *blob, size_t bytes)
         const ChainsDev &d = hc->dev;
         HIPCHK(hipMemset(d.slots, 0, (size_t)d.slot_rep * d.slot_stride * sizeof(unsigned long long)));
         HIPCHK(hipMemset(d.pgran, 0, (size_t)d.n_chains * d.n_workers * d.pgran_stride * sizeof(unsigned long long)));
+        // The swap-record inbox too: its tags are bare iteration numbers, and the iterations after the saved one are about
+        // to be run again (records and stop / error words of the first time must not be taken for the second).  For a
+        // multi-rank job a load is therefore COLLECTIVE: every rank loads, then the ranks meet at a barrier before the next
+        // htm_chains_run_lockstep_direct (no peer posts outside a run, so nothing lands in a cleared inbox before that).
+        if (hc->d_inbox && hc->inbox_bytes) HIPCHK(hipMemset(hc->d_inbox, 0, hc->inbox_bytes));
     }
     hc->lik_iter.clear(); hc->lik_chain.clear(); hc->lik_val.clear();
     hc->smp_iter.clear(); hc->smp_chain.clear(); hc->smp_data.clear();
@@ -1996,7 +2001,7 @@ int htm_selftest_math(int device, int which, const double *x, double *y, int n)
 {
     int rc = use_device(device);
     if (rc) return rc;
-    if (!x || !y || n < 0 || which < 0 || which > 2) return fail(HTM_EINVAL, "htm_selftest_math: null pointer, negative count or unknown function");
+    if (!x || !y || n < 0 || which < 0 || which > 3) return fail(HTM_EINVAL, "htm_selftest_math: null pointer, negative count or unknown function");
     if (n == 0) return HTM_OK;
     double *d = nullptr;
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&d), 2 * (size_t)n * sizeof(double)));

@@ -200,7 +200,7 @@ namespace htm {
 __global__ void k_mathtest(int which, const double *x, double *y, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) y[i] = which == 0 ? htm_log(x[i]) : which == 1 ? htm_sqrt(x[i]) : sqrt(x[i]);
+    if (i < n) y[i] = which == 0 ? htm_log(x[i]) : which == 1 ? htm_sqrt(x[i]) : which == 2 ? sqrt(x[i]) : log(x[i]);   // 3: the device library's log (Rayleigh prior ratio, htm_step.hpp)
 }
 
 __global__ void k_selftest(const double *in, double *out_dpp, double *out_ref, uint32_t *rng_out,

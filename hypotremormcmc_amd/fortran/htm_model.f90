@@ -86,7 +86,7 @@ contains
        case (1)
           self%x(i) = self%mu(i) + rand_r() * self%sigma(i)
        case default
-          write(0, *) "unsupported prior type : prior_type = ", self%prior_type(i)
+          write(0, '(A,I0,A,I0,A)') "generate_model: element ", i, " has prior_type ", self%prior_type(i), " (known: 0 Gaussian, 1 Rayleigh)"
           stop
        end select
     end do

@@ -35,6 +35,8 @@ program hypo_tremor_mcmc_hip
   integer, allocatable :: win_id(:)
   double precision, allocatable :: x_mu(:), y_mu(:)
   integer :: n_events, n_sta, n_chains, i, j, io, id, ierr, rank, n_ranks
+  integer :: slice = 1000           ! iterations per call into the library (the reference reports every 1000: src/cls_mcmc.f90:230)
+  integer(8) :: t_loop0 = 0
   logical :: direct = .false., want_rccl = .false.
   integer(c_int) :: n_dev
   real(c_double), allocatable :: rec(:), gathered(:)
@@ -70,6 +72,15 @@ program hypo_tremor_mcmc_hip
      stop 1
   end if
   call rng_seed([5551111, 453222, 4444431, 6765], rank)
+  block
+    character(16) :: ev
+    integer :: el, es, v
+    call get_environment_variable("HTM_SLICE", ev, el, es)
+    if (es == 0 .and. el > 0) then
+       read(ev(1:el), *, iostat=es) v
+       if (es == 0 .and. v >= 1) slice = v
+    end if
+  end block
 
   ! events
   allocate(win_id(0))
@@ -210,11 +221,13 @@ program hypo_tremor_mcmc_hip
   if (direct) then
      if (rank == 0) print *, "swap exchange: in-kernel (peer-mapped inboxes)"
      call mpi_barrier(MPI_COMM_WORLD, ierr)
-     do i = 0, para%n_iter - 1, 1000
-        call check(htm_chains_run_lockstep_direct(chains, int(min(1000, para%n_iter - i), c_int)), &
+     call loop_timer(.true.)
+     do i = 0, para%n_iter - 1, slice
+        call check(htm_chains_run_lockstep_direct(chains, int(min(slice, para%n_iter - i), c_int)), &
              & "htm_chains_run_lockstep_direct")
-        if (rank == 0) call summary(min(i + 1000, para%n_iter))
+        if (rank == 0) call summary(min(i + slice, para%n_iter))
      end do
+     call loop_timer(.false.)
   end if
   ! Second transport: RCCL driven from Fortran.  Rank 0 draws RCCL's unique id, MPI_Bcast carries it, every rank joins the
   ! communicator (ncclCommInitRank), and the loop of htm_chains_run_lockstep -- one k_mcmc launch + one ncclAllGather
@@ -239,12 +252,14 @@ program hypo_tremor_mcmc_hip
        end if
        if (ok_all == 1) then
           if (rank == 0) print *, "swap exchange: RCCL all-gather per iteration"
-          do i = 0, para%n_iter - 1, 1000
-             call check(htm_chains_run_lockstep_comm(chains, int(min(1000, para%n_iter - i), c_int), comm), &
+          call loop_timer(.true.)
+          do i = 0, para%n_iter - 1, slice
+             call check(htm_chains_run_lockstep_comm(chains, int(min(slice, para%n_iter - i), c_int), comm), &
                   & "htm_chains_run_lockstep_comm")
              call check(htm_chains_drain(chains), "htm_chains_drain")
-             if (rank == 0) call summary(min(i + 1000, para%n_iter))
+             if (rank == 0) call summary(min(i + slice, para%n_iter))
           end do
+          call loop_timer(.false.)
           direct = .true.         ! (the iterations are done)
           call check(htm_comm_destroy(comm), "htm_comm_destroy")
        else if (rank == 0) then
@@ -266,10 +281,12 @@ program hypo_tremor_mcmc_hip
   end do
   call check(htm_chains_drain(chains), "htm_chains_drain")
 #else
-  do i = 0, para%n_iter - 1, 1000
-     call check(htm_chains_run(chains, int(min(1000, para%n_iter - i), c_int)), "htm_chains_run")
-     call summary(min(i + 1000, para%n_iter))
+  call loop_timer(.true.)
+  do i = 0, para%n_iter - 1, slice
+     call check(htm_chains_run(chains, int(min(slice, para%n_iter - i), c_int)), "htm_chains_run")
+     call summary(min(i + slice, para%n_iter))
   end do
+  call loop_timer(.false.)
 #endif
 
   call write_outputs()
@@ -296,7 +313,28 @@ contains
     m%x = c_loc(x); m%mu = c_loc(mu); m%sigma = c_loc(sg); m%step_size = c_loc(st); m%prior_type = c_loc(pt)
   end function pack_model
 
-  !> the reference prints chain 1 every 1000 iterations (src/cls_mcmc.f90:230-237)
+  !> HTM_TIME_MAIN_LOOP=1: wall time of the main loop alone (src/hypo_tremor_mcmc.f90:236-284) on standard error
+  subroutine loop_timer(start)
+    logical, intent(in) :: start
+    character(8) :: ev
+    integer :: el, es
+    integer(8) :: now, rate
+    real(8) :: sec
+    call get_environment_variable("HTM_TIME_MAIN_LOOP", ev, el, es)
+    if (es /= 0 .or. el < 1) return
+    if (ev(1:1) == "0") return
+    call system_clock(now, rate)
+    if (start) then
+       t_loop0 = now
+    else if (rank == 0) then
+       sec = real(now - t_loop0, 8) / real(rate, 8)
+       write(0, '(A,F12.6,A,I0,A,I0,A,I0,A,F14.1,A)') "main loop: ", sec, " s for ", para%n_iter, " iterations x ", n_chains, &
+            & " chains x ", n_ranks, " rank(s) = ", real(para%n_iter, 8) * n_chains * n_ranks / sec, " proposal steps/s"
+    end if
+  end subroutine loop_timer
+
+  !> the reference prints chain 1 every 1000 iterations (src/cls_mcmc.f90:230-237); HTM_SLICE=n makes a slice of the
+  !> main loop -- one call into the library, one progress report -- n iterations long instead
   subroutine summary(it)
     integer, intent(in) :: it
     real(c_double) :: h(3*n_events), tc(n_sta), ac(n_sta), v, q, t, l

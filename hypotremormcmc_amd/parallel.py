@@ -86,6 +86,27 @@ class TorchWorld:
         self.drain_every = 4096
         self.direct = self._try_direct_exchange()
         self.fast = None if self.direct else self._try_direct_rccl()
+        # The set-up probe proves one token per peer, not the loop.  The FIRST direct run is therefore guarded: the rank's
+        # state is saved before it, every rank reports how it ended, and if any rank failed (error -10: a peer's records
+        # did not arrive; -11: a peer reported a failure) ALL ranks reload their state and repeat the iterations on the
+        # per-iteration all-gather path.  `fell_back` says so (bench.py prints it).
+        self._direct_proven = False
+        self._probe_token = 1
+        self.fell_back = None
+
+    def transport_name(self):
+        if self.direct:
+            return ("persistent lock-step: swap records written into the peers' inboxes from inside the kernel "
+                    "(xGMI peer memory)")
+        if self.fast is not None:
+            return "one k_mcmc launch + one RCCL all-gather per iteration, enqueued from C"
+        return "torch.distributed all-gather per iteration"
+
+    def _all_ok(self, ok: bool) -> bool:
+        dev = self.gathered.device if self.dist.get_backend(self.group) == "nccl" else self.torch.device("cpu")
+        flag = self.torch.tensor([1 if ok else 0], dtype=self.torch.int32, device=dev)
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN, group=self.group)
+        return bool(int(flag.item()))
 
     def _try_direct_exchange(self):
         """Persistent lock-step (htm_chains_run_lockstep_direct): every rank's kernel writes its swap record straight
@@ -120,7 +141,7 @@ class TorchWorld:
         # every rank mapped every peer: prove that writes into the inboxes reach a polling kernel (all ranks probe together)
         dist.barrier(group=self.group)
         try:
-            cs.xchg_probe(token=1, seconds=10.0)
+            cs.xchg_probe(token=1, seconds=10.0)       # (a later probe of the same set must use another token)
         except Exception:
             ok = 0
         flag = torch.tensor([ok], dtype=torch.int32, device=dev)
@@ -165,9 +186,29 @@ class TorchWorld:
 
     def run(self, n_iter: int):
         if self.direct:
+            cs = self.r.cs
+            blob = None if self._direct_proven else cs.checkpoint()
             self.dist.barrier(group=self.group)      # the ranks' kernels start together (the exchange waits 20 s for a peer)
-            self.r.cs.run_lockstep_direct(n_iter)
-            return
+            err = None
+            try:
+                cs.run_lockstep_direct(n_iter)
+            except Exception as exc:
+                if self._direct_proven:
+                    raise
+                err = exc
+            if self._direct_proven:
+                return
+            if self._all_ok(err is None):
+                self._direct_proven = True
+                return
+            # some rank's exchange failed inside the loop: everybody goes back to the saved state and takes the
+            # all-gather path from here on (restore clears this rank's inbox; nobody posts again: direct is off)
+            cs.restore(blob)
+            self.dist.barrier(group=self.group)
+            self.direct = False
+            self.fast = self._try_direct_rccl()
+            self.fell_back = ("the in-kernel exchange failed in its first run (%s); state reloaded, iterations repeated on: %s"
+                              % (err if err is not None else "on another rank", self.transport_name()))
         if self.fast is not None:
             self.r.cs.run_lockstep(n_iter, self.fast[0], self.fast[1], self.gathered.data_ptr())
             self.r.drain()

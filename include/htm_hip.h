@@ -300,8 +300,10 @@ int htm_selftest(int device);
 
 /* y[i] = fn(x[i]) for n host values, fn = the forward model's own fp64 routines: which = 0 the logarithm of the amplitude
  * term (reference src/cls_forward.f90:204, `log(d)`), 1 the square root of the squared distance (:115-117), 2 the device
- * library's sqrt (what 1 must equal).  Lets a test measure them against a wider-precision result (stated bound of the
- * logarithm: < 1 ulp).  Synchronous. */
+ * library's sqrt (what 1 must equal), 3 the device library's log -- the one used by the Rayleigh prior ratio
+ * (reference src/cls_model.f90:184-185, `log(x_new - mu) - log(x_old - mu)`: a term of the Metropolis decision, so the test
+ * compares it with the host libm the reference links).  Lets a test measure them against a wider-precision result (stated
+ * bound of the logarithm: < 1 ulp).  Synchronous. */
 int htm_selftest_math(int device, int which, const double *x, double *y, int n);
 
 /* mod_random's generator (reference src/mod_random.f90:60-74) is linear over GF(2): the state after n draws is

@@ -127,3 +127,142 @@ def test_fp32_chains_at_the_configs4_shape_agree_statistically():
           f"(rel {abs(m64 - m32) / abs(m64):.3e}); " + "; ".join(lines))
     assert rel0 <= 3e-6
     assert abs(m64 - m32) <= 2e-3 * abs(m64)
+
+
+# ---- BASELINE configs[4] as a multi-rank job: tempered chains over several ranks with the fp32 forward ----------------
+def _t4_compare(tag, r64, r32, n_skip):
+    """T4 between an fp64 and an fp32 run of the same job (common random numbers): same records at iteration 1 within
+    T1, same temperature trajectory of the cold chains where T3 says so (a flipped decision in < 0.5 % of the steps),
+    acceptance counts within 4 binomial sigma + 2 %, cold chains' log-likelihood within 2e-3 relative."""
+    (p64, a64), (p32, a32) = r64["counts"], r32["counts"]
+    assert np.array_equal(p64, p32) or abs(int(p64.sum()) - int(p32.sum())) <= 0.02 * p64.sum()
+    lines = []
+    for k in range(7):
+        n = max(int(p64[k]), 1)
+        q64, q32 = a64[k] / n, a32[k] / max(int(p32[k]), 1)
+        tol = 4.0 * np.sqrt(max(q64 * (1 - q64), 0.05) / n) * np.sqrt(2.0) + 0.02
+        lines.append(f"type {k + 1}: {int(p64[k])}/{int(p32[k])} proposed, {int(a64[k])}/{int(a32[k])} accepted")
+        assert abs(q64 - q32) <= tol, lines[-1]
+    same_rec, n_rec, rel0, m64, m32 = 0, 0, 0.0, [], []
+    for (it64, ch64, lk64), (it32, ch32, lk32) in zip(r64["traces"], r32["traces"]):
+        f64_, f32_ = lk64[it64 == 1], lk32[it32 == 1]
+        assert len(f64_) == len(f32_)
+        if len(f64_):
+            rel0 = max(rel0, float(np.max(np.abs(f64_ - f32_) / np.abs(f64_))))
+        # which chain is cold at which recorded iteration is decided by the swaps: equal lists = equal swap decisions
+        k = min(len(it64), len(it32))
+        same_rec += int(np.sum((it64[:k] == it32[:k]) & (ch64[:k] == ch32[:k]))); n_rec += max(len(it64), len(it32))
+        m64.extend(lk64[it64 > n_skip]); m32.extend(lk32[it32 > n_skip])
+    m64, m32 = float(np.mean(m64)), float(np.mean(m32))
+    _note(f"T4 {tag}: first-iteration records max rel {rel0:.3e}; records on the same (iteration, chain) {same_rec}/{n_rec}; "
+          f"mean cold log-likelihood fp64 {m64:.6e} fp32 {m32:.6e} (rel {abs(m64 - m32) / abs(m64):.3e}); " + "; ".join(lines))
+    assert rel0 <= 3e-6
+    assert same_rec >= 0.98 * n_rec
+    assert abs(m64 - m32) <= 2e-3 * abs(m64)
+
+
+def test_configs4_eight_ranks_of_sixteen_chains_fp32_forward(monkeypatch):
+    """BASELINE configs[4]: 10 000 events x 128 stations, 128 tempered chains over 8 ranks, fp32 forward / fp64 accept
+    (src/cls_forward.f90:268-303 under src/cls_parallel.f90:100-216).  Eight rank objects on the one GPU, records
+    exchanged by device copies (LocalWorld): the lock-step kernels k_mcmc<2, true, 1> against the same job in fp64."""
+    from hypotremormcmc_amd import driver, synth
+    from hypotremormcmc_amd.obs_data import ObsData
+    from hypotremormcmc_amd.parallel import LocalWorld
+
+    monkeypatch.setenv("HTM_STREAM_CAP", str(1 << 17))      # eight ranks' stream rings on one device: the short ring
+    E, S, nc, world, n_iter = 10000, 128, 16, 8, 120
+    data = synth.make_synthetic(E, S, 5)
+    obs = ObsData.from_arrays(data.sta_x, data.sta_y, data.t_obs, data.t_stdv, data.a_obs, data.a_stdv)
+    res = {}
+    for prec in ("fp64", "fp32"):
+        params = dict(synth.DEFAULT_PARAMS, n_procs=world, n_chains=nc, n_cool=4, temp_high=200.0, n_iter=n_iter, n_burn=n_iter,
+                      n_interval=2, forward_precision=prec)
+        fwd, sets = None, []
+        for r in range(world):
+            fwd, cs = driver.build_rank(params, data.sta_x, data.sta_y, data.sta_z, obs, r, n_procs=world, fwd=fwd)
+            sets.append(cs)
+        assert fwd.forward_precision == prec
+        LocalWorld(sets).run(n_iter)
+        npr = np.zeros(7, np.int64); nac = np.zeros(7, np.int64)
+        for cs in sets:
+            a, b = cs.counts(); npr += a; nac += b
+        res[prec] = dict(counts=(npr, nac), traces=[cs.likelihood_trace() for cs in sets])
+        for cs in sets:
+            cs.close()
+        del sets, fwd
+    _t4_compare(f"{E}x{S}, {world} ranks x {nc} chains (LocalWorld)", res["fp64"], res["fp32"], n_iter // 2)
+
+
+def _fp32_direct_worker(rank, world, port, q):
+    import sys
+
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HTM_XCHG="1",
+                      HTM_RANKS_PER_GPU=str(world), HTM_STREAM_CAP=str(1 << 17))
+    import torch.distributed as dist
+
+    from hypotremormcmc_amd import driver, synth
+    from hypotremormcmc_amd.obs_data import ObsData
+    from hypotremormcmc_amd.parallel import TorchWorld
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        E, S, nc, n_iter = 10000, 128, 16, 300
+        data = synth.make_synthetic(E, S, 5)
+        obs = ObsData.from_arrays(data.sta_x, data.sta_y, data.t_obs, data.t_stdv, data.a_obs, data.a_stdv)
+        out = {}
+        for prec in ("fp64", "fp32"):
+            params = dict(synth.DEFAULT_PARAMS, n_procs=world, n_chains=nc, n_cool=4, temp_high=200.0, n_iter=n_iter,
+                          n_burn=n_iter, n_interval=2, forward_precision=prec)
+            fwd, cs = driver.build_rank(params, data.sta_x, data.sta_y, data.sta_z, obs, rank, n_procs=world, device=0)
+            tw = TorchWorld(cs)
+            assert tw.direct, "peer mapping of the inboxes failed"
+            tw.run(n_iter // 3)
+            tw.run(n_iter - n_iter // 3)
+            assert tw.direct and tw.fell_back is None
+            npr, nac = tw.reduce_counts()
+            out[prec] = dict(counts=(npr, nac), trace=cs.likelihood_trace())
+            cs.close()
+            del tw, cs, fwd
+            dist.barrier()
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_configs4_two_processes_fp32_forward_through_the_in_kernel_exchange():
+    """The same shape with the ranks in separate processes and the swap records exchanged INSIDE the persistent kernels
+    (k_mcmc<2, true, 2>; inboxes mapped between the processes as a node maps them between GPUs): 2 ranks x 16 chains,
+    fp32 against fp64, both through that transport."""
+    import queue
+    import socket
+    import time
+
+    import torch.multiprocessing as mp
+
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fp32_direct_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res, t_end = {}, time.time() + 500
+    while len(res) < world and time.time() < t_end:
+        try:
+            r, out = q.get(timeout=2)
+            res[r] = out
+        except queue.Empty:
+            if any(p.exitcode not in (None, 0) for p in procs):
+                break
+    for p in procs:
+        p.join(timeout=60)
+        if p.is_alive():
+            p.kill()
+        assert p.exitcode == 0
+    assert sorted(res) == list(range(world))
+    r64 = dict(counts=res[0]["fp64"]["counts"], traces=[res[r]["fp64"]["trace"] for r in range(world)])
+    r32 = dict(counts=res[0]["fp32"]["counts"], traces=[res[r]["fp32"]["trace"] for r in range(world)])
+    _t4_compare("10000x128, 2 processes x 16 chains (in-kernel exchange)", r64, r32, 150)
