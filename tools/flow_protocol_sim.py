@@ -1,0 +1,316 @@
+#!/usr/bin/env python3
+"""Model check of the synchronisation protocol of the free-running chain master (csrc/htm_flow.hpp), on the CPU.
+
+The master's waves run their chains' steps without workgroup barriers; what keeps the run identical to the serial
+loop of the reference (src/hypo_tremor_mcmc.f90:236-284) is a handful of rules on shared words in LDS:
+  prog[c]   (epoch, key, reject flag) published by chain c's wave when the proposal of its step is known
+  done[c]   key of the chain's last committed step;  L4 / T4: log-likelihood and temperature by iteration & 3
+  epoch, anchor[epoch & 1] = (key, pos): after a Rayleigh-prior rejection (a step one draw shorter than the hop tables
+            assume) every later step starts elsewhere: "step `key` starts at `pos`"
+This script runs those rules as coroutines (one per wave) under a random scheduler that may switch between any two
+shared-memory accesses, with state-dependent rejections, swaps and a stop request, and compares everything -- the
+position every step started at, final chain states, temperatures, final stream position -- with the serial loop.
+
+    python tools/flow_protocol_sim.py [n_cases]          # exits non-zero on the first difference
+"""
+import random
+import sys
+
+
+def h32(*a):
+    x = 0x9E3779B9
+    for v in a:
+        x = (x ^ (int(v) & 0xFFFFFFFF)) * 0x85EBCA6B & 0xFFFFFFFF
+        x ^= x >> 13
+        x = x * 0xC2B2AE35 & 0xFFFFFFFF
+        x ^= x >> 16
+    return x
+
+
+class Stream:
+    """what the stream rings hold, as functions of the position"""
+
+    def __init__(self, seed, nc, p_rej):
+        self.seed, self.nc, self.p_rej = seed, nc, p_rej
+
+    def w(self, p):                      # draws of a step starting at p if its prior is ok (dec.w)
+        return 4 + h32(self.seed, 1, p) % 3
+
+    def rayleigh(self, p):               # a step that CAN be rejected by its prior (z component)
+        return h32(self.seed, 2, p) % 3 == 0
+
+    def hop(self, p, n):                 # start of the step n steps after the one starting at p (optimistic)
+        for _ in range(n):
+            p += self.w(p)
+        return p
+
+    def sw(self, p):                     # select_pair at p: (i1, i2, draws incl. the judge draw)
+        if self.nc < 2:
+            return 0, 0, 0
+        i1 = h32(self.seed, 3, p) % self.nc
+        i2 = (i1 + 1 + h32(self.seed, 4, p) % (self.nc - 1)) % self.nc
+        return i1, i2, 2 + h32(self.seed, 5, p) % 3 + 1
+
+    def next_from(self, p, n):           # (end of this iteration's chain steps, base of the next) when n steps remain from p
+        e = self.hop(p, n)
+        return e, e + self.sw(e)[2]
+
+
+def step_outcome(st, p, x, L, T):
+    """proposal at position p on chain state (x, L) at temperature T -> (ok, cnt, accepted, x', L')"""
+    ok = not (st.rayleigh(p) and h32(st.seed, 6, p, x) % 1000 < int(1000 * st.p_rej))
+    cnt = st.w(p) - (0 if ok else 1)
+    acc = ok and h32(st.seed, 7, p, L, T) % 100 < 45
+    return ok, cnt, acc, (h32(x, p) if acc else x), (h32(L, p, 1) % 100000 if acc else L)
+
+
+def swap_outcome(st, e, L1, L2, T1, T2):
+    return h32(st.seed, 8, e, L1, L2, T1, T2) % 100 < 30
+
+
+def serial(st, nc, n_iter, x0, L0, T0):
+    x, L, T = list(x0), list(L0), list(T0)
+    p, trace = 0, {}
+    for i in range(1, n_iter + 1):
+        for c in range(nc):
+            trace[(i, c)] = p
+            ok, cnt, acc, x[c], L[c] = step_outcome(st, p, x[c], L[c], T[c])
+            p += cnt
+        if nc > 1:
+            i1, i2, d = st.sw(p)
+            if swap_outcome(st, p, L[i1], L[i2], T[i1], T[i2]):
+                T[i1], T[i2] = T[i2], T[i1]
+            p += d
+    return x, L, T, p, trace
+
+
+class Shared:
+    pass
+
+
+def wave(sh, st, w, NW, nc, i0, target, rnd, trace):
+    """one wave of the master: chains w, w + NW, ...; a generator that yields between shared-memory accesses"""
+    key = lambda i, c: (i - i0) * nc + c
+    nextB = lambda pos, n: st.next_from(pos, n)[1]
+    my_epoch, my_akey = 0, 0             # the epoch this wave predicts in, and that epoch's anchor key
+    i = i0 + 1
+    # "chain rc's step of this iteration starts at rpos" (rc = 0: the iteration's base); the same for the next iteration;
+    # B2 = base of the iteration after that (orders sent ahead only)
+    rc, rpos = 0, 0
+    rc1, rpos1 = 0, nextB(0, nc)
+    B2 = nextB(rpos1, nc)
+    chains = list(range(w, nc, NW))
+    if not chains:
+        return
+    ci = 0
+
+    def from_anchor(a_key, a_pos):
+        """(iteration, chain, position) of the anchor step.  A rejected LAST step of an iteration leaves a_pos = the end
+        of that iteration's chain steps: the anchor step (chain 0 of the next) starts after the swap's draws"""
+        ia, ca = i0 + a_key // nc, a_key % nc
+        return (ia, 0, a_pos + st.sw(a_pos)[2]) if ca == 0 else (ia, ca, a_pos)
+
+    while True:
+        c = chains[ci]
+        # ---- top of a step: the epoch this step's position is predicted in
+        e = sh.epoch; yield
+        if e != my_epoch:
+            while True:
+                a_key, a_pos = sh.anchor[e & 1]; yield
+                e2 = sh.epoch; yield
+                if e2 == e:
+                    break
+                e = e2
+            my_epoch, my_akey = e, a_key
+            ia, ca, ap = from_anchor(a_key, a_pos)
+            # every step this wave has still to run lies at or after the anchor (the rejected step right before it could
+            # only be committed after all earlier steps had passed their checks -- this one has not started)
+            assert key(i, c) >= a_key, (i, c, a_key)
+            if ia == i:
+                rc, rpos = ca, ap
+            else:
+                assert ia == i - 1 and ca > 0, (ia, ca, i)
+                rc, rpos = 0, nextB(ap, nc - ca)
+            rc1, rpos1 = 0, nextB(rpos, nc - rc)
+            B2 = nextB(rpos1, nc)
+        last = sh.last_iter; yield
+        if i > last:
+            break
+        assert c >= rc
+        P = st.hop(rpos, c - rc)
+        if c == 0:                       # chain 0's wave: stop request of this launch (records / stream nearly used up)
+            if sh.stop_at == i:
+                sh.last_iter = i; yield
+        # ---- front: proposal (own chain state only)
+        for _ in range(rnd.randint(0, 3)):
+            yield
+        x, L = sh.x[c], sh.L[c]
+        ok_pre = not (st.rayleigh(P) and h32(st.seed, 6, P, x) % 1000 < int(1000 * st.p_rej))
+        cnt_pre = st.w(P) - (0 if ok_pre else 1)
+        if c == nc - 1:
+            sh.Eof[i & 3] = P + cnt_pre; yield       # where this iteration's swap starts (valid if this step is)
+        sh.prog[c] = (my_epoch, key(i, c), 0 if ok_pre else 1); yield
+        for _ in range(rnd.randint(0, 6)):     # evaluation
+            yield
+        # ---- turn: every earlier step has passed its check in this epoch (or lies before the anchor)
+        restart = False
+        while True:
+            pr = list(sh.prog); yield
+            e = sh.epoch; yield
+            if e != my_epoch:
+                a_key, a_pos = sh.anchor[e & 1]; yield
+                e2 = sh.epoch; yield
+                if e2 != e:
+                    continue
+                if key(i, c) >= a_key:
+                    restart = True
+                    break
+                # this step stands; everything this wave runs after it starts at or after the anchor
+                my_epoch, my_akey = e, a_key
+                ia, ca, ap = from_anchor(a_key, a_pos)
+                if ia == i:
+                    assert ca > c
+                    rc, rpos = ca, ap                 # (the wave's later chains of this iteration)
+                    rc1, rpos1 = 0, nextB(ap, nc - ca)
+                else:
+                    assert ia == i + 1 and ca <= c, (ia, i, ca, c)
+                    rc1, rpos1 = ca, ap
+                B2 = nextB(rpos1, nc - rc1)
+                continue
+            good = True
+            for c2 in range(nc):
+                if c2 == c:
+                    continue
+                need = key(i, c2) if c2 < c else key(i - 1, c2)
+                pe, pk, pf = pr[c2]
+                if pk > need:
+                    continue
+                # the step itself: final if it lies before the anchor (checked in an earlier epoch; the one right before
+                # the anchor is the committed rejection itself), else it must have passed its check in THIS epoch
+                if pk == need and (pk < my_akey or (pe == my_epoch and pf == 0)):
+                    continue
+                good = False
+            if good:
+                break
+            yield
+        if restart:
+            continue
+        # ---- the swap of the iteration before, if this chain was in its pair
+        T_now = sh.T4[(i - 1) & 3][c] if i - 1 > i0 else sh.T4[i & 3][c]
+        if i - 1 > i0 and nc > 1:
+            E_prev = sh.Eof[(i - 1) & 3]; yield      # written by the last chain's wave before it published its check
+            i1, i2, d = st.sw(E_prev)
+            if c in (i1, i2):
+                o = i2 if c == i1 else i1
+                while True:
+                    dn = sh.done[o]; yield
+                    if dn >= key(i - 1, o):
+                        break
+                L1, L2 = sh.L4[(i - 1) & 3][i1], sh.L4[(i - 1) & 3][i2]; yield
+                T1, T2 = sh.T4[(i - 1) & 3][i1], sh.T4[(i - 1) & 3][i2]; yield
+                if swap_outcome(st, E_prev, L1, L2, T1, T2):
+                    T_now = T2 if c == i1 else T1
+        sh.T4[i & 3][c] = T_now; yield
+        ok, cnt, acc, x2, L2_ = step_outcome(st, P, x, L, T_now)
+        assert ok == ok_pre
+        trace[(i, c)] = P
+        sh.x[c], sh.L[c] = x2, L2_
+        sh.L4[i & 3][c] = L2_; yield
+        sh.done[c] = key(i, c); yield
+        if not ok:
+            # a step one draw shorter than predicted: everything after it starts elsewhere
+            a = (key(i, c) + 1, P + cnt)
+            sh.anchor[(my_epoch + 1) & 1] = a; yield
+            sh.epoch = my_epoch + 1; yield
+            my_epoch, my_akey = my_epoch + 1, a[0]
+            ia, ca, ap = from_anchor(*a)
+            if ia == i:
+                rc, rpos = ca, ap                     # (the wave's later chains of this iteration)
+                rc1, rpos1 = 0, nextB(ap, nc - ca)
+            else:
+                rc1, rpos1 = 0, ap
+            B2 = nextB(rpos1, nc - rc1)
+        # ---- next step of this wave
+        ci += 1
+        if ci == len(chains):
+            ci = 0
+            i += 1
+            rc, rpos = rc1, rpos1
+            rc1, rpos1 = 0, B2
+            B2 = nextB(B2, nc)
+    return
+
+
+def run_case(seed, verbose=False):
+    rnd = random.Random(seed)
+    nc = rnd.choice([1, 2, 3, 5, 8, 8, 11, 16, 19])
+    NW = 8
+    n_iter = rnd.randint(3, 40)
+    p_rej = rnd.choice([0.0, 0.02, 0.2, 0.6, 1.0])
+    st = Stream(seed, nc, p_rej)
+    x0 = [h32(seed, 10, c) for c in range(nc)]
+    L0 = [h32(seed, 11, c) % 100000 for c in range(nc)]
+    T0 = [1 + c for c in range(nc)]
+    stop_at = rnd.choice([None, None, rnd.randint(1, n_iter)])
+    n_run = stop_at if stop_at else n_iter
+    xs, Ls, Ts, ps, tr_s = serial(st, nc, n_run, x0, L0, T0)
+
+    sh = Shared()
+    sh.epoch, sh.anchor = 0, [(0, 0), (0, 0)]
+    i0 = 0
+    sh.prog = [(0, c, 0) for c in range(nc)]                # key(i0, c): the steps of the iteration before the launch
+    sh.done = [c for c in range(nc)]
+    sh.x, sh.L = list(x0), list(L0)
+    sh.L4 = [[0] * nc for _ in range(4)]
+    sh.T4 = [[0] * nc for _ in range(4)]
+    for c in range(nc):
+        sh.T4[(i0 + 1) & 3][c] = T0[c]
+    sh.last_iter, sh.stop_at = n_iter, stop_at
+    sh.Eof = [0, 0, 0, 0]
+    trace = {}
+    gens = [wave(sh, st, w, NW, nc, i0, n_iter, rnd, trace) for w in range(NW)]
+    alive = list(range(NW))
+    steps = 0
+    bias = rnd.choice([None, None, rnd.randrange(NW)])        # one wave that is scheduled rarely (a straggler)
+    while alive:
+        k = rnd.choice(alive)
+        if bias is not None and k == bias and rnd.random() < 0.85:
+            continue
+        try:
+            next(gens[k])
+        except StopIteration:
+            alive.remove(k)
+        steps += 1
+        if steps > 5_000_000:
+            raise RuntimeError("no progress (deadlock or livelock): seed %d" % seed)
+    # after the final barrier: the swap of the last iteration, by one thread
+    T = [sh.T4[n_run & 3][c] for c in range(nc)]
+    L = [sh.L4[n_run & 3][c] for c in range(nc)]
+    p_end = sh.Eof[n_run & 3]
+    if nc > 1:
+        i1, i2, d = st.sw(p_end)
+        if swap_outcome(st, p_end, L[i1], L[i2], T[i1], T[i2]):
+            T[i1], T[i2] = T[i2], T[i1]
+        p_end += d
+    ok = (sh.x == xs and sh.L == Ls and T == Ts and p_end == ps and trace == tr_s)
+    if verbose or not ok:
+        print("seed %d: nc %d, %d iterations (stop at %s), p_rej %.2f, epochs %d: %s" %
+              (seed, nc, n_iter, stop_at, p_rej, sh.epoch, "equal" if ok else "MISMATCH"))
+        if not ok:
+            for k in sorted(tr_s):
+                if trace.get(k) != tr_s[k]:
+                    print("  first differing step", k, "serial", tr_s[k], "flow", trace.get(k))
+                    break
+            print("  x", sh.x == xs, "L", sh.L == Ls, "T", T == Ts, "pos", p_end, ps)
+    return ok
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    bad = 0
+    for s in range(1, n + 1):
+        if not run_case(s):
+            bad += 1
+            break
+    print("%d cases: %s" % (n, "all equal to the serial loop" if not bad else "FAILED"))
+    sys.exit(1 if bad else 0)
