@@ -1,0 +1,755 @@
+// htm_flow.hpp -- the FREE-RUNNING chain master of k_mcmc (single rank, MODE_RUN): the main loop of a rank
+// (hypo_tremor_mcmc.f90:236-284) without workgroup barriers.
+//
+// step_body (htm_step.hpp) runs an iteration as  passes | barrier A | roles | barrier B | post : every iteration lasts as
+// long as its slowest chain step plus ~3 k cycles of roles and post (round 2: 14.7 k cycles per iteration at 8 chains, of
+// which a partial update is 7-8.6 k).  Here every chain wave runs its chain's steps back to back -- proposal, evaluation,
+// decision, commit, records, the orders of its coming full evaluations, next step -- and the waves meet only where the
+// algorithm couples the chains:
+//   * the rank's random stream (mod_random, one serial stream shared by all chains): where a step starts depends on how
+//     many draws every earlier step took.  The hop tables (htm_stream.hpp) predict that assuming every prior is ok; a
+//     Rayleigh-prior rejection (cls_model.f90:178-181, no judge draw: cls_mcmc.f90:193) makes a step one draw shorter.
+//     Rule: a step is COMMITTED only when every step before it in stream order -- (i, c') for c' < c, (i-1, c') for
+//     c' > c -- has passed its prior check (`prog`, published ~3 k cycles into a step; the commit comes ~7 k cycles in:
+//     that is the slack between the waves).  A step that finds its prior violated commits (as a rejection) when its turn
+//     comes and then publishes an ANCHOR "step `key` starts at `pos`" under a new EPOCH: every later step re-predicts from
+//     it (nothing after a pending rejection can have been committed, so nothing is ever undone).
+//   * the temperature swap (cls_parallel.f90:121-136): the pair of iteration i-1 concerns two chains; each of their waves
+//     evaluates the same decision from (T, L) of both chains after iteration i-1 (rings of four iterations in LDS), just
+//     before its own decision of iteration i -- the first thing that needs the temperature.  Nobody else waits.
+//   * records: slots by LDS atomics, sorted by (iteration, chain) on the host when drained.
+// The protocol (prog / done / epoch / anchor, the turn rule, re-prediction from the anchor alone) is model-checked on the
+// CPU against the serial loop under random interleavings: tools/flow_protocol_sim.py.
+// Full evaluations: the worker blocks and the tagged-granule hand-off of htm_step.hpp, unchanged; the orders role P sent
+// for all chains are sent by each chain's own wave right after its commit (one step ahead, or two around a hypocentre step).
+#pragma once
+#include "htm_step.hpp"
+
+namespace htm {
+
+struct FlowShared : StepShared {
+    unsigned long long prog[kMaxChains];   // {epoch << 1 | prior rejected : 32, key : 32} of the chain's latest checked step
+    int done[kMaxChains];                  // key of the chain's latest committed step
+    double L4[4][kMaxChains];              // log-likelihood after iteration i (index i & 3)
+    double T4[4][kMaxChains];              // temperature DURING iteration i
+    double rT4[4][kMaxChains];             // its reciprocal (what the Metropolis ratio and the swap multiply by; travels with T)
+    unsigned long long anch[2];            // [epoch & 1] {key : 32, pos : 32}: step `key` starts at stream position `pos`
+    int epoch;
+    int Eof[4];                            // [i & 3] where the chain steps of iteration i end (= where its swap starts)
+    // [i & 3] the swap of iteration i as the stream has it there: pair, draws it takes, judge_swap's draw and its log.  Written
+    // with Eof by the last chain's wave when its step has passed its check (the positions are its own near future: inside the
+    // LDS window); read when the swap is decided, up to two iterations later -- by then the window may have moved on
+    int sw_i1[4], sw_i2[4], sw_nd[4];
+    double sw_r[4], sw_logr[4];
+    int last_iter;                         // the launch ends after this iteration
+    int stop_code;
+    int i0;                                // iterations completed before this launch
+    // order book of every chain (owning wave only): the step starting at ob_pos has its order out under ob_tag
+    int ob_pos[kMaxChains], ob_mode[kMaxChains], ob_mid[kMaxChains];     // ob_mid: type | event << 3 of the step in between (mode 2)
+    unsigned ob_tag[kMaxChains];
+    unsigned long long n_full_w, n_part_w;
+};
+
+// LDS words shared between the waves: relaxed accesses in program order.  LDS operations of a wave are executed in
+// issue order and the LDS is one serialisation point for the workgroup, so "release" and "acquire" are compiler
+// barriers here, not waits for outstanding memory operations.
+__device__ __forceinline__ int lds_ld(const int *p) { const int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); asm volatile("" ::: "memory"); return v; }
+__device__ __forceinline__ unsigned long long lds_ld(const unsigned long long *p) { const unsigned long long v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); asm volatile("" ::: "memory"); return v; }
+__device__ __forceinline__ void lds_st(int *p, int v) { asm volatile("" ::: "memory"); __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_st(unsigned long long *p, unsigned long long v) { asm volatile("" ::: "memory"); __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+struct FlowWave {                 // a wave's predictions (wave-uniform)
+    int epoch, akey;              // the epoch they are made in, that epoch's anchor key
+    int rc, rpos;                 // "chain rc's step of the current iteration starts at rpos" (rc = 0: the iteration's base)
+    int rc1, rpos1;               // the same for the next iteration
+    int B2;                       // base of the iteration after that (orders sent ahead only); -1 = not known
+};
+
+constexpr int kFlowRestart = -1;  // flow_step: the step's position was disproved before its turn came: run it again
+constexpr int kFlowAbort = -2;    // flow_step: a wait gave up (sh.c.err is set)
+
+// select_pair + the judge_swap draw starting at E (cls_parallel.f90:226-230, :163): pair, draws used in all (single rank:
+// this rank draws both).  The stream service has the usual case precomputed (sw ring); more than 12 redraws follow the stream.
+__device__ __forceinline__ bool flow_swap_at(CsRef cs_, const StepShared &sh, const Ring &rg, int E, int limit, int &i1, int &i2, int &nd)
+{
+    CsRef cs = rebase(cs_);
+    const int n_all = cs.n_procs * cs.n_chains;
+    i1 = -1; i2 = -1; nd = 0;
+    if (n_all <= 1) return true;
+    if (E + 2 >= limit) return false;
+    const i32x4 sw = reinterpret_cast<const i32x4 *>(rg.sw)[E & rg.mask];
+    if (sw.z > 0) { i1 = sw.x; i2 = sw.y; nd = sw.z + 1; return E + nd < limit; }
+    int pos = E;
+    i1 = (int)(rg.U[pos & rg.mask] * cs.n_procs * cs.n_chains);
+    pos++;
+    for (;;) {
+        if (pos + 1 >= limit) return false;
+        i2 = (int)(rg.U[pos & rg.mask] * cs.n_procs * cs.n_chains);
+        pos++;
+        if (i1 != i2) break;
+    }
+    nd = pos - E + 1;
+    return true;
+}
+
+// base of the next iteration when n chain steps of this one remain from pos; -1 if the window does not cover it
+__device__ __forceinline__ int flow_next_base(CsRef cs, const StepShared &sh, const Ring &rg, int pos, int n, int limit)
+{
+    if (pos < 0) return -1;
+    const int E = hop_ahead(rg, pos, n);
+    int i1, i2, nd;
+    if (E + 16 >= limit || !flow_swap_at(cs, sh, rg, E, limit, i1, i2, nd)) return -1;
+    return E + nd;
+}
+
+// the anchor as (iteration, chain, position of that chain's step).  A rejected LAST step of an iteration leaves pos = the
+// end of that iteration's chain steps: chain 0 of the next iteration starts after the swap's draws.
+__device__ __forceinline__ void flow_from_anchor(CsRef cs_, const FlowShared &sh, const Ring &rg, unsigned long long a, int &ia, int &ca, int &ap)
+{
+    CsRef cs = rebase(cs_);
+    const int nc = cs.n_chains;
+    const int key = (int)(unsigned)(a >> 32), pos = (int)(unsigned)a;
+    ia = sh.i0 + key / nc; ca = key - (key / nc) * nc; ap = pos;
+    if (ca == 0) {
+        int i1, i2, nd;
+        flow_swap_at(cs, sh, rg, pos, 1 << 30, i1, i2, nd);     // (the rejected step's own wave read these positions: covered)
+        ap = pos + nd;
+    }
+}
+
+// every order this wave has out for its chains is void (their positions were predicted in another epoch): the workers are told
+__device__ __forceinline__ void flow_void_books(CsRef cs, FlowShared &sh, int wave, int NW, int nc, int lane)
+{
+    for (int c = wave; c < nc; c += NW) {
+        if (sh.ob_pos[c] != -1) {
+            if (lane == 0) { void_slot(cs, c); sh.ob_pos[c] = -1; }
+        }
+    }
+}
+
+// this wave adopts epoch e (read from sh.epoch a moment ago).  `standing`: its current step (it, c) has passed its check and lies
+// before the anchor -- it stands, and everything the wave runs after it starts at or after the anchor; else the current
+// step itself starts at or after the anchor.  Returns false if the epoch moved on meanwhile (the caller looks again).
+__device__ __forceinline__ bool flow_adopt(CsRef cs_, FlowShared &sh, const Ring &rg, FlowWave &W, int e, int it, int c, bool in_turn, bool &stands)
+{
+    CsRef cs = rebase(cs_);
+    const int nc = cs.n_chains;
+    const unsigned long long a = lds_ld(&sh.anch[e & 1]);
+    if (lds_ld(&sh.epoch) != e) return false;
+    const int akey = (int)(unsigned)(a >> 32);
+    const int key = (it - sh.i0) * nc + c;
+    int ia, ca, ap;
+    flow_from_anchor(cs, sh, rg, a, ia, ca, ap);
+    const int limit = sh.fill;
+    stands = in_turn && key < akey;
+    W.epoch = e; W.akey = akey;
+    if (!stands) {
+        // the current step starts at or after the anchor: same iteration, or the anchor sits in the iteration before
+        if (ia == it) { W.rc = ca; W.rpos = ap; }
+        else { W.rc = 0; W.rpos = flow_next_base(cs, sh, rg, ap, nc - ca, 1 << 30); }
+        W.rc1 = 0; W.rpos1 = flow_next_base(cs, sh, rg, W.rpos, nc - W.rc, limit);
+        W.B2 = flow_next_base(cs, sh, rg, W.rpos1, nc, limit);
+    } else if (ia == it) {
+        W.rc = ca; W.rpos = ap;                         // (the wave's later chains of this iteration)
+        W.rc1 = 0; W.rpos1 = flow_next_base(cs, sh, rg, ap, nc - ca, limit);
+        W.B2 = flow_next_base(cs, sh, rg, W.rpos1, nc, limit);
+    } else {                                            // the anchor is a step of the next iteration
+        W.rc1 = ca; W.rpos1 = ap;
+        W.B2 = flow_next_base(cs, sh, rg, ap, nc - ca, limit);
+    }
+    return true;
+}
+
+// One chain step from its front to its commit and the orders of the chain's coming full evaluations (the free-running
+// counterpart of chain_pass).  All 64 lanes execute with identical (uniform) values; lane <-> station only inside
+// event_misfit.  `ext`: this wave keeps the LDS window of the stream ahead (chain 0's wave, one round of <= 64 positions
+// per step, in flight under the step's own loads).  Returns the stream position after the step, kFlowRestart or kFlowAbort.
+template <int NCH, bool F32>
+__device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, const Ring &rg, FlowWave &W,
+                                         const double *s_sx, const double *s_sy, const double *s_sz, int c, int p, int iter,
+                                         int lane, int wave, int NW, unsigned long long launch, bool ext, int look, int back,
+                                         bool rec_now)
+{
+    CsRef cs = rebase(cs_);
+    FwRef f = rebase(f_);
+    const int M = rg.mask;
+    p = __builtin_amdgcn_readfirstlane(p);
+    // ---- the LDS window of the stream rings, one round per step of chain 0's wave: requested first, stored behind the
+    // ---- step's own loads (which return after it: vector-memory operations complete in order)
+    PfRegs pf;
+    pf.p = -1;
+    int fill_to = 0;
+    if (ext) {
+        const int fl = sh.fill;
+        // (this step is chain c's: the iteration's base lies 4 c .. 6 c positions back; the other waves may still read `back`
+        // positions behind it, and want `look` positions ahead of it)
+        fill_to = min(min(p - 4 * c + look, sh.avail), p - 6 * c - back + M + 1);
+        if (fill_to > fl + 64) fill_to = fl + 64;
+        if (fill_to > fl) pf_load(pf, cs, sh, fl + lane, fill_to);
+    }
+    const double *xall_ = cs.xall, *muall_ = cs.muall, *rs2all_ = cs.rs2all, *stall_ = cs.stall;
+    const int *ptall_ = cs.ptall;
+    const int nc_ = cs.n_chains, S_ = cs.S, nh = 3 * cs.E;
+    const i32x4 dec = reinterpret_cast<const i32x4 *>(rg.dec)[p & M];      // decoded ahead of time (htm_stream.hpp)
+    asm volatile("" : "+s"(xall_), "+s"(muall_), "+s"(rs2all_), "+s"(stall_), "+s"(ptall_));
+    const int type = __builtin_amdgcn_readfirstlane(dec.x), idx = __builtin_amdgcn_readfirstlane(dec.y);
+    const int evt = __builtin_amdgcn_readfirstlane(dec.z), dec_w = __builtin_amdgcn_readfirstlane(dec.w);
+    const double g = rg.pg[p & M], r_ring = rg.pr[p & M], logr_ring = rg.plogr[p & M];
+    const bool partial = evt > 0 && iter > 1;       // hypo_tremor_mcmc.f90:246
+    const int off_tc = nc_, off_qs = nc_ + nc_ * S_, off_ac = 2 * nc_ + nc_ * S_, off_hy = 2 * nc_ + 2 * nc_ * S_;
+    const int goff = type == 1 ? 0 : type == 2 ? off_tc : type == 3 ? off_qs : type == 4 ? off_ac : off_hy;
+    const int gnx = (type == 1 || type == 3) ? 1 : (type == 2 || type == 4) ? S_ : nh;
+    const int o = goff + c * gnx + idx;             // element of the rank's parameter vector this step perturbs
+    const int ev = partial ? evt - 1 : 0;
+    const int o_h = off_hy + c * nh + 3 * ev;
+    int goffs = o;
+    goffs = lane == 1 ? o_h : goffs; goffs = lane == 2 ? o_h + 1 : goffs; goffs = lane == 3 ? o_h + 2 : goffs;
+    goffs = lane == 4 ? c : goffs; goffs = lane == 5 ? off_qs + c : goffs;
+    const double gathered_v = xall_[goffs];
+    const double mu = ld_const(muall_ + o), rs2 = ld_const(rs2all_ + o), step = ld_const(stall_ + o);
+    const int ptype = ld_const(ptall_ + o);
+    const double *tc = xall_ + off_tc + c * S_, *ac = xall_ + off_ac + c * S_;
+    StaRegs<(NCH > 0 ? NCH : 1)> st;
+    ObsRegs<(NCH > 0 ? NCH : 1)> ob;
+    if (partial) {
+        if constexpr (NCH > 0) {
+            load_sta_regs<NCH>(st, f.S, lane, s_sx, s_sy, s_sz, tc, ac, 0, -1, 0.0);
+            load_obs_regs<NCH, F32>(ob, f, ev, lane);      // in flight while the proposal is worked out
+        }
+    }
+    // the book of this chain: is this step's order out already, and how
+    const int book_pos = sh.ob_pos[c], book_mode = sh.ob_mode[c], book_mid = sh.ob_mid[c];
+    const unsigned book_tag = sh.ob_tag[c];
+    const bool pre = !partial && book_pos == p;
+    const int pre_mode = pre ? book_mode : 0;
+    // a full-evaluation step whose order went out two steps ahead adds the event of the step in between itself (below):
+    // its inputs are requested now, into the registers a partial update would use
+    int d_e = 0;
+    double d_ex = 0.0, d_ey = 0.0, d_ez = 0.0;
+    const bool own_evt = NCH > 0 && pre_mode == 2 && (book_mid & 7) >= 5;
+    if constexpr (NCH > 0) {
+        if (__builtin_expect(own_evt, 0)) {
+            d_e = __builtin_amdgcn_readfirstlane(book_mid >> 3) - 1;
+            const int vzd = opaque_zero();
+            const double *hypd = xall_ + off_hy + c * nh + 3 * d_e;
+            d_ex = ld_state(hypd, vzd); d_ey = ld_state(hypd + 1, vzd); d_ez = ld_state(hypd + 2, vzd);
+            load_sta_regs<NCH>(st, f.S, lane, s_sx, s_sy, s_sz, tc, ac, 0, -1, 0.0);
+            load_obs_regs<NCH, F32>(ob, f, d_e, lane);
+        }
+    }
+    const double x_old = rl_f64(gathered_v, 0);
+    const double hx = rl_f64(gathered_v, 1), hy = rl_f64(gathered_v, 2), hz = rl_f64(gathered_v, 3);
+    const double beta = rl_f64(gathered_v, 4), q = rl_f64(gathered_v, 5);
+    const double L_cur = sh.L[c];
+    const double x_new = x_old + g * step;                      // cls_model.f90:172
+    const double da = x_new - mu, db = x_old - mu;
+    double lpr = -(da * da - db * db) * rs2;                    // :175-177 (rs2 = 1 / (2 sigma^2), formed once on the host)
+    int ok = 1;
+    if (ptype == 1) {                                           // :178-187
+        if (x_new <= mu) { lpr = (double)-1.0e+30f; ok = 0; }
+        else lpr = lpr + log(x_new - mu) - log(x_old - mu);
+    }
+    const double r = ok ? r_ring : 0.0, logr = ok ? logr_ring : 0.0;
+    const int cnt = dec_w - 1 + ok;                             // the judge draw happens only if prior_ok
+    const int key = (iter - sh.i0) * nc_ + c;
+    // ---- the step has passed (or failed) its prior check: the later steps may go ahead on it
+    if (c == nc_ - 1) {                                         // where this iteration's swap starts, and what it draws there
+        const int E = p + cnt, k4 = iter & 3;
+        int i1, i2, nd;
+        flow_swap_at(cs, sh, rg, E, 1 << 30, i1, i2, nd);
+        if (lane == 0) {
+            sh.sw_i1[k4] = i1; sh.sw_i2[k4] = i2; sh.sw_nd[k4] = nd;
+            if (nd > 0) { sh.sw_r[k4] = rg.U[(E + nd - 1) & M]; sh.sw_logr[k4] = rg.LOGU[(E + nd - 1) & M]; }
+            lds_st(&sh.Eof[k4], E);
+        }
+    }
+    if (lane == 0) {
+        lds_st(&sh.prog[c], ((unsigned long long)(((unsigned)W.epoch << 1) | (ok ? 0u : 1u)) << 32) | (unsigned)key);
+    }
+    if (ext && fill_to > sh.fill) {                             // (the window's loads were issued before the step's: they are there)
+        pf_store(pf, rg);
+        if (lane == 0) lds_st(&sh.fill, fill_to);
+    }
+
+    double L_new = 0.0;
+    int need_full = 0;
+    if (__builtin_expect(ok != 0, 1)) {
+        if (__builtin_expect(partial, 1)) {
+            const int cmp = idx - 3 * ev;        // 0 x, 1 y, 2 z of event ev (selects: see htm_step.hpp)
+            const double px[2] = {hx, cmp == 0 ? x_new : hx};
+            const double py[2] = {hy, cmp == 1 ? x_new : hy};
+            const double pz[2] = {hz, cmp == 2 ? x_new : hz};
+            double out[2];
+            if constexpr (NCH > 0) event_misfit<NCH, 2, F32>(f, ob, lane, st, px, py, pz, beta, q, out);
+            else event_misfit_generic<2>(f, ev, lane, s_sx, s_sy, s_sz, tc, ac, 0, -1, 0.0, px, py, pz, beta, q, out);
+            L_new = L_cur + wave_sum1(out[0] - out[1]);
+        } else {
+            need_full = 1;
+            // ---- work order: recognised (sent by this wave one or two steps ago) or sent now -------------------------
+            unsigned long long tk = 0;
+            if (lane == 0) {
+                tk = pre ? (unsigned long long)book_tag : ((atomicAdd(&sh.c.jobs_total, 1ull) + 1ull) & 0x7fffffffull);
+                if (tk == 0) tk = 0x7fffffffull;      // 0 = empty slot: never a tag (the counter wraps after 2^31 orders)
+                // an order of its own overwrites the slot: whatever else is on the book for this chain is void with it
+                sh.ob_pos[c] = -1;
+            }
+            const unsigned tag = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)tk);
+            // every chain-state store of this wave has landed before a worker can see the order (write-through stores,
+            // drained here; an order sent ahead names the commit the workers have to see instead)
+            if (!pre) drain_vmem();
+            if (!pre && lane < cs.slot_rep * kGranPerSlot) {
+                const int gi = lane & 7;
+                const unsigned long long xb = (unsigned long long)__double_as_longlong(x_new);
+                const unsigned pay = gi == 0 ? (unsigned)launch : gi == 1 ? ((unsigned)type | ((unsigned)idx << 3))
+                                   : gi == 2 ? (unsigned)(xb >> 32) : gi == 3 ? (unsigned)xb
+                                   : gi == 4 ? 0xffffffffu : 0u;          // no commit to wait for (drained above), nothing left out
+                st_gran(cs.slots + (size_t)(lane >> 3) * cs.slot_stride + c * kGranPerSlot + gi, tag, pay);
+            }
+            // ---- the workers' partial sums: tagged granules, fixed summation order; two rounds of loads in flight --
+            const unsigned long long *pg = cs.pgran + (size_t)c * cs.n_wg * cs.pgran_stride;
+            const int pgs = cs.pgran_stride;
+            double part = 0.0;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz
+            constexpr int kSweep = 4;                 // <= 256 workers (host-checked)
+            unsigned long long hi[2][kSweep], lo[2][kSweep];
+            int which = 0;
+            auto issue = [&](int b) __attribute__((always_inline)) {
+#pragma unroll
+                for (int j = 0; j < kSweep; ++j) {
+                    const int k = j * 64 + lane;
+                    hi[b][j] = 0; lo[b][j] = 0;
+                    if (k < cs.n_wg) { hi[b][j] = ld_agent(pg + (size_t)pgs * k); lo[b][j] = ld_agent(pg + (size_t)pgs * k + 1); }
+                }
+            };
+            auto complete = [&](int b) __attribute__((always_inline)) {
+                bool got = true;
+#pragma unroll
+                for (int j = 0; j < kSweep; ++j)
+                    if (j * 64 + lane < cs.n_wg) got = got && (unsigned)(hi[b][j] >> 32) == tag && (unsigned)(lo[b][j] >> 32) == tag;
+                return __all(got);
+            };
+            // an order sent two steps ahead was answered a step ago: its granules are requested now, under the evaluation
+            // of the wave's own event
+            const bool early = pre_mode == 2;
+            if (early) issue(0);
+            // An order sent TWO steps ahead was evaluated while the step in between (a hypocentre step of this chain) may
+            // or may not have committed: the workers LEFT THAT EVENT OUT, this wave adds its misfit -- at the position the
+            // event has now, under this step's proposed parameters.  The result does not depend on when the workers looked.
+            double own_lane = 0.0;
+            if constexpr (NCH > 0) {
+                if (own_evt) {
+                    if (type == 2 || type == 4) {          // this step's proposed correction, on the lane of its station
+#pragma unroll
+                        for (int k = 0; k < NCH; ++k) {
+                            if (lane + 64 * k == idx) { if (type == 2) st.tc[k] = x_new; else st.ac[k] = x_new; }
+                        }
+                    }
+                    const double pxd[1] = {d_ex}, pyd[1] = {d_ey}, pzd[1] = {d_ez};
+                    double outd[1];
+                    event_misfit<NCH, 1, F32>(f, ob, lane, st, pxd, pyd, pzd, type == 1 ? x_new : beta, type == 3 ? x_new : q, outd);
+                    own_lane = outd[0];
+                }
+            }
+            bool have = false;
+            if (early) have = complete(0);
+            if (!have) {
+                issue(0);
+                for (;;) {
+                    issue(1);
+                    if (complete(0)) { which = 0; break; }
+                    issue(0);
+                    if (complete(1)) { which = 1; break; }
+                    if (sh.c.err != 0) return kFlowAbort;
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) {
+                        if (lane == 0) {
+                            sh.c.err = -8;
+                            unsigned long long *dg = cs.diag;          // what was waited for: the host puts it into its message
+                            dg[1] = c; dg[2] = tag; dg[3] = pre; dg[4] = pre_mode; dg[5] = iter; dg[6] = p; dg[7] = type; dg[8] = idx;
+                            dg[9] = hi[0][0]; dg[10] = lo[0][0]; dg[11] = 1; dg[12] = p; dg[0] = 1;
+                        }
+                        return kFlowAbort;
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < kSweep; ++j)            // fixed order: worker lane, lane + 64, ...
+                if (j * 64 < cs.n_wg)
+                    part += (j * 64 + lane < cs.n_wg) ? (which == 0 ? gran_f64(hi[0][j], lo[0][j]) : gran_f64(hi[1][j], lo[1][j])) : 0.0;
+            L_new = -wave_sum1(part + own_lane) - f.const_sum;       // cls_forward.f90:277-300
+        }
+    }
+
+    // ---- the step's turn: every step before it in stream order has passed its check in this epoch (or lies before the
+    // ---- epoch's anchor: checked earlier, final).  Lanes <-> chains.
+    {
+        const int key_i = (iter - sh.i0) * nc_, key_m = key_i - nc_;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (unsigned spin = 0;; ++spin) {
+            const unsigned long long pv = lane < nc_ ? lds_ld(&sh.prog[lane]) : 0ull;
+            const int e = lds_ld(&sh.epoch);
+            if (__builtin_expect(e != W.epoch, 0)) {
+                bool stands = false;
+                if (!flow_adopt(cs, sh, rg, W, e, iter, c, true, stands)) continue;
+                flow_void_books(cs, sh, wave, NW, nc_, lane);
+                if (!stands) return kFlowRestart;
+                continue;
+            }
+            const int need = (lane < c ? key_i : key_m) + lane;
+            const int pk = (int)(unsigned)pv;
+            const unsigned ph = (unsigned)(pv >> 32);
+            const bool okl = lane >= nc_ || lane == c || pk > need ||
+                             (pk == need && (pk < W.akey || (ph == ((unsigned)W.epoch << 1))));
+            if (__all(okl)) break;
+            if ((spin & 15u) == 15u) {
+                if (sh.c.err != 0) return kFlowAbort;
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) { if (lane == 0) sh.c.err = -12; return kFlowAbort; }
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    // ---- the temperature of this iteration: the swap of the iteration before (cls_parallel.f90:121-136, :285-302), decided
+    // ---- here by the waves of the two chains it concerns -- each evaluates the same expression on the same values
+    const int par = iter & 3, ppar = (iter - 1) & 3;
+    double T = sh.T4[par][c], rT = sh.rT4[par][c];        // (first iteration of a launch: written by the prologue)
+    if (iter - 1 > sh.i0) {
+        T = sh.T4[ppar][c]; rT = sh.rT4[ppar][c];
+        if (cs.n_procs * nc_ > 1) {
+            // (written by the last chain's wave before it published its check; this step's turn has seen that check)
+            const int i1 = lds_ld(&sh.sw_i1[ppar]), i2 = sh.sw_i2[ppar];
+            if (c == i1 || c == i2) {
+                const int o2 = c == i1 ? i2 : i1;
+                const int want = (iter - 1 - sh.i0) * nc_ + o2;
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                for (unsigned spin = 0; lds_ld(&sh.done[o2]) < want; ++spin) {
+                    if ((spin & 15u) == 15u) {
+                        if (sh.c.err != 0) return kFlowAbort;
+                        if (__builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) { if (lane == 0) sh.c.err = -12; return kFlowAbort; }
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                const double sr = sh.sw_r[ppar], slr = sh.sw_logr[ppar];
+                const double T1 = sh.T4[ppar][i1], T2 = sh.T4[ppar][i2], rT1 = sh.rT4[ppar][i1], rT2 = sh.rT4[ppar][i2];
+                const double del_s = (sh.L4[ppar][i2] - sh.L4[ppar][i1]) * (rT1 - rT2);      // :292 (1/T formed once per temperature)
+                if (sr >= kEps && slr <= del_s) { T = c == i1 ? T2 : T1; rT = c == i1 ? rT2 : rT1; }      // :131-136
+            }
+        }
+    }
+    const int acc = (ok != 0 && metropolis(L_new, L_cur, rT, lpr, r, logr)) ? 1 : 0;       // cls_mcmc.f90:193-203
+    // this wave's chain-state stores of EARLIER steps have landed before this step's commit goes out: an order sent after
+    // the commit names only the commit itself for the workers to wait for
+    drain_vmem();
+    const int cool = (T < 1.0 + kEps) ? 1 : 0;
+    const double L_post = acc ? L_new : L_cur;
+    if (lane == 0) {
+        sh.T4[par][c] = T; sh.rT4[par][c] = rT;
+        if (ok != 0) atomicAdd(need_full ? &sh.n_full_w : &sh.n_part_w, 1ull);      // (a step that is run again left before this point)
+        if (cool) sh.np[c * 7 + type - 1] += 1;                 // cls_mcmc.f90:186-189
+        if (acc) {                                              // :207-219
+            st_agent(cs.xall + o, x_new);
+            if (o < rg.mir_n) rg.mx[o] = x_new;
+            sh.L[c] = L_new;
+            if (cool) sh.na[c * 7 + type - 1] += 1;
+        }
+        sh.L4[par][c] = L_post;
+        lds_st(&sh.done[c], key);
+    }
+    // ---- a rejected prior: this step was one draw shorter than the hop tables assume.  Everything after it starts
+    // ---- elsewhere: new epoch, anchored at the step after this one
+    if (__builtin_expect(ok == 0, 0)) {
+        const int e1 = W.epoch + 1;
+        if (lane == 0) {
+            lds_st(&sh.anch[e1 & 1], ((unsigned long long)(unsigned)(key + 1) << 32) | (unsigned)(p + cnt));
+            lds_st(&sh.epoch, e1);
+        }
+        bool stands = false;
+        // (this wave's own view: as any wave whose step stands before the anchor; a later rejection may already have moved on)
+        while (!flow_adopt(cs, sh, rg, W, lds_ld(&sh.epoch), iter, c, true, stands)) { }
+        flow_void_books(cs, sh, wave, NW, nc_, lane);
+    }
+    // ---- records of this step (hypo_tremor_mcmc.f90:270-280): slots by LDS atomics, put in order on the host
+    if (__builtin_expect(sh.c.slog_cap > 0, 0)) {
+        const int row = sh.c.slog_n + (iter - sh.i0 - 1) * nc_ + c;
+        if (lane == 0 && row < sh.c.slog_cap) {
+            int32_t *ir = cs.slog_i + 8 * (size_t)row;
+            double *dr = cs.slog_d + 4 * (size_t)row;
+            ir[0] = iter; ir[1] = c; ir[2] = type; ir[3] = idx + 1; ir[4] = ok; ir[5] = acc; ir[6] = need_full; ir[7] = 0;
+            dr[0] = x_new; dr[1] = L_new; dr[2] = L_post; dr[3] = T;
+        }
+    }
+    if (__builtin_expect(rec_now && cool, 0)) {
+        int sl = 0, ss = -1;
+        if (lane == 0) {
+            sl = atomicAdd(&sh.c.n_lik, 1);
+            if (iter > cs.n_burn) ss = atomicAdd(&sh.c.n_smp, 1);
+        }
+        sl = __builtin_amdgcn_readfirstlane(sl); ss = __builtin_amdgcn_readfirstlane(ss);
+        if (lane == 0 && sl < cs.cap_lik) { cs.lik_iter[sl] = iter; cs.lik_chain[sl] = c; cs.lik_val[sl] = L_post; }
+        if (ss >= 0 && ss < cs.cap_smp) {
+            const int S = cs.S, rec = nh + 2 * S + 2;
+            double *dst = cs.smp_data + (size_t)ss * rec;
+            const double *hxp = cs.xall + off_hy + (size_t)c * nh;
+            const int vz = opaque_zero();
+            for (int k = lane; k < nh; k += 64) dst[k] = ld_state(hxp + k, vz);
+            for (int k = lane; k < S; k += 64) {
+                dst[nh + k] = ld_state(cs.xall + off_tc + (size_t)c * S + k, vz);
+                dst[nh + S + k] = ld_state(cs.xall + off_ac + (size_t)c * S + k, vz);
+            }
+            if (lane == 0) {
+                dst[nh + 2 * S] = ld_state(cs.xall + c, vz);
+                dst[nh + 2 * S + 1] = ld_state(cs.xall + off_qs + c, vz);
+                cs.smp_iter[ss] = iter; cs.smp_chain[ss] = c;
+            }
+        }
+    }
+    // ---- orders of this chain's coming full evaluations (what role P does for all chains in step_body): the next step's
+    // ---- if it needs one (one step ahead), else -- that step being a hypocentre step -- the one after it (two steps ahead:
+    // ---- the workers leave the event of the step in between out, this wave adds it).  Positions are predictions; a step
+    // ---- uses an order only if it starts exactly where the order was written for, and an epoch change voids the book.
+    if (rg.mir_n > 0 && sh.ob_pos[c] == -1 && iter + 1 <= sh.c.iter_target) {
+        const int lim = sh.fill - 8;
+        // this chain's next step is its step of the next iteration (this wave's other chains of this iteration come first)
+        const int p1 = (W.rpos1 >= 0 && c >= W.rc1) ? hop_ahead(rg, W.rpos1, c - W.rc1) : -1;
+        const bool w1 = p1 >= 0 && p1 < lim;
+        const i32x4 d1 = reinterpret_cast<const i32x4 *>(rg.dec)[(w1 ? p1 : 0) & M];
+        const bool job1 = w1 && d1.x >= 1 && d1.x <= 4;
+        int mode = job1 ? 1 : 0;
+        int pj = p1;
+        int jt = d1.x, ji = d1.y;
+        if (HTM_ALLOW2 && NCH > 0 && w1 && !job1 && iter + 2 <= sh.c.iter_target && W.B2 >= 0) {
+            const int p2 = hop_ahead(rg, W.B2, c);
+            if (p2 < lim) {
+                const i32x4 d2 = reinterpret_cast<const i32x4 *>(rg.dec)[p2 & M];
+                if (d2.x >= 1 && d2.x <= 4) { mode = 2; pj = p2; jt = d2.x; ji = d2.y; }
+            }
+        }
+        if (mode) {
+            const int jgoff = jt == 1 ? 0 : jt == 2 ? nc_ : jt == 3 ? nc_ + nc_ * S_ : 2 * nc_ + nc_ * S_;
+            const int jo = jgoff + c * ((jt == 1 || jt == 3) ? 1 : S_) + ji;
+            const double jx_old = rg.mx[jo];                                  // LDS mirror, kept current by this wave's commits
+            const double jstep = rg.mir_steps ? rg.mstep[jo] : ld_const(cs.stall + jo);
+            const double jx_new = jx_old + rg.pg[pj & M] * jstep;             // cls_model.f90:172, as the step will compute it
+            if (cs.rayleigh14) {                                              // a Rayleigh prior among vs/qs/corrections (:178-187)
+                if (ld_const(cs.ptall + jo) == 1 && jx_new <= ld_const(cs.muall + jo)) mode = 0;      // prior rejects: no evaluation
+            }
+            // two ahead: the workers wait for this step's commit by reading its value back; the step in between must not
+            // be able to overwrite that very element before they look
+            const int o_mid = off_hy + c * nh + d1.y;
+            if (mode == 2 && acc && o == o_mid) mode = 0;
+            if (mode) {
+                unsigned long long tk = 0;
+                if (lane == 0) {
+                    tk = (atomicAdd(&sh.c.jobs_total, 1ull) + 1ull) & 0x7fffffffull;
+                    if (tk == 0) tk = 0x7fffffffull;
+                    sh.ob_pos[c] = pj; sh.ob_tag[c] = (unsigned)tk; sh.ob_mode[c] = mode; sh.ob_mid[c] = d1.x | (d1.z << 3);
+                }
+                const unsigned tag = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)tk);
+                if (lane < cs.slot_rep * kGranPerSlot) {
+                    const int gi = lane & 7;
+                    const unsigned long long xb = (unsigned long long)__double_as_longlong(jx_new);
+                    const unsigned long long cb = (unsigned long long)__double_as_longlong(x_new);
+                    const unsigned pay = gi == 0 ? (unsigned)launch : gi == 1 ? ((unsigned)jt | ((unsigned)ji << 3))
+                                       : gi == 2 ? (unsigned)(xb >> 32) : gi == 3 ? (unsigned)xb
+                                       : gi == 4 ? (acc ? (unsigned)o : 0xffffffffu)              // the commit the workers must see
+                                       : gi == 5 ? (unsigned)(cb >> 32) : gi == 6 ? (unsigned)cb
+                                       : (mode == 2 ? (unsigned)o_mid + 1u : 0u);                  // element of the step in between (+1; 0 = none)
+                    st_gran(cs.slots + (size_t)(lane >> 3) * cs.slot_stride + c * kGranPerSlot + gi, tag, pay);
+                }
+            }
+        }
+    }
+    return p + cnt;
+}
+
+// block 0 of a k_mcmc<NCH, F32, 0> launch when the host selects the free-running master (htm_hip.hip: flow_ok)
+template <int NCH, bool F32>
+__device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, int ring_size, int wmax, unsigned long long launch)
+{
+    CsRef cs = rebase(cs_);
+    FwRef f = rebase(f_);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    FlowShared &sh = *reinterpret_cast<FlowShared *>(smem);
+    char *carve = smem + ((sizeof(FlowShared) + 15) & ~size_t(15));
+    Ring rg;
+    rg.mask = ring_size - 1;
+    rg.U = reinterpret_cast<double *>(carve);          carve += sizeof(double) * ring_size;
+    rg.LOGU = reinterpret_cast<double *>(carve);       carve += sizeof(double) * ring_size;
+    rg.pg = reinterpret_cast<double *>(carve);         carve += sizeof(double) * ring_size;
+    rg.pr = reinterpret_cast<double *>(carve);         carve += sizeof(double) * ring_size;
+    rg.plogr = reinterpret_cast<double *>(carve);      carve += sizeof(double) * ring_size;
+    rg.dec = reinterpret_cast<int4 *>(carve);          carve += sizeof(int4) * ring_size;
+    rg.sw = reinterpret_cast<int4 *>(carve);           carve += sizeof(int4) * ring_size;
+    rg.hop = reinterpret_cast<int *>(carve);           carve += sizeof(int) * kHops * ring_size;
+    double *s_sx = reinterpret_cast<double *>(carve);
+    double *s_sy = s_sx + f.S;
+    double *s_sz = s_sy + f.S;
+    double *s_gath = s_sz + f.S;
+    rg.mir_n = cs.mirror_n;
+    rg.mx = s_gath + kGathStage;
+    rg.mstep = rg.mx + rg.mir_n;
+    rg.mir_steps = cs.mirror_steps != 0;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NW = blockDim.x >> 6;
+    const int nc = cs.n_chains;
+    {
+        const int vz0 = opaque_zero();
+        constexpr int kCtrlWords = (int)(sizeof(Ctrl) / sizeof(int));
+        if (tid < kCtrlWords) reinterpret_cast<int *>(&sh.c)[tid] = reinterpret_cast<const int *>(cs.ctrl)[tid + vz0];
+        if (tid == kCtrlWords) sh.hop_end = cs.stream.hop_end[vz0];
+    }
+    for (int j = tid; j < f.S; j += blockDim.x) { s_sx[j] = f.sx[j]; s_sy[j] = f.sy[j]; s_sz[j] = f.sz[j]; }
+    for (int k = tid; k < 7 * nc; k += blockDim.x) { sh.np[k] = 0; sh.na[k] = 0; }
+    for (int k = tid; k < rg.mir_n; k += blockDim.x) { rg.mx[k] = cs.xall[k]; if (rg.mir_steps) rg.mstep[k] = cs.stall[k]; }
+    __syncthreads();
+    if (tid == 0) {
+        if (target_arg >= 0) sh.c.iter_target = target_arg;
+        sh.origin = sh.c.spos;
+        const long long av = sh.hop_end - sh.c.spos;
+        sh.avail = av > (1 << 30) ? (1 << 30) : (int)av;
+        sh.fill = 0; sh.base = 0;
+        sh.epoch = 0; sh.anch[0] = 0ull; sh.anch[1] = 0ull;
+        sh.i0 = sh.c.iter_done; sh.last_iter = sh.c.iter_target; sh.stop_code = 0;
+        sh.n_full_w = 0ull; sh.n_part_w = 0ull;
+    }
+    __syncthreads();
+    const int i0 = sh.i0;
+    for (int c = tid; c < kMaxChains; c += blockDim.x) {
+        sh.ob_pos[c] = -1;
+        sh.prog[c] = (unsigned long long)(unsigned)c;          // key(i0, c), epoch 0, prior ok
+        sh.done[c] = c;
+        if (c < nc) {
+            const double T = cs.temp[c], L = cs.L[c];
+            sh.L[c] = L;
+            sh.T4[(i0 + 1) & 3][c] = T; sh.T4[i0 & 3][c] = T; sh.L4[i0 & 3][c] = L;
+            sh.rT4[(i0 + 1) & 3][c] = 1.0 / T; sh.rT4[i0 & 3][c] = 1.0 / T;
+        }
+    }
+    if (sh.c.iter_done >= sh.c.iter_target || sh.c.stop || sh.c.err) return;      // (uniform)
+    if (sh.avail < 3 * wmax) {                                 // the produced stream does not cover a safe stretch: the host refills
+        __syncthreads();
+        if (tid == 0) { sh.c.stop = 2; *cs.ctrl = sh.c; }
+        return;
+    }
+    // the draws an iteration can take: 6 per chain step + select_pair's and judge_swap's
+    const int wd = 6 * nc + 16;
+    const int look = 3 * wd + 24, back = wd + 8;
+    prefetch_all(cs, sh, rg, min(look, ring_size - back));       // ends with a barrier
+    const int n_int = cs.n_interval;
+    int rec_phase = (i0 + 1) % n_int;                            // iteration % n_interval, kept by increments
+
+    FlowWave W;
+    W.epoch = 0; W.akey = 0; W.rc = 0; W.rpos = 0;
+    W.rc1 = 0; W.rpos1 = flow_next_base(cs, sh, rg, 0, nc, sh.fill);
+    W.B2 = flow_next_base(cs, sh, rg, W.rpos1, nc, sh.fill);
+    int iter = i0 + 1;
+    int c = wave;
+    bool alive = wave < nc;
+    while (alive) {
+        // ---- top of a step: the epoch its position is predicted in
+        {
+            const int e = lds_ld(&sh.epoch);
+            if (__builtin_expect(e != W.epoch, 0)) {
+                bool stands = false;
+                if (!flow_adopt(cs, sh, rg, W, e, iter, c, false, stands)) continue;
+                flow_void_books(cs, sh, wave, NW, nc, lane);
+            }
+        }
+        if (iter > lds_ld(&sh.last_iter) || sh.c.err != 0) break;
+        if (__builtin_expect(W.rpos1 < 0 || W.B2 < 0, 0)) {      // predictions the window did not cover when they were made
+            if (W.rpos1 < 0) { W.rpos1 = flow_next_base(cs, sh, rg, W.rpos, nc - W.rc, sh.fill); W.rc1 = 0; }
+            if (W.B2 < 0 && W.rpos1 >= 0) W.B2 = flow_next_base(cs, sh, rg, W.rpos1, nc - W.rc1, sh.fill);
+        }
+        const int p = hop_ahead(rg, W.rpos, c - W.rc);
+        if (wave == 0 && c == 0 && lane == 0) {
+            // chain 0's wave decides where the launch ends: record buffers or produced stream nearly used up.  Everybody
+            // learns it before committing a step of this iteration (its turn waits for chain 0's check)
+            int code = 0;
+            if (sh.c.n_lik + 3 * nc > cs.cap_lik || sh.c.n_smp + 3 * nc > cs.cap_smp) code = 1;
+            else if (sh.avail < p + 3 * wd + 32) code = 2;
+            if (code && lds_ld(&sh.last_iter) > iter) { sh.stop_code = code; lds_st(&sh.last_iter, iter); }
+        }
+        // the window covers this step (chain 0's wave keeps it 3 iterations ahead); a fail-stop, never expected to wait
+        if (__builtin_expect(p + 16 >= lds_ld(&sh.fill), 0)) {
+            if (wave == 0) { if (lane == 0) sh.c.err = -13; break; }
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            bool dead = false;
+            while (p + 16 >= lds_ld(&sh.fill)) {
+                if (sh.c.err != 0 || __builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) { dead = true; break; }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (dead) { if (lane == 0 && sh.c.err == 0) sh.c.err = -13; break; }
+        }
+        const int r = flow_step<NCH, F32>(f, cs, sh, rg, W, s_sx, s_sy, s_sz, c, p, iter, lane, wave, NW, launch, wave == 0,
+                                          look, back, rec_phase == 1);
+        if (r == kFlowRestart) continue;
+        if (r == kFlowAbort) break;
+        // ---- this wave's next step
+        c += NW;
+        if (c >= nc) {
+            c = wave;
+            iter += 1;
+            rec_phase = rec_phase + 1 == n_int ? 0 : rec_phase + 1;
+            if (W.rpos1 < 0) {    // (the window did not cover the prediction when it was made: it does now)
+                W.rpos1 = flow_next_base(cs, sh, rg, W.rpos, nc - W.rc, 1 << 30); W.rc1 = 0;
+                W.B2 = -1;
+            }
+            W.rc = W.rc1; W.rpos = W.rpos1;
+            W.rc1 = 0; W.rpos1 = W.B2 >= 0 ? W.B2 : flow_next_base(cs, sh, rg, W.rpos, nc - W.rc, sh.fill);
+            W.B2 = flow_next_base(cs, sh, rg, W.rpos1, nc, sh.fill);
+        }
+    }
+    __syncthreads();
+    // ---- every step up to last_iter is committed: the swap of the last iteration, counters, the launch's end state
+    if (tid == 0 && sh.c.err == 0) {
+        const int last = min(sh.last_iter, sh.c.iter_target);
+        if (last > i0) {
+            const int par = last & 3;
+            const int E = sh.Eof[par], i1 = sh.sw_i1[par], i2 = sh.sw_i2[par], nd = sh.sw_nd[par];
+            if (cs.n_procs * nc > 1) {
+                const double sr = sh.sw_r[par], slr = sh.sw_logr[par];
+                const double T1 = sh.T4[par][i1], T2 = sh.T4[par][i2];
+                const double del_s = (sh.L4[par][i2] - sh.L4[par][i1]) * (sh.rT4[par][i1] - sh.rT4[par][i2]);
+                if (sr >= kEps && slr <= del_s) { sh.T4[par][i1] = T2; sh.T4[par][i2] = T1; }
+                sh.c.swap_i1 = i1; sh.c.swap_i2 = i2; sh.c.swap_r = sr; sh.c.swap_logr = slr;
+            }
+            for (int k = 0; k < nc; ++k) { cs.temp[k] = sh.T4[last & 3][k]; cs.L[k] = sh.L[k]; }
+            sh.c.spos = sh.origin + E + nd;
+            sh.c.iter_done = last;
+            sh.c.stage = ST_IDLE;
+            if (sh.c.slog_cap > 0) sh.c.slog_n = min(sh.c.slog_cap, sh.c.slog_n + (last - i0) * nc);
+            sh.c.n_full_evals += (long long)sh.n_full_w;
+            sh.c.n_partial_evals += (long long)sh.n_part_w;
+            if (last < sh.c.iter_target) sh.c.stop = sh.stop_code;
+        }
+    }
+    __syncthreads();
+    for (int k = tid; k < 7 * nc; k += blockDim.x) {          // flush this launch's counters
+        if (sh.np[k]) atomicAdd(&cs.n_propose[k], sh.np[k]);
+        if (sh.na[k]) atomicAdd(&cs.n_accept[k], sh.na[k]);
+    }
+    if (tid == 0) *cs.ctrl = sh.c;
+}
+
+// One launch = the chain master (block 0) + W full-evaluation workers (blocks 1..W), all resident.
+// `launch` = the host's count of k_mcmc launches of this chain set (1, 2, ...): orders and the quit word carry it, so
+// nothing a previous launch left in memory can be mistaken for this launch's.
+template <int NCH, bool F32 = false, int MK = 0>
+__global__ __launch_bounds__(512) void k_mcmc(FwdDev f, ChainsDev cs, int mode, int target_arg,
+                                               const double *gathered, int ring_size, int wmax,
+                                               unsigned long long launch)
+{
+    const KArgLayout __attribute__((address_space(4))) &ka = *(const KArgLayout __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+    if (blockIdx.x == 0) {
+        // MK 3: the single-rank loop on the free-running master (flow_body); 0: the same loop with barriers (step_body)
+        if constexpr (MK == 3) flow_body<NCH, F32>(ka.f, ka.cs, target_arg, ring_size, wmax, launch);
+        else step_body<NCH, true, F32, MK>(ka.f, ka.cs, mode, target_arg, gathered, ring_size, wmax, launch);
+        // every exit of the master comes through here (its returns are uniform over the block): release the workers
+        __syncthreads();
+        if (threadIdx.x == 0) st_agent(&ka.cs.ps->quit, launch + 1ull);
+    } else {
+        worker_body<NCH, F32>(ka.f, ka.cs, launch);
+    }
+}
+
+}  // namespace htm

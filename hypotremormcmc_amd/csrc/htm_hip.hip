@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "htm_kernels.hpp"
+#include "htm_flow.hpp"
 #include "htm_select.hpp"
 
 using namespace htm;
@@ -166,6 +167,7 @@ struct htm_chains {
     double *d_gath_host = nullptr, *h_gath_pinned = nullptr;   // staging buffers of htm_chains_step_end_host
     unsigned long long launch_seq = 0;         // k_mcmc launches of this chain set so far (the kernels' launch index)
     bool persist = true;                       // k_mcmc (master + resident full-evaluation workers) vs k_step + k_full
+    bool flow = false;                         // single-rank loop on the free-running master (htm_flow.hpp) instead of step_body
     ChainsDev dev_np{};                        // view for the non-persistent kernels (partial sums per k_full tile)
     uint32_t init_state[4] = {0, 0, 0, 0};     // mod_random state at stream position 0
     // in-kernel exchange of the swap records (persistent lock-step): this rank's inbox, the peers' inboxes as mapped here
@@ -232,7 +234,8 @@ int launch_mcmc(htm_chains *hc, int mode, int target, const double *gathered)
         else HTM_LAUNCH_MCMC(0, false, K);                                                                 \
     } while (0)
     // one instantiation per main loop: the single-rank loop, one lock-step iteration per launch, persistent lock-step
-    if (mode == MODE_RUN) HTM_LAUNCH_MCMC_K(0);
+    if (mode == MODE_RUN && hc->flow) HTM_LAUNCH_MCMC_K(3);
+    else if (mode == MODE_RUN) HTM_LAUNCH_MCMC_K(0);
     else if (mode == MODE_LOCKRUN) HTM_LAUNCH_MCMC_K(2);
     else HTM_LAUNCH_MCMC_K(1);
 #undef HTM_LAUNCH_MCMC_K
@@ -834,7 +837,7 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
     // iterations ahead), else one -- and the mirror of (vs, t_corr, qs, a_corr) x all chains + their step sizes that
     // role P reads (without it no orders are sent ahead).  Per ring position: U, LOGU, pg, pr, plogr (5 doubles), dec,
     // sw (int4), hop (kHops ints).
-    const size_t lds_fixed = ((sizeof(StepShared) + 15) & ~size_t(15)) + 3 * (size_t)h->S * sizeof(double) + kGathStage * sizeof(double);
+    const size_t lds_fixed = ((sizeof(FlowShared) + 15) & ~size_t(15)) + 3 * (size_t)h->S * sizeof(double) + kGathStage * sizeof(double);
     const size_t lds_pos = 5 * sizeof(double) + 2 * sizeof(int4) + kHops * sizeof(int);
     const size_t mir = 2 * (size_t)nc + 2 * (size_t)nc * h->S;
     const size_t lds_cap = 156 * 1024;
@@ -871,13 +874,17 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
         // block carries the master's LDS size).  Workers take events round-robin, so fewer of them only take longer.
 #define HTM_MCMC_FN(K) (h->dev.fp32 ? (h->nch == 1 ? (const void *)k_mcmc<1, true, K> : (const void *)k_mcmc<2, true, K>)                  \
                         : h->nch == 1 ? (const void *)k_mcmc<1, false, K> : h->nch == 2 ? (const void *)k_mcmc<2, false, K> : (const void *)k_mcmc<0, false, K>)
-        const void *fns[3] = {HTM_MCMC_FN(0), HTM_MCMC_FN(1), HTM_MCMC_FN(2)};
+        const void *fns[4] = {HTM_MCMC_FN(0), HTM_MCMC_FN(1), HTM_MCMC_FN(2), HTM_MCMC_FN(3)};
 #undef HTM_MCMC_FN
-        const void *fn = fns[0];
         if (hc->step_smem > 48 * 1024)
             for (const void *g : fns) HIPCHK(hipFuncSetAttribute(g, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hc->step_smem));
-        int per_cu = 0, n_cu = 0;
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 512, hc->step_smem));
+        // the residency bound holds for whichever main loop gets launched: the smallest of the instantiations' occupancies
+        int per_cu = 1 << 20, n_cu = 0;
+        for (const void *g : fns) {
+            int pc = 0;
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, g, 512, hc->step_smem));
+            per_cu = std::min(per_cu, pc);
+        }
         HIPCHK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
         long room = (long)per_cu * n_cu - 1;
         // Several ranks on one GPU (more masters instead of more rounds per master: 4 ranks x 8 chains run 2.7 M steps/s where one
@@ -887,6 +894,16 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
         else hc->dev.n_workers = (int)std::min<long>(hc->dev.n_workers, room);
     }
     hc->dev.n_wg = hc->dev.n_workers;           // persistent kernel: one partial per worker block
+    {
+        // The free-running master (htm_flow.hpp) runs the single-rank loop when its stream window fits: three iterations of
+        // look-ahead + one behind + the spread of chain 0's wave over its chains (flow_step's window extension), and the LDS
+        // mirror the orders are computed from.  HTM_FLOW=0 keeps the loop with barriers (step_body); so do the hand-off tests'
+        // debug switches.
+        const char *e = getenv("HTM_FLOW");
+        const int wd = 6 * nc + 16, c_max = 8 * ((nc - 1) / 8);
+        hc->flow = hc->persist && d.n_procs == 1 && !(e && e[0] == '0') && d.dbg == 0 && hc->dev.mirror_n > 0 &&
+                   hc->ring_size >= 4 * wd + 32 + 2 * c_max + 16;
+    }
     // first stretch of the random stream (synchronous)
     if ((rc = stream_produce(hc, 1 << 16))) return cleanup(rc);
     HIPCHK(hipStreamSynchronize(hc->side));
@@ -1023,6 +1040,35 @@ static int drain_records(htm_chains *hc)
         HIPCHK(hipMemcpy(hc->smp_chain.data() + o, d.smp_chain, ns * sizeof(int32_t), hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(hc->smp_data.data() + o * hc->rec_len, d.smp_data, (size_t)ns * hc->rec_len * sizeof(double),
                          hipMemcpyDeviceToHost));
+    }
+    if (hc->flow) {
+        // the free-running master hands out record slots as its waves get to them: put the drained records into the
+        // reference's order, iteration by iteration and chain by chain (hypo_tremor_mcmc.f90:270-280)
+        auto order = [](size_t n, const int32_t *it, const int32_t *ch) {
+            std::vector<size_t> idx(n);
+            for (size_t k = 0; k < n; ++k) idx[k] = k;
+            std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return it[a] != it[b] ? it[a] < it[b] : ch[a] < ch[b]; });
+            return idx;
+        };
+        if (nl > 1) {
+            const size_t o = hc->lik_iter.size() - nl;
+            const std::vector<size_t> idx = order(nl, hc->lik_iter.data() + o, hc->lik_chain.data() + o);
+            std::vector<int32_t> it(nl), ch(nl); std::vector<double> v(nl);
+            for (int k = 0; k < nl; ++k) { it[k] = hc->lik_iter[o + idx[k]]; ch[k] = hc->lik_chain[o + idx[k]]; v[k] = hc->lik_val[o + idx[k]]; }
+            std::copy(it.begin(), it.end(), hc->lik_iter.begin() + o); std::copy(ch.begin(), ch.end(), hc->lik_chain.begin() + o);
+            std::copy(v.begin(), v.end(), hc->lik_val.begin() + o);
+        }
+        if (ns > 1) {
+            const size_t o = hc->smp_iter.size() - ns, rl = hc->rec_len;
+            const std::vector<size_t> idx = order(ns, hc->smp_iter.data() + o, hc->smp_chain.data() + o);
+            std::vector<int32_t> it(ns), ch(ns); std::vector<double> v((size_t)ns * rl);
+            for (int k = 0; k < ns; ++k) {
+                it[k] = hc->smp_iter[o + idx[k]]; ch[k] = hc->smp_chain[o + idx[k]];
+                std::copy(hc->smp_data.begin() + (o + idx[k]) * rl, hc->smp_data.begin() + (o + idx[k] + 1) * rl, v.begin() + (size_t)k * rl);
+            }
+            std::copy(it.begin(), it.end(), hc->smp_iter.begin() + o); std::copy(ch.begin(), ch.end(), hc->smp_chain.begin() + o);
+            std::copy(v.begin(), v.end(), hc->smp_data.begin() + o * rl);
+        }
     }
     if (nl > 0 || ns > 0 || hc->h_ctrl.stop) {   // stop: 1 = record buffers full, 2 = stream underrun
         hc->h_ctrl.n_lik = 0; hc->h_ctrl.n_smp = 0; hc->h_ctrl.stop = 0;
