@@ -65,6 +65,15 @@ struct FlowWave {                 // a wave's predictions (wave-uniform)
     int B2;                       // base of the iteration after that (orders sent ahead only); -1 = not known
 };
 
+#ifdef HTM_STAMPS
+// diagnostic cycle accounting of the free-running master (tools/flow_stamps.py): per wave, [k] ticks of phase k summed over its
+// partial-update steps (0 front: loads issued, 1 proposal + check published, 2 evaluation, 3 turn, 4 swap + decision + commit,
+// 5 records + orders), 6 ticks of its full-evaluation steps, 7 / 8 the two counts, 9 ticks between steps (loop top), 10 wait part of 6
+#define FSTAMP(k) do { if (lane == 0 && cs.stamps) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_acc[k] += n_ - t_last; t_last = n_; } } while (0)
+#else
+#define FSTAMP(k) do { } while (0)
+#endif
+
 constexpr int kFlowRestart = -1;  // flow_step: the step's position was disproved before its turn came: run it again
 constexpr int kFlowAbort = -2;    // flow_step: a wait gave up (sh.c.err is set)
 
@@ -174,6 +183,11 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
     FwRef f = rebase(f_);
     const int M = rg.mask;
     p = __builtin_amdgcn_readfirstlane(p);
+#ifdef HTM_STAMPS
+    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long t_last = __builtin_amdgcn_s_memtime(), t_wait = 0;
+    const unsigned long long t_step0 = t_last;
+#endif
     // ---- the LDS window of the stream rings, one round per step of chain 0's wave: requested first, stored behind the
     // ---- step's own loads (which return after it: vector-memory operations complete in order)
     PfRegs pf;
@@ -237,6 +251,7 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
             load_obs_regs<NCH, F32>(ob, f, d_e, lane);
         }
     }
+    FSTAMP(0);
     const double x_old = rl_f64(gathered_v, 0);
     const double hx = rl_f64(gathered_v, 1), hy = rl_f64(gathered_v, 2), hz = rl_f64(gathered_v, 3);
     const double beta = rl_f64(gathered_v, 4), q = rl_f64(gathered_v, 5);
@@ -271,6 +286,7 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
         if (lane == 0) lds_st(&sh.fill, fill_to);
     }
 
+    FSTAMP(1);
     double L_new = 0.0;
     int need_full = 0;
     if (__builtin_expect(ok != 0, 1)) {
@@ -352,6 +368,9 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
             }
             bool have = false;
             if (early) have = complete(0);
+#ifdef HTM_STAMPS
+            const unsigned long long tw0_ = __builtin_amdgcn_s_memtime();
+#endif
             if (!have) {
                 issue(0);
                 for (;;) {
@@ -371,6 +390,9 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
                     }
                 }
             }
+#ifdef HTM_STAMPS
+            t_wait = __builtin_amdgcn_s_memtime() - tw0_;
+#endif
 #pragma unroll
             for (int j = 0; j < kSweep; ++j)            // fixed order: worker lane, lane + 64, ...
                 if (j * 64 < cs.n_wg)
@@ -378,6 +400,7 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
             L_new = -wave_sum1(part + own_lane) - f.const_sum;       // cls_forward.f90:277-300
         }
     }
+    FSTAMP(2);
 
     // ---- the step's turn: every step before it in stream order has passed its check in this epoch (or lies before the
     // ---- epoch's anchor: checked earlier, final).  Lanes <-> chains.
@@ -407,6 +430,7 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
             __builtin_amdgcn_s_sleep(1);
         }
     }
+    FSTAMP(3);
     // ---- the temperature of this iteration: the swap of the iteration before (cls_parallel.f90:121-136, :285-302), decided
     // ---- here by the waves of the two chains it concerns -- each evaluates the same expression on the same values
     const int par = iter & 3, ppar = (iter - 1) & 3;
@@ -453,6 +477,7 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
         sh.L4[par][c] = L_post;
         lds_st(&sh.done[c], key);
     }
+    FSTAMP(4);
     // ---- a rejected prior: this step was one draw shorter than the hop tables assume.  Everything after it starts
     // ---- elsewhere: new epoch, anchored at the step after this one
     if (__builtin_expect(ok == 0, 0)) {
@@ -557,6 +582,14 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
             }
         }
     }
+#ifdef HTM_STAMPS
+    FSTAMP(5);
+    if (lane == 0 && cs.stamps) {
+        unsigned long long *a = sh.stamp_acc + 12 * (wave & 7);
+        if (need_full) { a[6] += t_last - t_step0; a[8] += 1; a[10] += t_wait; }
+        else { for (int k = 0; k < 6; ++k) a[k] += st_acc[k]; a[7] += 1; }
+    }
+#endif
     return p + cnt;
 }
 
@@ -600,6 +633,9 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
     }
     for (int j = tid; j < f.S; j += blockDim.x) { s_sx[j] = f.sx[j]; s_sy[j] = f.sy[j]; s_sz[j] = f.sz[j]; }
     for (int k = tid; k < 7 * nc; k += blockDim.x) { sh.np[k] = 0; sh.na[k] = 0; }
+#ifdef HTM_STAMPS
+    for (int k = tid; k < 96; k += blockDim.x) sh.stamp_acc[k] = 0ull;
+#endif
     for (int k = tid; k < rg.mir_n; k += blockDim.x) { rg.mx[k] = cs.xall[k]; if (rg.mir_steps) rg.mstep[k] = cs.stall[k]; }
     __syncthreads();
     if (tid == 0) {
@@ -645,6 +681,9 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
     int iter = i0 + 1;
     int c = wave;
     bool alive = wave < nc;
+#ifdef HTM_STAMPS
+    const unsigned long long t_loop0 = __builtin_amdgcn_s_memtime();
+#endif
     while (alive) {
         // ---- top of a step: the epoch its position is predicted in
         {
@@ -699,7 +738,14 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
             W.B2 = flow_next_base(cs, sh, rg, W.rpos1, nc, sh.fill);
         }
     }
+#ifdef HTM_STAMPS
+    if (lane == 0 && cs.stamps && wave < 8) sh.stamp_acc[12 * wave + 11] += __builtin_amdgcn_s_memtime() - t_loop0;
+#endif
     __syncthreads();
+#ifdef HTM_STAMPS
+    if (cs.stamps)
+        for (int k = tid; k < 96; k += blockDim.x) if (sh.stamp_acc[k]) atomicAdd(&cs.stamps[k], sh.stamp_acc[k]);
+#endif
     // ---- every step up to last_iter is committed: the swap of the last iteration, counters, the launch's end state
     if (tid == 0 && sh.c.err == 0) {
         const int last = min(sh.last_iter, sh.c.iter_target);
