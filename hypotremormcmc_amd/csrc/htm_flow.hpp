@@ -169,27 +169,135 @@ __device__ __forceinline__ bool flow_adopt(CsRef cs_, FlowShared &sh, const Ring
     return true;
 }
 
-// One chain step from its front to its commit and the orders of the chain's coming full evaluations (the free-running
-// counterpart of chain_pass).  All 64 lanes execute with identical (uniform) values; lane <-> station only inside
-// event_misfit.  `ext`: this wave keeps the LDS window of the stream ahead (chain 0's wave, one round of <= 64 positions
-// per step, in flight under the step's own loads).  Returns the stream position after the step, kFlowRestart or kFlowAbort.
+// The inputs of one chain step, REQUESTED ONE STEP AHEAD: where a wave's next step starts and what it proposes is in the
+// stream window long before the step runs, so everything the step reads from memory -- the element it perturbs and the
+// event's coordinates (gA: lane 0, lanes 1..3), prior mean, 1 / (2 sigma^2), step size and the event's reciprocal precision
+// sums (gB: lanes 0..4), the prior type, the event's four observation rows and the chain's station corrections -- is
+// requested with vector loads while the step before it is evaluated (the kernel has the registers: 150 of 256), and the
+// step itself starts with its arithmetic.  What the step in between commits to the same chain is patched into the
+// registers (flow_patch); vs, qs and the elements of the full-evaluation types come from the LDS mirror at use.
+template <int N>
+struct StepIn {
+    int it, c, p, epoch;          // which step, its predicted start, the epoch of the prediction; p < 0: nothing requested
+    int type, idx, evt, dec_w;    // the decoded proposal (htm_stream.hpp)
+    double g, r, logr;            // its Gaussian, its Metropolis draw and log
+    double gA, gB;
+    int pt;
+    double tob[N], tpr[N], aob[N], apr[N], tc[N], ac[N];
+};
+
 template <int NCH, bool F32>
-__device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, const Ring &rg, FlowWave &W,
-                                         const double *s_sx, const double *s_sy, const double *s_sz, int c, int p, int iter,
-                                         int lane, int wave, int NW, unsigned long long launch, bool ext, int look, int back,
-                                         bool rec_now)
+__device__ __forceinline__ void flow_request(FwRef f_, CsRef cs_, const Ring &rg, const FlowWave &W, StepIn<(NCH > 0 ? NCH : 1)> &n,
+                                             int it, int c, int p, int lane)
 {
     CsRef cs = rebase(cs_);
     FwRef f = rebase(f_);
     const int M = rg.mask;
-    p = __builtin_amdgcn_readfirstlane(p);
+    n.it = it; n.c = c; n.p = p; n.epoch = W.epoch;
+    const double *xall_ = cs.xall, *muall_ = cs.muall, *rs2all_ = cs.rs2all, *stall_ = cs.stall;
+    const int *ptall_ = cs.ptall;
+    const int nc_ = cs.n_chains, S_ = cs.S, nh = 3 * cs.E;
+    const i32x4 dec = reinterpret_cast<const i32x4 *>(rg.dec)[p & M];
+    asm volatile("" : "+s"(xall_), "+s"(muall_), "+s"(rs2all_), "+s"(stall_), "+s"(ptall_));
+    const int type = __builtin_amdgcn_readfirstlane(dec.x), idx = __builtin_amdgcn_readfirstlane(dec.y);
+    const int evt = __builtin_amdgcn_readfirstlane(dec.z);
+    n.type = type; n.idx = idx; n.evt = evt; n.dec_w = __builtin_amdgcn_readfirstlane(dec.w);
+    n.g = rg.pg[p & M]; n.r = rg.pr[p & M]; n.logr = rg.plogr[p & M];
+    const bool partial = evt > 0 && it > 1;       // hypo_tremor_mcmc.f90:246
+    const int off_tc = nc_, off_qs = nc_ + nc_ * S_, off_ac = 2 * nc_ + nc_ * S_, off_hy = 2 * nc_ + 2 * nc_ * S_;
+    const int goff = type == 1 ? 0 : type == 2 ? off_tc : type == 3 ? off_qs : type == 4 ? off_ac : off_hy;
+    const int gnx = (type == 1 || type == 3) ? 1 : (type == 2 || type == 4) ? S_ : nh;
+    const int o = goff + c * gnx + idx;
+    const int ev = evt > 0 ? evt - 1 : 0;
+    const int o_h = off_hy + c * nh + 3 * ev;
+    int ga = o;
+    ga = lane == 1 ? o_h : ga; ga = lane == 2 ? o_h + 1 : ga; ga = lane == 3 ? o_h + 2 : ga;
+    n.gA = xall_[ga];
+    const double *pb = muall_ + o;
+    pb = lane == 1 ? rs2all_ + o : pb; pb = lane == 2 ? stall_ + o : pb;
+    pb = lane == 3 ? f.rpsum_t + ev : pb; pb = lane == 4 ? f.rpsum_a + ev : pb;
+    n.gB = *pb;
+    n.pt = ptall_[o + opaque_zero()];             // (a vector load: scalar loads in flight would hold up every LDS wait)
+    if (partial) {
+        if constexpr (NCH > 0) {
+            const double *tc = xall_ + off_tc + c * S_, *ac = xall_ + off_ac + c * S_;
+            const size_t base = (size_t)ev * (size_t)f.S;
+            const bool ut = f.use_time != 0, ua = f.use_amp != 0;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                const int j = lane + 64 * k;
+                const bool valid = j < f.S;
+                n.tob[k] = n.tpr[k] = n.aob[k] = n.apr[k] = 0.0; n.tc[k] = 0.0; n.ac[k] = 0.0;
+                if (valid) {
+                    n.tc[k] = tc[j]; n.ac[k] = ac[j];
+                    if constexpr (F32) {
+                        if (ut) { n.tob[k] = (double)f.t_obs32[base + j]; n.tpr[k] = (double)f.t_prec32[base + j]; }
+                        if (ua) { n.aob[k] = (double)f.a_obs32[base + j]; n.apr[k] = (double)f.a_prec32[base + j]; }
+                    } else {
+                        if (ut) { n.tob[k] = f.t_obs[base + j]; n.tpr[k] = f.t_prec[base + j]; }
+                        if (ua) { n.aob[k] = f.a_obs[base + j]; n.apr[k] = f.a_prec[base + j]; }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// what the step that has just been committed (chain c, accepted, element o := x_new) changes in the inputs requested for
+// the wave's next step, if that is a step of the same chain
+template <int N>
+__device__ __forceinline__ void flow_patch(StepIn<N> &n, int c, int type, int idx, int evt, int o, double x_new, int lane,
+                                           int nc_, int S_, int nh)
+{
+    if (n.p < 0 || n.c != c) return;
+    if (type >= 5) {
+        if (n.type >= 5) {
+            const int off_hy = 2 * nc_ + 2 * nc_ * S_;
+            const int on = off_hy + c * nh + n.idx;
+            if (on == o && lane == 0) n.gA = x_new;
+            if (n.evt == evt && lane == 1 + (idx - 3 * (evt - 1))) n.gA = x_new;
+        }
+    } else if (type == 2 || type == 4) {
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+            if (lane + 64 * k == idx) { if (type == 2) n.tc[k] = x_new; else n.ac[k] = x_new; }
+    }
+}
+
+// the orders a chain may send ahead, looked up from positions alone while the step is evaluated; what depends on the
+// step's outcome is filled in after its commit (flow_step)
+struct PlanIn {
+    int mode, pj, jt, ji, jo, mid, o_mid, epoch;
+    double jx_old, jstep, jg;
+};
+
+// One chain step: its inputs were requested a step ago (cur); proposal, the request of the wave's NEXT step's inputs (nx),
+// evaluation, the step's turn, decision, commit, records and the orders of the chain's coming full evaluations (the
+// free-running counterpart of chain_pass).  All 64 lanes execute with identical (uniform) values; lane <-> station only inside
+// event_misfit.  `ext`: this wave keeps the LDS window of the stream ahead (chain 0's wave, one round of <= 64 positions
+// per step, in flight under the step's arithmetic).  Returns the stream position after the step, kFlowRestart or kFlowAbort.
+template <int NCH, bool F32>
+__device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, const Ring &rg, FlowWave &W,
+                                         const StepIn<(NCH > 0 ? NCH : 1)> &cur, StepIn<(NCH > 0 ? NCH : 1)> &nx,
+                                         const double (&rsx)[(NCH > 0 ? NCH : 1)], const double (&rsy)[(NCH > 0 ? NCH : 1)],
+                                         const double (&rsz)[(NCH > 0 ? NCH : 1)],
+                                         const double *s_sx, const double *s_sy, const double *s_sz,
+                                         int lane, int wave, int NW, unsigned long long launch, bool ext, int look, int back,
+                                         bool rec_now)
+{
+    constexpr int N = NCH > 0 ? NCH : 1;
+    CsRef cs = rebase(cs_);
+    FwRef f = rebase(f_);
+    const int M = rg.mask;
+    const int c = cur.c, iter = cur.it;
+    const int p = cur.p;
 #ifdef HTM_STAMPS
     unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long t_last = __builtin_amdgcn_s_memtime(), t_wait = 0;
     const unsigned long long t_step0 = t_last;
 #endif
     // ---- the LDS window of the stream rings, one round per step of chain 0's wave: requested first, stored behind the
-    // ---- step's own loads (which return after it: vector-memory operations complete in order)
+    // ---- step's arithmetic
     PfRegs pf;
     pf.p = -1;
     int fill_to = 0;
@@ -201,43 +309,25 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
         if (fill_to > fl + 64) fill_to = fl + 64;
         if (fill_to > fl) pf_load(pf, cs, sh, fl + lane, fill_to);
     }
-    const double *xall_ = cs.xall, *muall_ = cs.muall, *rs2all_ = cs.rs2all, *stall_ = cs.stall;
-    const int *ptall_ = cs.ptall;
     const int nc_ = cs.n_chains, S_ = cs.S, nh = 3 * cs.E;
-    const i32x4 dec = reinterpret_cast<const i32x4 *>(rg.dec)[p & M];      // decoded ahead of time (htm_stream.hpp)
-    asm volatile("" : "+s"(xall_), "+s"(muall_), "+s"(rs2all_), "+s"(stall_), "+s"(ptall_));
-    const int type = __builtin_amdgcn_readfirstlane(dec.x), idx = __builtin_amdgcn_readfirstlane(dec.y);
-    const int evt = __builtin_amdgcn_readfirstlane(dec.z), dec_w = __builtin_amdgcn_readfirstlane(dec.w);
-    const double g = rg.pg[p & M], r_ring = rg.pr[p & M], logr_ring = rg.plogr[p & M];
+    const int type = cur.type, idx = cur.idx, evt = cur.evt, dec_w = cur.dec_w;
+    const double g = cur.g, r_ring = cur.r, logr_ring = cur.logr;
     const bool partial = evt > 0 && iter > 1;       // hypo_tremor_mcmc.f90:246
     const int off_tc = nc_, off_qs = nc_ + nc_ * S_, off_ac = 2 * nc_ + nc_ * S_, off_hy = 2 * nc_ + 2 * nc_ * S_;
     const int goff = type == 1 ? 0 : type == 2 ? off_tc : type == 3 ? off_qs : type == 4 ? off_ac : off_hy;
     const int gnx = (type == 1 || type == 3) ? 1 : (type == 2 || type == 4) ? S_ : nh;
     const int o = goff + c * gnx + idx;             // element of the rank's parameter vector this step perturbs
     const int ev = partial ? evt - 1 : 0;
-    const int o_h = off_hy + c * nh + 3 * ev;
-    int goffs = o;
-    goffs = lane == 1 ? o_h : goffs; goffs = lane == 2 ? o_h + 1 : goffs; goffs = lane == 3 ? o_h + 2 : goffs;
-    goffs = lane == 4 ? c : goffs; goffs = lane == 5 ? off_qs + c : goffs;
-    const double gathered_v = xall_[goffs];
-    const double mu = ld_const(muall_ + o), rs2 = ld_const(rs2all_ + o), step = ld_const(stall_ + o);
-    const int ptype = ld_const(ptall_ + o);
-    const double *tc = xall_ + off_tc + c * S_, *ac = xall_ + off_ac + c * S_;
-    StaRegs<(NCH > 0 ? NCH : 1)> st;
-    ObsRegs<(NCH > 0 ? NCH : 1)> ob;
-    if (partial) {
-        if constexpr (NCH > 0) {
-            load_sta_regs<NCH>(st, f.S, lane, s_sx, s_sy, s_sz, tc, ac, 0, -1, 0.0);
-            load_obs_regs<NCH, F32>(ob, f, ev, lane);      // in flight while the proposal is worked out
-        }
-    }
+    const double *tc = cs.xall + off_tc + c * S_, *ac = cs.xall + off_ac + c * S_;
     // the book of this chain: is this step's order out already, and how
     const int book_pos = sh.ob_pos[c], book_mode = sh.ob_mode[c], book_mid = sh.ob_mid[c];
     const unsigned book_tag = sh.ob_tag[c];
     const bool pre = !partial && book_pos == p;
     const int pre_mode = pre ? book_mode : 0;
     // a full-evaluation step whose order went out two steps ahead adds the event of the step in between itself (below):
-    // its inputs are requested now, into the registers a partial update would use
+    // its inputs are requested now
+    StaRegs<N> st;
+    ObsRegs<N> ob;
     int d_e = 0;
     double d_ex = 0.0, d_ey = 0.0, d_ez = 0.0;
     const bool own_evt = NCH > 0 && pre_mode == 2 && (book_mid & 7) >= 5;
@@ -245,16 +335,26 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
         if (__builtin_expect(own_evt, 0)) {
             d_e = __builtin_amdgcn_readfirstlane(book_mid >> 3) - 1;
             const int vzd = opaque_zero();
-            const double *hypd = xall_ + off_hy + c * nh + 3 * d_e;
+            const double *hypd = cs.xall + off_hy + c * nh + 3 * d_e;
             d_ex = ld_state(hypd, vzd); d_ey = ld_state(hypd + 1, vzd); d_ez = ld_state(hypd + 2, vzd);
             load_sta_regs<NCH>(st, f.S, lane, s_sx, s_sy, s_sz, tc, ac, 0, -1, 0.0);
             load_obs_regs<NCH, F32>(ob, f, d_e, lane);
+        } else if (partial) {
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                st.sx[k] = rsx[k]; st.sy[k] = rsy[k]; st.sz[k] = rsz[k]; st.tc[k] = cur.tc[k]; st.ac[k] = cur.ac[k];
+                ob.tob[k] = cur.tob[k]; ob.tpr[k] = cur.tpr[k]; ob.aob[k] = cur.aob[k]; ob.apr[k] = cur.apr[k];
+            }
+            ob.rpst = f.use_time ? rl_f64(cur.gB, 3) : 1.0;
+            ob.rpsa = f.use_amp ? rl_f64(cur.gB, 4) : 1.0;
         }
     }
     FSTAMP(0);
-    const double x_old = rl_f64(gathered_v, 0);
-    const double hx = rl_f64(gathered_v, 1), hy = rl_f64(gathered_v, 2), hz = rl_f64(gathered_v, 3);
-    const double beta = rl_f64(gathered_v, 4), q = rl_f64(gathered_v, 5);
+    const double x_old = type >= 5 ? rl_f64(cur.gA, 0) : rg.mx[o];       // (types 1..4: the LDS mirror, kept current by the commits)
+    const double hx = rl_f64(cur.gA, 1), hy = rl_f64(cur.gA, 2), hz = rl_f64(cur.gA, 3);
+    const double beta = rg.mx[c], q = rg.mx[off_qs + c];
+    const double mu = rl_f64(cur.gB, 0), rs2 = rl_f64(cur.gB, 1), step = rl_f64(cur.gB, 2);
+    const int ptype = __builtin_amdgcn_readfirstlane(cur.pt);
     const double L_cur = sh.L[c];
     const double x_new = x_old + g * step;                      // cls_model.f90:172
     const double da = x_new - mu, db = x_old - mu;
@@ -278,14 +378,62 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
             lds_st(&sh.Eof[k4], E);
         }
     }
-    if (lane == 0) {
+    if (lane == 0)
         lds_st(&sh.prog[c], ((unsigned long long)(((unsigned)W.epoch << 1) | (ok ? 0u : 1u)) << 32) | (unsigned)key);
-    }
-    if (ext && fill_to > sh.fill) {                             // (the window's loads were issued before the step's: they are there)
+    if (ext && fill_to > sh.fill) {
         pf_store(pf, rg);
         if (lane == 0) lds_st(&sh.fill, fill_to);
     }
-
+    // ---- the wave's NEXT step: where it starts (a prediction in this epoch), and the request of its inputs -- in flight
+    // ---- under this step's evaluation, turn and commit
+    nx.p = -1;
+    {
+        const int cn = c + NW < nc_ ? c + NW : wave;
+        const bool same_it = cn > c;
+        const int itn = same_it ? iter : iter + 1;
+        const int rcn = same_it ? W.rc : W.rc1, rpn = same_it ? W.rpos : W.rpos1;
+        if (ok != 0 && rpn >= 0 && cn >= rcn && itn <= sh.c.iter_target) {
+            const int pn = hop_ahead(rg, rpn, cn - rcn);
+            if (pn + 16 < sh.fill) flow_request<NCH, F32>(f, cs, rg, W, nx, itn, cn, pn, lane);
+        }
+    }
+    // ---- the orders this chain may send ahead after this step (what role P does for all chains in step_body): its next
+    // ---- step's if that needs the full evaluation (one step ahead), else -- that step being a hypocentre step -- the one
+    // ---- after it (two steps ahead: the workers leave the event of the step in between out, this wave adds it).
+    // ---- Looked up here from positions alone; sent after the commit.  A step uses an order only if it starts exactly where
+    // ---- the order was written for, and an epoch change voids the book.
+    PlanIn pl;
+    pl.mode = 0; pl.epoch = W.epoch; pl.pj = 0; pl.jt = 0; pl.ji = 0; pl.jo = 0; pl.mid = 0; pl.o_mid = -1; pl.jx_old = 0.0; pl.jstep = 0.0; pl.jg = 0.0;
+    if (rg.mir_n > 0 && (book_pos == -1 || book_pos == p) && ok != 0 && iter + 1 <= sh.c.iter_target) {
+        const int lim = sh.fill - 8;
+        int p1 = -1, d1x = 0, d1y = 0, d1z = 0;
+        if (nx.p >= 0 && nx.c == c) { p1 = nx.p; d1x = nx.type; d1y = nx.idx; d1z = nx.evt; }     // (a wave with one chain)
+        else if (W.rpos1 >= 0 && c >= W.rc1) {
+            p1 = hop_ahead(rg, W.rpos1, c - W.rc1);
+            if (p1 < lim) {
+                const i32x4 d1 = reinterpret_cast<const i32x4 *>(rg.dec)[p1 & M];
+                d1x = d1.x; d1y = d1.y; d1z = d1.z;
+            } else p1 = -1;
+        }
+        const bool w1 = p1 >= 0;
+        const bool job1 = w1 && d1x >= 1 && d1x <= 4;
+        int mode = job1 ? 1 : 0, pj = p1, jt = d1x, ji = d1y;
+        if (HTM_ALLOW2 && NCH > 0 && w1 && !job1 && iter + 2 <= sh.c.iter_target && W.B2 >= 0) {
+            const int p2 = hop_ahead(rg, W.B2, c);
+            if (p2 < lim) {
+                const i32x4 d2 = reinterpret_cast<const i32x4 *>(rg.dec)[p2 & M];
+                if (d2.x >= 1 && d2.x <= 4) { mode = 2; pj = p2; jt = d2.x; ji = d2.y; }
+            }
+        }
+        if (mode) {
+            const int jgoff = jt == 1 ? 0 : jt == 2 ? nc_ : jt == 3 ? nc_ + nc_ * S_ : 2 * nc_ + nc_ * S_;
+            pl.jo = jgoff + c * ((jt == 1 || jt == 3) ? 1 : S_) + ji;
+            pl.jx_old = rg.mx[pl.jo];                                         // LDS mirror (this step's own commit: below)
+            pl.jstep = rg.mir_steps ? rg.mstep[pl.jo] : cs.stall[pl.jo + opaque_zero()];
+            pl.jg = rg.pg[pj & M];
+            pl.mode = mode; pl.pj = pj; pl.jt = jt; pl.ji = ji; pl.mid = d1x | (d1z << 3); pl.o_mid = off_hy + c * nh + d1y;
+        }
+    }
     FSTAMP(1);
     double L_new = 0.0;
     int need_full = 0;
@@ -414,6 +562,7 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
                 bool stands = false;
                 if (!flow_adopt(cs, sh, rg, W, e, iter, c, true, stands)) continue;
                 flow_void_books(cs, sh, wave, NW, nc_, lane);
+                nx.p = -1;                       // (requested for a position of the old epoch)
                 if (!stands) return kFlowRestart;
                 continue;
             }
@@ -477,6 +626,7 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
         sh.L4[par][c] = L_post;
         lds_st(&sh.done[c], key);
     }
+    if (acc) flow_patch<N>(nx, c, type, idx, evt, o, x_new, lane, nc_, S_, nh);
     FSTAMP(4);
     // ---- a rejected prior: this step was one draw shorter than the hop tables assume.  Everything after it starts
     // ---- elsewhere: new epoch, anchored at the step after this one
@@ -490,6 +640,7 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
         // (this wave's own view: as any wave whose step stands before the anchor; a later rejection may already have moved on)
         while (!flow_adopt(cs, sh, rg, W, lds_ld(&sh.epoch), iter, c, true, stands)) { }
         flow_void_books(cs, sh, wave, NW, nc_, lane);
+        nx.p = -1;
     }
     // ---- records of this step (hypo_tremor_mcmc.f90:270-280): slots by LDS atomics, put in order on the host
     if (__builtin_expect(sh.c.slog_cap > 0, 0)) {
@@ -526,59 +677,35 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
             }
         }
     }
-    // ---- orders of this chain's coming full evaluations (what role P does for all chains in step_body): the next step's
-    // ---- if it needs one (one step ahead), else -- that step being a hypocentre step -- the one after it (two steps ahead:
-    // ---- the workers leave the event of the step in between out, this wave adds it).  Positions are predictions; a step
-    // ---- uses an order only if it starts exactly where the order was written for, and an epoch change voids the book.
-    if (rg.mir_n > 0 && sh.ob_pos[c] == -1 && iter + 1 <= sh.c.iter_target) {
-        const int lim = sh.fill - 8;
-        // this chain's next step is its step of the next iteration (this wave's other chains of this iteration come first)
-        const int p1 = (W.rpos1 >= 0 && c >= W.rc1) ? hop_ahead(rg, W.rpos1, c - W.rc1) : -1;
-        const bool w1 = p1 >= 0 && p1 < lim;
-        const i32x4 d1 = reinterpret_cast<const i32x4 *>(rg.dec)[(w1 ? p1 : 0) & M];
-        const bool job1 = w1 && d1.x >= 1 && d1.x <= 4;
-        int mode = job1 ? 1 : 0;
-        int pj = p1;
-        int jt = d1.x, ji = d1.y;
-        if (HTM_ALLOW2 && NCH > 0 && w1 && !job1 && iter + 2 <= sh.c.iter_target && W.B2 >= 0) {
-            const int p2 = hop_ahead(rg, W.B2, c);
-            if (p2 < lim) {
-                const i32x4 d2 = reinterpret_cast<const i32x4 *>(rg.dec)[p2 & M];
-                if (d2.x >= 1 && d2.x <= 4) { mode = 2; pj = p2; jt = d2.x; ji = d2.y; }
-            }
+    // ---- the order looked up above goes out, if this epoch still stands and the book is free
+    if (pl.mode != 0 && pl.epoch == W.epoch && sh.ob_pos[c] == -1) {
+        int mode = pl.mode;
+        const double jx_old = (acc && o == pl.jo) ? x_new : pl.jx_old;        // (this step's own commit of that very element)
+        const double jx_new = jx_old + pl.jg * pl.jstep;                       // cls_model.f90:172, as the step will compute it
+        if (cs.rayleigh14) {                                                  // a Rayleigh prior among vs/qs/corrections (:178-187)
+            if (ld_const(cs.ptall + pl.jo) == 1 && jx_new <= ld_const(cs.muall + pl.jo)) mode = 0;      // prior rejects: no evaluation
         }
+        // two ahead: the workers wait for this step's commit by reading its value back; the step in between must not
+        // be able to overwrite that very element before they look
+        if (mode == 2 && acc && o == pl.o_mid) mode = 0;
         if (mode) {
-            const int jgoff = jt == 1 ? 0 : jt == 2 ? nc_ : jt == 3 ? nc_ + nc_ * S_ : 2 * nc_ + nc_ * S_;
-            const int jo = jgoff + c * ((jt == 1 || jt == 3) ? 1 : S_) + ji;
-            const double jx_old = rg.mx[jo];                                  // LDS mirror, kept current by this wave's commits
-            const double jstep = rg.mir_steps ? rg.mstep[jo] : ld_const(cs.stall + jo);
-            const double jx_new = jx_old + rg.pg[pj & M] * jstep;             // cls_model.f90:172, as the step will compute it
-            if (cs.rayleigh14) {                                              // a Rayleigh prior among vs/qs/corrections (:178-187)
-                if (ld_const(cs.ptall + jo) == 1 && jx_new <= ld_const(cs.muall + jo)) mode = 0;      // prior rejects: no evaluation
+            unsigned long long tk = 0;
+            if (lane == 0) {
+                tk = (atomicAdd(&sh.c.jobs_total, 1ull) + 1ull) & 0x7fffffffull;
+                if (tk == 0) tk = 0x7fffffffull;
+                sh.ob_pos[c] = pl.pj; sh.ob_tag[c] = (unsigned)tk; sh.ob_mode[c] = mode; sh.ob_mid[c] = pl.mid;
             }
-            // two ahead: the workers wait for this step's commit by reading its value back; the step in between must not
-            // be able to overwrite that very element before they look
-            const int o_mid = off_hy + c * nh + d1.y;
-            if (mode == 2 && acc && o == o_mid) mode = 0;
-            if (mode) {
-                unsigned long long tk = 0;
-                if (lane == 0) {
-                    tk = (atomicAdd(&sh.c.jobs_total, 1ull) + 1ull) & 0x7fffffffull;
-                    if (tk == 0) tk = 0x7fffffffull;
-                    sh.ob_pos[c] = pj; sh.ob_tag[c] = (unsigned)tk; sh.ob_mode[c] = mode; sh.ob_mid[c] = d1.x | (d1.z << 3);
-                }
-                const unsigned tag = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)tk);
-                if (lane < cs.slot_rep * kGranPerSlot) {
-                    const int gi = lane & 7;
-                    const unsigned long long xb = (unsigned long long)__double_as_longlong(jx_new);
-                    const unsigned long long cb = (unsigned long long)__double_as_longlong(x_new);
-                    const unsigned pay = gi == 0 ? (unsigned)launch : gi == 1 ? ((unsigned)jt | ((unsigned)ji << 3))
-                                       : gi == 2 ? (unsigned)(xb >> 32) : gi == 3 ? (unsigned)xb
-                                       : gi == 4 ? (acc ? (unsigned)o : 0xffffffffu)              // the commit the workers must see
-                                       : gi == 5 ? (unsigned)(cb >> 32) : gi == 6 ? (unsigned)cb
-                                       : (mode == 2 ? (unsigned)o_mid + 1u : 0u);                  // element of the step in between (+1; 0 = none)
-                    st_gran(cs.slots + (size_t)(lane >> 3) * cs.slot_stride + c * kGranPerSlot + gi, tag, pay);
-                }
+            const unsigned tag = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)tk);
+            if (lane < cs.slot_rep * kGranPerSlot) {
+                const int gi = lane & 7;
+                const unsigned long long xb = (unsigned long long)__double_as_longlong(jx_new);
+                const unsigned long long cb = (unsigned long long)__double_as_longlong(x_new);
+                const unsigned pay = gi == 0 ? (unsigned)launch : gi == 1 ? ((unsigned)pl.jt | ((unsigned)pl.ji << 3))
+                                   : gi == 2 ? (unsigned)(xb >> 32) : gi == 3 ? (unsigned)xb
+                                   : gi == 4 ? (acc ? (unsigned)o : 0xffffffffu)              // the commit the workers must see
+                                   : gi == 5 ? (unsigned)(cb >> 32) : gi == 6 ? (unsigned)cb
+                                   : (mode == 2 ? (unsigned)pl.o_mid + 1u : 0u);               // element of the step in between (+1; 0 = none)
+                st_gran(cs.slots + (size_t)(lane >> 3) * cs.slot_stride + c * kGranPerSlot + gi, tag, pay);
             }
         }
     }
@@ -678,6 +805,20 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
     W.epoch = 0; W.akey = 0; W.rc = 0; W.rpos = 0;
     W.rc1 = 0; W.rpos1 = flow_next_base(cs, sh, rg, 0, nc, sh.fill);
     W.B2 = flow_next_base(cs, sh, rg, W.rpos1, nc, sh.fill);
+    constexpr int N = NCH > 0 ? NCH : 1;
+    // station coordinates of this wave's lanes: resident in registers for the whole launch
+    double rsx[N], rsy[N], rsz[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const int j = lane + 64 * k;
+        const bool valid = NCH > 0 && j < f.S;
+        rsx[k] = valid ? s_sx[j] : 0.0; rsy[k] = valid ? s_sy[j] : 0.0; rsz[k] = valid ? s_sz[j] : 0.0;
+    }
+    StepIn<N> nx;                     // the inputs of the wave's next step, requested while the step before it runs
+    nx.p = -1; nx.it = 0; nx.c = 0; nx.epoch = 0; nx.type = 5; nx.idx = 0; nx.evt = 1; nx.dec_w = 6;
+    nx.g = 0.0; nx.r = 0.0; nx.logr = 0.0; nx.gA = 0.0; nx.gB = 0.0; nx.pt = 0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) { nx.tob[k] = nx.tpr[k] = nx.aob[k] = nx.apr[k] = 0.0; nx.tc[k] = nx.ac[k] = 0.0; }
     int iter = i0 + 1;
     int c = wave;
     bool alive = wave < nc;
@@ -692,6 +833,7 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
                 bool stands = false;
                 if (!flow_adopt(cs, sh, rg, W, e, iter, c, false, stands)) continue;
                 flow_void_books(cs, sh, wave, NW, nc, lane);
+                nx.p = -1;
             }
         }
         if (iter > lds_ld(&sh.last_iter) || sh.c.err != 0) break;
@@ -699,28 +841,34 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
             if (W.rpos1 < 0) { W.rpos1 = flow_next_base(cs, sh, rg, W.rpos, nc - W.rc, sh.fill); W.rc1 = 0; }
             if (W.B2 < 0 && W.rpos1 >= 0) W.B2 = flow_next_base(cs, sh, rg, W.rpos1, nc - W.rc1, sh.fill);
         }
-        const int p = hop_ahead(rg, W.rpos, c - W.rc);
+        if (__builtin_expect(nx.p < 0 || nx.it != iter || nx.c != c || nx.epoch != W.epoch, 0)) {
+            // nothing (valid) was requested ahead for this step -- first step of a launch, after an epoch change, or the
+            // window did not reach: look its position up and request its inputs now
+            const int p = hop_ahead(rg, W.rpos, c - W.rc);
+            if (__builtin_expect(p + 16 >= lds_ld(&sh.fill), 0)) {
+                // the window covers every step that can run (chain 0's wave keeps it 3 iterations ahead); a fail-stop
+                if (wave == 0) { if (lane == 0) sh.c.err = -13; break; }
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                bool dead = false;
+                while (p + 16 >= lds_ld(&sh.fill)) {
+                    if (sh.c.err != 0 || __builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) { dead = true; break; }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+                if (dead) { if (lane == 0 && sh.c.err == 0) sh.c.err = -13; break; }
+            }
+            flow_request<NCH, F32>(f, cs, rg, W, nx, iter, c, p, lane);
+        }
+        const StepIn<N> cur = nx;
         if (wave == 0 && c == 0 && lane == 0) {
             // chain 0's wave decides where the launch ends: record buffers or produced stream nearly used up.  Everybody
             // learns it before committing a step of this iteration (its turn waits for chain 0's check)
             int code = 0;
             if (sh.c.n_lik + 3 * nc > cs.cap_lik || sh.c.n_smp + 3 * nc > cs.cap_smp) code = 1;
-            else if (sh.avail < p + 3 * wd + 32) code = 2;
+            else if (sh.avail < cur.p + 3 * wd + 32) code = 2;
             if (code && lds_ld(&sh.last_iter) > iter) { sh.stop_code = code; lds_st(&sh.last_iter, iter); }
         }
-        // the window covers this step (chain 0's wave keeps it 3 iterations ahead); a fail-stop, never expected to wait
-        if (__builtin_expect(p + 16 >= lds_ld(&sh.fill), 0)) {
-            if (wave == 0) { if (lane == 0) sh.c.err = -13; break; }
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            bool dead = false;
-            while (p + 16 >= lds_ld(&sh.fill)) {
-                if (sh.c.err != 0 || __builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) { dead = true; break; }
-                __builtin_amdgcn_s_sleep(4);
-            }
-            if (dead) { if (lane == 0 && sh.c.err == 0) sh.c.err = -13; break; }
-        }
-        const int r = flow_step<NCH, F32>(f, cs, sh, rg, W, s_sx, s_sy, s_sz, c, p, iter, lane, wave, NW, launch, wave == 0,
-                                          look, back, rec_phase == 1);
+        const int r = flow_step<NCH, F32>(f, cs, sh, rg, W, cur, nx, rsx, rsy, rsz, s_sx, s_sy, s_sz, lane, wave, NW, launch,
+                                          wave == 0, look, back, rec_phase == 1);
         if (r == kFlowRestart) continue;
         if (r == kFlowAbort) break;
         // ---- this wave's next step
