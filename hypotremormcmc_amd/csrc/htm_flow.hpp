@@ -264,6 +264,41 @@ __device__ __forceinline__ void flow_patch(StepIn<N> &n, int c, int type, int id
     }
 }
 
+// The global stores of a step -- its commit and the order it sends ahead -- are ISSUED AT THE START OF THE WAVE'S NEXT STEP,
+// behind that step's first use of its requested inputs.  Vector-memory operations of a wave complete in issue order and a
+// write-through store is acknowledged by memory (~1 us): a step that waits for its inputs right after the commit store of
+// the step before waits for that acknowledgement (measured: 2.5 k of a step's 12 k cycles).  Issued here, the stores are
+// younger than everything the step waits for; they are a step old by the time anything waits behind them.
+struct Deferred {
+    int commit_o;                 // element to write, -1: none
+    double commit_x;
+    int ord_c;                    // chain whose order slot to write, -1: none
+    unsigned ord_tag, ord_w1, ord_co, ord_rep;
+    double ord_x, ord_cx;
+};
+__device__ __forceinline__ void flow_issue(CsRef cs_, Deferred &df, int lane, unsigned long long launch)
+{
+    CsRef cs = rebase(cs_);
+    if (df.commit_o >= 0) {
+        if (lane == 0) st_agent(cs.xall + df.commit_o, df.commit_x);
+        df.commit_o = -1;
+    }
+    if (df.ord_c >= 0) {
+        if (lane < cs.slot_rep * kGranPerSlot) {
+            const int gi = lane & 7;
+            const unsigned long long xb = (unsigned long long)__double_as_longlong(df.ord_x);
+            const unsigned long long cb = (unsigned long long)__double_as_longlong(df.ord_cx);
+            const unsigned pay = gi == 0 ? (unsigned)launch : gi == 1 ? df.ord_w1
+                               : gi == 2 ? (unsigned)(xb >> 32) : gi == 3 ? (unsigned)xb
+                               : gi == 4 ? df.ord_co                                    // the commit the workers must see, or ~0
+                               : gi == 5 ? (unsigned)(cb >> 32) : gi == 6 ? (unsigned)cb
+                               : df.ord_rep;                                            // element of the step in between (+1; 0 = none)
+            st_gran(cs.slots + (size_t)(lane >> 3) * cs.slot_stride + df.ord_c * kGranPerSlot + gi, df.ord_tag, pay);
+        }
+        df.ord_c = -1;
+    }
+}
+
 // the orders a chain may send ahead, looked up from positions alone while the step is evaluated; what depends on the
 // step's outcome is filled in after its commit (flow_step)
 struct PlanIn {
@@ -278,7 +313,7 @@ struct PlanIn {
 // per step, in flight under the step's arithmetic).  Returns the stream position after the step, kFlowRestart or kFlowAbort.
 template <int NCH, bool F32>
 __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, const Ring &rg, FlowWave &W,
-                                         const StepIn<(NCH > 0 ? NCH : 1)> &cur, StepIn<(NCH > 0 ? NCH : 1)> &nx,
+                                         const StepIn<(NCH > 0 ? NCH : 1)> &cur, StepIn<(NCH > 0 ? NCH : 1)> &nx, Deferred &df,
                                          const double (&rsx)[(NCH > 0 ? NCH : 1)], const double (&rsy)[(NCH > 0 ? NCH : 1)],
                                          const double (&rsz)[(NCH > 0 ? NCH : 1)],
                                          const double *s_sx, const double *s_sy, const double *s_sz,
@@ -296,19 +331,6 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
     unsigned long long t_last = __builtin_amdgcn_s_memtime(), t_wait = 0;
     const unsigned long long t_step0 = t_last;
 #endif
-    // ---- the LDS window of the stream rings, one round per step of chain 0's wave: requested first, stored behind the
-    // ---- step's arithmetic
-    PfRegs pf;
-    pf.p = -1;
-    int fill_to = 0;
-    if (ext) {
-        const int fl = sh.fill;
-        // (this step is chain c's: the iteration's base lies 4 c .. 6 c positions back; the other waves may still read `back`
-        // positions behind it, and want `look` positions ahead of it)
-        fill_to = min(min(p - 4 * c + look, sh.avail), p - 6 * c - back + M + 1);
-        if (fill_to > fl + 64) fill_to = fl + 64;
-        if (fill_to > fl) pf_load(pf, cs, sh, fl + lane, fill_to);
-    }
     const int nc_ = cs.n_chains, S_ = cs.S, nh = 3 * cs.E;
     const int type = cur.type, idx = cur.idx, evt = cur.evt, dec_w = cur.dec_w;
     const double g = cur.g, r_ring = cur.r, logr_ring = cur.logr;
@@ -355,6 +377,21 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
     const double beta = rg.mx[c], q = rg.mx[off_qs + c];
     const double mu = rl_f64(cur.gB, 0), rs2 = rl_f64(cur.gB, 1), step = rl_f64(cur.gB, 2);
     const int ptype = __builtin_amdgcn_readfirstlane(cur.pt);
+    // ---- everything this step had requested is in: the stores of the step before go out now (see Deferred), and the round
+    // ---- of the LDS window of the stream rings that chain 0's wave owes per step is requested (stored behind the evaluation)
+    drain_vmem();
+    flow_issue(cs, df, lane, launch);
+    PfRegs pf;
+    pf.p = -1;
+    int fill_to = 0;
+    if (ext) {
+        const int fl = sh.fill;
+        // (this step is chain c's: the iteration's base lies 4 c .. 6 c positions back; the other waves may still read `back`
+        // positions behind it, and want `look` positions ahead of it)
+        fill_to = min(min(p - 4 * c + look, sh.avail), p - 6 * c - back + M + 1);
+        if (fill_to > fl + 64) fill_to = fl + 64;
+        if (fill_to > fl) pf_load(pf, cs, sh, fl + lane, fill_to);
+    }
     const double L_cur = sh.L[c];
     const double x_new = x_old + g * step;                      // cls_model.f90:172
     const double da = x_new - mu, db = x_old - mu;
@@ -380,10 +417,6 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
     }
     if (lane == 0)
         lds_st(&sh.prog[c], ((unsigned long long)(((unsigned)W.epoch << 1) | (ok ? 0u : 1u)) << 32) | (unsigned)key);
-    if (ext && fill_to > sh.fill) {
-        pf_store(pf, rg);
-        if (lane == 0) lds_st(&sh.fill, fill_to);
-    }
     // ---- the wave's NEXT step: where it starts (a prediction in this epoch), and the request of its inputs -- in flight
     // ---- under this step's evaluation, turn and commit
     nx.p = -1;
@@ -548,6 +581,10 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
             L_new = -wave_sum1(part + own_lane) - f.const_sum;       // cls_forward.f90:277-300
         }
     }
+    if (ext && fill_to > sh.fill) {
+        pf_store(pf, rg);
+        if (lane == 0) lds_st(&sh.fill, fill_to);
+    }
     FSTAMP(2);
 
     // ---- the step's turn: every step before it in stream order has passed its check in this epoch (or lies before the
@@ -562,6 +599,7 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
                 bool stands = false;
                 if (!flow_adopt(cs, sh, rg, W, e, iter, c, true, stands)) continue;
                 flow_void_books(cs, sh, wave, NW, nc_, lane);
+                df.ord_c = -1;                   // (an order not yet issued is void with the book)
                 nx.p = -1;                       // (requested for a position of the old epoch)
                 if (!stands) return kFlowRestart;
                 continue;
@@ -618,7 +656,6 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
         if (ok != 0) atomicAdd(need_full ? &sh.n_full_w : &sh.n_part_w, 1ull);      // (a step that is run again left before this point)
         if (cool) sh.np[c * 7 + type - 1] += 1;                 // cls_mcmc.f90:186-189
         if (acc) {                                              // :207-219
-            st_agent(cs.xall + o, x_new);
             if (o < rg.mir_n) rg.mx[o] = x_new;
             sh.L[c] = L_new;
             if (cool) sh.na[c * 7 + type - 1] += 1;
@@ -626,7 +663,13 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
         sh.L4[par][c] = L_post;
         lds_st(&sh.done[c], key);
     }
-    if (acc) flow_patch<N>(nx, c, type, idx, evt, o, x_new, lane, nc_, S_, nh);
+    if (acc) {
+        // the store to the chain's state in memory: at the start of the wave's next step (Deferred) -- unless this step's
+        // sample record is about to read the state back
+        if (rec_now && cool) { if (lane == 0) st_agent(cs.xall + o, x_new); }
+        else { df.commit_o = o; df.commit_x = x_new; }
+        flow_patch<N>(nx, c, type, idx, evt, o, x_new, lane, nc_, S_, nh);
+    }
     FSTAMP(4);
     // ---- a rejected prior: this step was one draw shorter than the hop tables assume.  Everything after it starts
     // ---- elsewhere: new epoch, anchored at the step after this one
@@ -640,6 +683,7 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
         // (this wave's own view: as any wave whose step stands before the anchor; a later rejection may already have moved on)
         while (!flow_adopt(cs, sh, rg, W, lds_ld(&sh.epoch), iter, c, true, stands)) { }
         flow_void_books(cs, sh, wave, NW, nc_, lane);
+        df.ord_c = -1;
         nx.p = -1;
     }
     // ---- records of this step (hypo_tremor_mcmc.f90:270-280): slots by LDS atomics, put in order on the host
@@ -696,17 +740,10 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
                 sh.ob_pos[c] = pl.pj; sh.ob_tag[c] = (unsigned)tk; sh.ob_mode[c] = mode; sh.ob_mid[c] = pl.mid;
             }
             const unsigned tag = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)tk);
-            if (lane < cs.slot_rep * kGranPerSlot) {
-                const int gi = lane & 7;
-                const unsigned long long xb = (unsigned long long)__double_as_longlong(jx_new);
-                const unsigned long long cb = (unsigned long long)__double_as_longlong(x_new);
-                const unsigned pay = gi == 0 ? (unsigned)launch : gi == 1 ? ((unsigned)pl.jt | ((unsigned)pl.ji << 3))
-                                   : gi == 2 ? (unsigned)(xb >> 32) : gi == 3 ? (unsigned)xb
-                                   : gi == 4 ? (acc ? (unsigned)o : 0xffffffffu)              // the commit the workers must see
-                                   : gi == 5 ? (unsigned)(cb >> 32) : gi == 6 ? (unsigned)cb
-                                   : (mode == 2 ? (unsigned)pl.o_mid + 1u : 0u);               // element of the step in between (+1; 0 = none)
-                st_gran(cs.slots + (size_t)(lane >> 3) * cs.slot_stride + c * kGranPerSlot + gi, tag, pay);
-            }
+            df.ord_c = c; df.ord_tag = tag; df.ord_w1 = (unsigned)pl.jt | ((unsigned)pl.ji << 3);
+            df.ord_x = jx_new; df.ord_cx = x_new;
+            df.ord_co = acc ? (unsigned)o : 0xffffffffu;
+            df.ord_rep = mode == 2 ? (unsigned)pl.o_mid + 1u : 0u;
         }
     }
 #ifdef HTM_STAMPS
@@ -814,6 +851,8 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
         const bool valid = NCH > 0 && j < f.S;
         rsx[k] = valid ? s_sx[j] : 0.0; rsy[k] = valid ? s_sy[j] : 0.0; rsz[k] = valid ? s_sz[j] : 0.0;
     }
+    Deferred df;
+    df.commit_o = -1; df.commit_x = 0.0; df.ord_c = -1; df.ord_tag = 0; df.ord_w1 = 0; df.ord_co = 0; df.ord_rep = 0; df.ord_x = 0.0; df.ord_cx = 0.0;
     StepIn<N> nx;                     // the inputs of the wave's next step, requested while the step before it runs
     nx.p = -1; nx.it = 0; nx.c = 0; nx.epoch = 0; nx.type = 5; nx.idx = 0; nx.evt = 1; nx.dec_w = 6;
     nx.g = 0.0; nx.r = 0.0; nx.logr = 0.0; nx.gA = 0.0; nx.gB = 0.0; nx.pt = 0;
@@ -833,6 +872,7 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
                 bool stands = false;
                 if (!flow_adopt(cs, sh, rg, W, e, iter, c, false, stands)) continue;
                 flow_void_books(cs, sh, wave, NW, nc, lane);
+                df.ord_c = -1;
                 nx.p = -1;
             }
         }
@@ -867,7 +907,7 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
             else if (sh.avail < cur.p + 3 * wd + 32) code = 2;
             if (code && lds_ld(&sh.last_iter) > iter) { sh.stop_code = code; lds_st(&sh.last_iter, iter); }
         }
-        const int r = flow_step<NCH, F32>(f, cs, sh, rg, W, cur, nx, rsx, rsy, rsz, s_sx, s_sy, s_sz, lane, wave, NW, launch,
+        const int r = flow_step<NCH, F32>(f, cs, sh, rg, W, cur, nx, df, rsx, rsy, rsz, s_sx, s_sy, s_sz, lane, wave, NW, launch,
                                           wave == 0, look, back, rec_phase == 1);
         if (r == kFlowRestart) continue;
         if (r == kFlowAbort) break;
@@ -886,6 +926,7 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
             W.B2 = flow_next_base(cs, sh, rg, W.rpos1, nc, sh.fill);
         }
     }
+    flow_issue(cs, df, lane, launch);      // the last step's stores
 #ifdef HTM_STAMPS
     if (lane == 0 && cs.stamps && wave < 8) sh.stamp_acc[12 * wave + 11] += __builtin_amdgcn_s_memtime() - t_loop0;
 #endif
