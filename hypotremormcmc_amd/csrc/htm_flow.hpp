@@ -359,6 +359,11 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
             const int vzd = opaque_zero();
             const double *hypd = cs.xall + off_hy + c * nh + 3 * d_e;
             d_ex = ld_state(hypd, vzd); d_ey = ld_state(hypd + 1, vzd); d_ez = ld_state(hypd + 2, vzd);
+            // (the step in between is the chain's latest: if its commit is still waiting to be issued, memory has the old value)
+            const int od = off_hy + c * nh + 3 * d_e;
+            if (df.commit_o == od) d_ex = df.commit_x;
+            if (df.commit_o == od + 1) d_ey = df.commit_x;
+            if (df.commit_o == od + 2) d_ez = df.commit_x;
             load_sta_regs<NCH>(st, f.S, lane, s_sx, s_sy, s_sz, tc, ac, 0, -1, 0.0);
             load_obs_regs<NCH, F32>(ob, f, d_e, lane);
         } else if (partial) {
@@ -896,6 +901,8 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
                 }
                 if (dead) { if (lane == 0 && sh.c.err == 0) sh.c.err = -13; break; }
             }
+            // (the request reads the chain's state: a commit still waiting to be issued goes out first)
+            flow_issue(cs, df, lane, launch);
             flow_request<NCH, F32>(f, cs, rg, W, nx, iter, c, p, lane);
         }
         const StepIn<N> cur = nx;
