@@ -48,7 +48,23 @@ struct FlowShared : StepShared {
     int ob_pos[kMaxChains], ob_mode[kMaxChains], ob_mid[kMaxChains];     // ob_mid: type | event << 3 of the step in between (mode 2)
     unsigned ob_tag[kMaxChains];
     unsigned long long n_full_w, n_part_w;
+    StreamDev sd;                          // the stream rings' addresses (chain 0's wave extends the LDS window from them every step)
 };
+
+// pf_load (htm_step.hpp) with the rings' addresses taken from LDS instead of the kernarg segment
+__device__ __forceinline__ void flow_pf_load(PfRegs &r, const FlowShared &sh, int p, int limit)
+{
+    r.p = -1;
+    if (p < limit) {
+        const StreamDev &sd = sh.sd;
+        const long long g = (sh.origin + p) & sd.mask;
+        r.U = sd.U[g]; r.LOGU = sd.LOGU[g]; r.pg = sd.pg[g]; r.pr = sd.pr[g]; r.plogr = sd.plogr[g];
+        r.dec = reinterpret_cast<const i32x4 *>(sd.dec)[g]; r.sw = reinterpret_cast<const i32x4 *>(sd.sw)[g];
+        const i32x4 *hs = reinterpret_cast<const i32x4 *>(sd.hop + g * kHops);
+        r.h0 = hs[0]; r.h1 = hs[1];
+        r.p = p;
+    }
+}
 
 // LDS words shared between the waves: relaxed accesses in program order.  LDS operations of a wave are executed in
 // issue order and the LDS is one serialisation point for the workgroup, so "release" and "acquire" are compiler
@@ -65,11 +81,55 @@ struct FlowWave {                 // a wave's predictions (wave-uniform)
     int B2;                       // base of the iteration after that (orders sent ahead only); -1 = not known
 };
 
+// The kernel arguments the loop uses at every step, read ONCE per launch and kept in scalar registers (or their spill lanes:
+// a v_readlane) -- read at their uses (htm_step.hpp's rule for the 256-register kernels) each group of them is a scalar-cache
+// round trip the wave waits for: a dozen per step, ~2.4 k of its 12 k cycles.  Member names as in FwdDev / ChainsDev, so that
+// the forward model's templates (event_misfit, load_obs_regs) take it in place of the forward object.
+struct FlowHot {
+    int S, E, use_time, use_amp;
+    const double *t_obs, *t_prec, *a_obs, *a_prec, *rpsum_t, *rpsum_a;
+    const float *t_obs32, *t_prec32, *a_obs32, *a_prec32;
+    double const_sum;
+    int n_chains, n_all;
+    double *xall;
+    const double *muall, *rs2all, *stall;
+    const int *ptall;
+    unsigned long long *slots, *pgran;
+    int slot_rep, slot_stride, n_wg, pgran_stride;
+    unsigned long long *stamps;
+};
+template <class T>
+__device__ __forceinline__ void launder(T *&p) { asm volatile("" : "+s"(p)); }
+__device__ __forceinline__ void launder(int &v) { asm volatile("" : "+s"(v)); }
+__device__ __forceinline__ void flow_hot_load(FwRef f_, CsRef cs_, FlowHot &H)
+{
+    CsRef cs = rebase(cs_);
+    FwRef f = rebase(f_);
+    H.S = f.S; H.E = f.E; H.use_time = f.use_time; H.use_amp = f.use_amp;
+    H.t_obs = f.t_obs; H.t_prec = f.t_prec; H.a_obs = f.a_obs; H.a_prec = f.a_prec; H.rpsum_t = f.rpsum_t; H.rpsum_a = f.rpsum_a;
+    H.t_obs32 = f.t_obs32; H.t_prec32 = f.t_prec32; H.a_obs32 = f.a_obs32; H.a_prec32 = f.a_prec32;
+    H.const_sum = f.const_sum;
+    H.n_chains = cs.n_chains; H.n_all = cs.n_procs * cs.n_chains;
+    H.xall = cs.xall; H.muall = cs.muall; H.rs2all = cs.rs2all; H.stall = cs.stall; H.ptall = cs.ptall;
+    H.slots = cs.slots; H.pgran = cs.pgran;
+    H.slot_rep = cs.slot_rep; H.slot_stride = cs.slot_stride; H.n_wg = cs.n_wg; H.pgran_stride = cs.pgran_stride;
+    H.stamps = cs.stamps;
+    // (opaque from here on: a value the compiler can re-load from the kernarg segment it would rather re-load than keep)
+    launder(H.S); launder(H.E); launder(H.use_time); launder(H.use_amp);
+    launder(H.t_obs); launder(H.t_prec); launder(H.a_obs); launder(H.a_prec); launder(H.rpsum_t); launder(H.rpsum_a);
+    launder(H.t_obs32); launder(H.t_prec32); launder(H.a_obs32); launder(H.a_prec32);
+    launder(H.n_chains); launder(H.n_all);
+    launder(H.xall); launder(H.muall); launder(H.rs2all); launder(H.stall); launder(H.ptall);
+    launder(H.slots); launder(H.pgran);
+    launder(H.slot_rep); launder(H.slot_stride); launder(H.n_wg); launder(H.pgran_stride);
+    launder(H.stamps);
+}
+
 #ifdef HTM_STAMPS
 // diagnostic cycle accounting of the free-running master (tools/flow_stamps.py): per wave, [k] ticks of phase k summed over its
 // partial-update steps (0 front: loads issued, 1 proposal + check published, 2 evaluation, 3 turn, 4 swap + decision + commit,
 // 5 records + orders), 6 ticks of its full-evaluation steps, 7 / 8 the two counts, 9 ticks between steps (loop top), 10 wait part of 6
-#define FSTAMP(k) do { if (lane == 0 && cs.stamps) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_acc[k] += n_ - t_last; t_last = n_; } } while (0)
+#define FSTAMP(k) do { if (lane == 0 && H.stamps) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_acc[k] += n_ - t_last; t_last = n_; } } while (0)
 #else
 #define FSTAMP(k) do { } while (0)
 #endif
@@ -79,21 +139,19 @@ constexpr int kFlowAbort = -2;    // flow_step: a wait gave up (sh.c.err is set)
 
 // select_pair + the judge_swap draw starting at E (cls_parallel.f90:226-230, :163): pair, draws used in all (single rank:
 // this rank draws both).  The stream service has the usual case precomputed (sw ring); more than 12 redraws follow the stream.
-__device__ __forceinline__ bool flow_swap_at(CsRef cs_, const StepShared &sh, const Ring &rg, int E, int limit, int &i1, int &i2, int &nd)
+__device__ __forceinline__ bool flow_swap_at(int n_all, const Ring &rg, int E, int limit, int &i1, int &i2, int &nd)
 {
-    CsRef cs = rebase(cs_);
-    const int n_all = cs.n_procs * cs.n_chains;
     i1 = -1; i2 = -1; nd = 0;
     if (n_all <= 1) return true;
     if (E + 2 >= limit) return false;
     const i32x4 sw = reinterpret_cast<const i32x4 *>(rg.sw)[E & rg.mask];
     if (sw.z > 0) { i1 = sw.x; i2 = sw.y; nd = sw.z + 1; return E + nd < limit; }
     int pos = E;
-    i1 = (int)(rg.U[pos & rg.mask] * cs.n_procs * cs.n_chains);
+    i1 = (int)(rg.U[pos & rg.mask] * n_all);          // (= rand_u * n_proc * n_chain, cls_parallel.f90:226: one rank here)
     pos++;
     for (;;) {
         if (pos + 1 >= limit) return false;
-        i2 = (int)(rg.U[pos & rg.mask] * cs.n_procs * cs.n_chains);
+        i2 = (int)(rg.U[pos & rg.mask] * n_all);
         pos++;
         if (i1 != i2) break;
     }
@@ -102,36 +160,38 @@ __device__ __forceinline__ bool flow_swap_at(CsRef cs_, const StepShared &sh, co
 }
 
 // base of the next iteration when n chain steps of this one remain from pos; -1 if the window does not cover it
-__device__ __forceinline__ int flow_next_base(CsRef cs, const StepShared &sh, const Ring &rg, int pos, int n, int limit)
+__device__ __forceinline__ int flow_next_base(int n_all, const Ring &rg, int pos, int n, int limit)
 {
     if (pos < 0) return -1;
     const int E = hop_ahead(rg, pos, n);
     int i1, i2, nd;
-    if (E + 16 >= limit || !flow_swap_at(cs, sh, rg, E, limit, i1, i2, nd)) return -1;
+    if (E + 16 >= limit || !flow_swap_at(n_all, rg, E, limit, i1, i2, nd)) return -1;
     return E + nd;
 }
 
 // the anchor as (iteration, chain, position of that chain's step).  A rejected LAST step of an iteration leaves pos = the
 // end of that iteration's chain steps: chain 0 of the next iteration starts after the swap's draws.
-__device__ __forceinline__ void flow_from_anchor(CsRef cs_, const FlowShared &sh, const Ring &rg, unsigned long long a, int &ia, int &ca, int &ap)
+__device__ __forceinline__ void flow_from_anchor(const FlowHot &H, const FlowShared &sh, const Ring &rg, unsigned long long a, int &ia, int &ca, int &ap)
 {
-    CsRef cs = rebase(cs_);
-    const int nc = cs.n_chains;
+    const int nc = H.n_chains;
     const int key = (int)(unsigned)(a >> 32), pos = (int)(unsigned)a;
     ia = sh.i0 + key / nc; ca = key - (key / nc) * nc; ap = pos;
     if (ca == 0) {
         int i1, i2, nd;
-        flow_swap_at(cs, sh, rg, pos, 1 << 30, i1, i2, nd);     // (the rejected step's own wave read these positions: covered)
+        flow_swap_at(H.n_all, rg, pos, 1 << 30, i1, i2, nd);     // (the rejected step's own wave read these positions: covered)
         ap = pos + nd;
     }
 }
 
 // every order this wave has out for its chains is void (their positions were predicted in another epoch): the workers are told
-__device__ __forceinline__ void flow_void_books(CsRef cs, FlowShared &sh, int wave, int NW, int nc, int lane)
+__device__ __forceinline__ void flow_void_books(const FlowHot &H, FlowShared &sh, int wave, int NW, int nc, int lane)
 {
     for (int c = wave; c < nc; c += NW) {
         if (sh.ob_pos[c] != -1) {
-            if (lane == 0) { void_slot(cs, c); sh.ob_pos[c] = -1; }
+            if (lane == 0) {
+                for (int r = 0; r < H.slot_rep; ++r) st_gran(H.slots + (size_t)r * H.slot_stride + c * kGranPerSlot, 0u, 0u);   // (void_slot)
+                sh.ob_pos[c] = -1;
+            }
         }
     }
 }
@@ -139,32 +199,31 @@ __device__ __forceinline__ void flow_void_books(CsRef cs, FlowShared &sh, int wa
 // this wave adopts epoch e (read from sh.epoch a moment ago).  `standing`: its current step (it, c) has passed its check and lies
 // before the anchor -- it stands, and everything the wave runs after it starts at or after the anchor; else the current
 // step itself starts at or after the anchor.  Returns false if the epoch moved on meanwhile (the caller looks again).
-__device__ __forceinline__ bool flow_adopt(CsRef cs_, FlowShared &sh, const Ring &rg, FlowWave &W, int e, int it, int c, bool in_turn, bool &stands)
+__device__ __forceinline__ bool flow_adopt(const FlowHot &H, FlowShared &sh, const Ring &rg, FlowWave &W, int e, int it, int c, bool in_turn, bool &stands)
 {
-    CsRef cs = rebase(cs_);
-    const int nc = cs.n_chains;
+    const int nc = H.n_chains;
     const unsigned long long a = lds_ld(&sh.anch[e & 1]);
     if (lds_ld(&sh.epoch) != e) return false;
     const int akey = (int)(unsigned)(a >> 32);
     const int key = (it - sh.i0) * nc + c;
     int ia, ca, ap;
-    flow_from_anchor(cs, sh, rg, a, ia, ca, ap);
+    flow_from_anchor(H, sh, rg, a, ia, ca, ap);
     const int limit = sh.fill;
     stands = in_turn && key < akey;
     W.epoch = e; W.akey = akey;
     if (!stands) {
         // the current step starts at or after the anchor: same iteration, or the anchor sits in the iteration before
         if (ia == it) { W.rc = ca; W.rpos = ap; }
-        else { W.rc = 0; W.rpos = flow_next_base(cs, sh, rg, ap, nc - ca, 1 << 30); }
-        W.rc1 = 0; W.rpos1 = flow_next_base(cs, sh, rg, W.rpos, nc - W.rc, limit);
-        W.B2 = flow_next_base(cs, sh, rg, W.rpos1, nc, limit);
+        else { W.rc = 0; W.rpos = flow_next_base(H.n_all, rg, ap, nc - ca, 1 << 30); }
+        W.rc1 = 0; W.rpos1 = flow_next_base(H.n_all, rg, W.rpos, nc - W.rc, limit);
+        W.B2 = flow_next_base(H.n_all, rg, W.rpos1, nc, limit);
     } else if (ia == it) {
         W.rc = ca; W.rpos = ap;                         // (the wave's later chains of this iteration)
-        W.rc1 = 0; W.rpos1 = flow_next_base(cs, sh, rg, ap, nc - ca, limit);
-        W.B2 = flow_next_base(cs, sh, rg, W.rpos1, nc, limit);
+        W.rc1 = 0; W.rpos1 = flow_next_base(H.n_all, rg, ap, nc - ca, limit);
+        W.B2 = flow_next_base(H.n_all, rg, W.rpos1, nc, limit);
     } else {                                            // the anchor is a step of the next iteration
         W.rc1 = ca; W.rpos1 = ap;
-        W.B2 = flow_next_base(cs, sh, rg, ap, nc - ca, limit);
+        W.B2 = flow_next_base(H.n_all, rg, ap, nc - ca, limit);
     }
     return true;
 }
@@ -187,18 +246,15 @@ struct StepIn {
 };
 
 template <int NCH, bool F32>
-__device__ __forceinline__ void flow_request(FwRef f_, CsRef cs_, const Ring &rg, const FlowWave &W, StepIn<(NCH > 0 ? NCH : 1)> &n,
+__device__ __forceinline__ void flow_request(const FlowHot &H, const Ring &rg, const FlowWave &W, StepIn<(NCH > 0 ? NCH : 1)> &n,
                                              int it, int c, int p, int lane)
 {
-    CsRef cs = rebase(cs_);
-    FwRef f = rebase(f_);
     const int M = rg.mask;
     n.it = it; n.c = c; n.p = p; n.epoch = W.epoch;
-    const double *xall_ = cs.xall, *muall_ = cs.muall, *rs2all_ = cs.rs2all, *stall_ = cs.stall;
-    const int *ptall_ = cs.ptall;
-    const int nc_ = cs.n_chains, S_ = cs.S, nh = 3 * cs.E;
+    const double *xall_ = H.xall, *muall_ = H.muall, *rs2all_ = H.rs2all, *stall_ = H.stall;
+    const int *ptall_ = H.ptall;
+    const int nc_ = H.n_chains, S_ = H.S, nh = 3 * H.E;
     const i32x4 dec = reinterpret_cast<const i32x4 *>(rg.dec)[p & M];
-    asm volatile("" : "+s"(xall_), "+s"(muall_), "+s"(rs2all_), "+s"(stall_), "+s"(ptall_));
     const int type = __builtin_amdgcn_readfirstlane(dec.x), idx = __builtin_amdgcn_readfirstlane(dec.y);
     const int evt = __builtin_amdgcn_readfirstlane(dec.z);
     n.type = type; n.idx = idx; n.evt = evt; n.dec_w = __builtin_amdgcn_readfirstlane(dec.w);
@@ -215,27 +271,27 @@ __device__ __forceinline__ void flow_request(FwRef f_, CsRef cs_, const Ring &rg
     n.gA = xall_[ga];
     const double *pb = muall_ + o;
     pb = lane == 1 ? rs2all_ + o : pb; pb = lane == 2 ? stall_ + o : pb;
-    pb = lane == 3 ? f.rpsum_t + ev : pb; pb = lane == 4 ? f.rpsum_a + ev : pb;
+    pb = lane == 3 ? H.rpsum_t + ev : pb; pb = lane == 4 ? H.rpsum_a + ev : pb;
     n.gB = *pb;
     n.pt = ptall_[o + opaque_zero()];             // (a vector load: scalar loads in flight would hold up every LDS wait)
     if (partial) {
         if constexpr (NCH > 0) {
             const double *tc = xall_ + off_tc + c * S_, *ac = xall_ + off_ac + c * S_;
-            const size_t base = (size_t)ev * (size_t)f.S;
-            const bool ut = f.use_time != 0, ua = f.use_amp != 0;
+            const size_t base = (size_t)ev * (size_t)H.S;
+            const bool ut = H.use_time != 0, ua = H.use_amp != 0;
 #pragma unroll
             for (int k = 0; k < NCH; ++k) {
                 const int j = lane + 64 * k;
-                const bool valid = j < f.S;
+                const bool valid = j < H.S;
                 n.tob[k] = n.tpr[k] = n.aob[k] = n.apr[k] = 0.0; n.tc[k] = 0.0; n.ac[k] = 0.0;
                 if (valid) {
                     n.tc[k] = tc[j]; n.ac[k] = ac[j];
                     if constexpr (F32) {
-                        if (ut) { n.tob[k] = (double)f.t_obs32[base + j]; n.tpr[k] = (double)f.t_prec32[base + j]; }
-                        if (ua) { n.aob[k] = (double)f.a_obs32[base + j]; n.apr[k] = (double)f.a_prec32[base + j]; }
+                        if (ut) { n.tob[k] = (double)H.t_obs32[base + j]; n.tpr[k] = (double)H.t_prec32[base + j]; }
+                        if (ua) { n.aob[k] = (double)H.a_obs32[base + j]; n.apr[k] = (double)H.a_prec32[base + j]; }
                     } else {
-                        if (ut) { n.tob[k] = f.t_obs[base + j]; n.tpr[k] = f.t_prec[base + j]; }
-                        if (ua) { n.aob[k] = f.a_obs[base + j]; n.apr[k] = f.a_prec[base + j]; }
+                        if (ut) { n.tob[k] = H.t_obs[base + j]; n.tpr[k] = H.t_prec[base + j]; }
+                        if (ua) { n.aob[k] = H.a_obs[base + j]; n.apr[k] = H.a_prec[base + j]; }
                     }
                 }
             }
@@ -276,15 +332,14 @@ struct Deferred {
     unsigned ord_tag, ord_w1, ord_co, ord_rep;
     double ord_x, ord_cx;
 };
-__device__ __forceinline__ void flow_issue(CsRef cs_, Deferred &df, int lane, unsigned long long launch)
+__device__ __forceinline__ void flow_issue(const FlowHot &H, Deferred &df, int lane, unsigned long long launch)
 {
-    CsRef cs = rebase(cs_);
     if (df.commit_o >= 0) {
-        if (lane == 0) st_agent(cs.xall + df.commit_o, df.commit_x);
+        if (lane == 0) st_agent(H.xall + df.commit_o, df.commit_x);
         df.commit_o = -1;
     }
     if (df.ord_c >= 0) {
-        if (lane < cs.slot_rep * kGranPerSlot) {
+        if (lane < H.slot_rep * kGranPerSlot) {
             const int gi = lane & 7;
             const unsigned long long xb = (unsigned long long)__double_as_longlong(df.ord_x);
             const unsigned long long cb = (unsigned long long)__double_as_longlong(df.ord_cx);
@@ -293,7 +348,7 @@ __device__ __forceinline__ void flow_issue(CsRef cs_, Deferred &df, int lane, un
                                : gi == 4 ? df.ord_co                                    // the commit the workers must see, or ~0
                                : gi == 5 ? (unsigned)(cb >> 32) : gi == 6 ? (unsigned)cb
                                : df.ord_rep;                                            // element of the step in between (+1; 0 = none)
-            st_gran(cs.slots + (size_t)(lane >> 3) * cs.slot_stride + df.ord_c * kGranPerSlot + gi, df.ord_tag, pay);
+            st_gran(H.slots + (size_t)(lane >> 3) * H.slot_stride + df.ord_c * kGranPerSlot + gi, df.ord_tag, pay);
         }
         df.ord_c = -1;
     }
@@ -312,7 +367,7 @@ struct PlanIn {
 // event_misfit.  `ext`: this wave keeps the LDS window of the stream ahead (chain 0's wave, one round of <= 64 positions
 // per step, in flight under the step's arithmetic).  Returns the stream position after the step, kFlowRestart or kFlowAbort.
 template <int NCH, bool F32>
-__device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, const Ring &rg, FlowWave &W,
+__device__ __forceinline__ int flow_step(const FlowHot &H, CsRef cs_, FlowShared &sh, const Ring &rg, FlowWave &W,
                                          const StepIn<(NCH > 0 ? NCH : 1)> &cur, StepIn<(NCH > 0 ? NCH : 1)> &nx, Deferred &df,
                                          const double (&rsx)[(NCH > 0 ? NCH : 1)], const double (&rsy)[(NCH > 0 ? NCH : 1)],
                                          const double (&rsz)[(NCH > 0 ? NCH : 1)],
@@ -321,8 +376,7 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
                                          bool rec_now)
 {
     constexpr int N = NCH > 0 ? NCH : 1;
-    CsRef cs = rebase(cs_);
-    FwRef f = rebase(f_);
+    CsRef cs = rebase(cs_);      // (cold paths only: records, diagnostics; the loop's arguments are in H)
     const int M = rg.mask;
     const int c = cur.c, iter = cur.it;
     const int p = cur.p;
@@ -331,7 +385,7 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
     unsigned long long t_last = __builtin_amdgcn_s_memtime(), t_wait = 0;
     const unsigned long long t_step0 = t_last;
 #endif
-    const int nc_ = cs.n_chains, S_ = cs.S, nh = 3 * cs.E;
+    const int nc_ = H.n_chains, S_ = H.S, nh = 3 * H.E;
     const int type = cur.type, idx = cur.idx, evt = cur.evt, dec_w = cur.dec_w;
     const double g = cur.g, r_ring = cur.r, logr_ring = cur.logr;
     const bool partial = evt > 0 && iter > 1;       // hypo_tremor_mcmc.f90:246
@@ -340,7 +394,7 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
     const int gnx = (type == 1 || type == 3) ? 1 : (type == 2 || type == 4) ? S_ : nh;
     const int o = goff + c * gnx + idx;             // element of the rank's parameter vector this step perturbs
     const int ev = partial ? evt - 1 : 0;
-    const double *tc = cs.xall + off_tc + c * S_, *ac = cs.xall + off_ac + c * S_;
+    const double *tc = H.xall + off_tc + c * S_, *ac = H.xall + off_ac + c * S_;
     // the book of this chain: is this step's order out already, and how
     const int book_pos = sh.ob_pos[c], book_mode = sh.ob_mode[c], book_mid = sh.ob_mid[c];
     const unsigned book_tag = sh.ob_tag[c];
@@ -357,23 +411,23 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
         if (__builtin_expect(own_evt, 0)) {
             d_e = __builtin_amdgcn_readfirstlane(book_mid >> 3) - 1;
             const int vzd = opaque_zero();
-            const double *hypd = cs.xall + off_hy + c * nh + 3 * d_e;
+            const double *hypd = H.xall + off_hy + c * nh + 3 * d_e;
             d_ex = ld_state(hypd, vzd); d_ey = ld_state(hypd + 1, vzd); d_ez = ld_state(hypd + 2, vzd);
             // (the step in between is the chain's latest: if its commit is still waiting to be issued, memory has the old value)
             const int od = off_hy + c * nh + 3 * d_e;
             if (df.commit_o == od) d_ex = df.commit_x;
             if (df.commit_o == od + 1) d_ey = df.commit_x;
             if (df.commit_o == od + 2) d_ez = df.commit_x;
-            load_sta_regs<NCH>(st, f.S, lane, s_sx, s_sy, s_sz, tc, ac, 0, -1, 0.0);
-            load_obs_regs<NCH, F32>(ob, f, d_e, lane);
+            load_sta_regs<NCH>(st, H.S, lane, s_sx, s_sy, s_sz, tc, ac, 0, -1, 0.0);
+            load_obs_regs<NCH, F32>(ob, H, d_e, lane);
         } else if (partial) {
 #pragma unroll
             for (int k = 0; k < NCH; ++k) {
                 st.sx[k] = rsx[k]; st.sy[k] = rsy[k]; st.sz[k] = rsz[k]; st.tc[k] = cur.tc[k]; st.ac[k] = cur.ac[k];
                 ob.tob[k] = cur.tob[k]; ob.tpr[k] = cur.tpr[k]; ob.aob[k] = cur.aob[k]; ob.apr[k] = cur.apr[k];
             }
-            ob.rpst = f.use_time ? rl_f64(cur.gB, 3) : 1.0;
-            ob.rpsa = f.use_amp ? rl_f64(cur.gB, 4) : 1.0;
+            ob.rpst = H.use_time ? rl_f64(cur.gB, 3) : 1.0;
+            ob.rpsa = H.use_amp ? rl_f64(cur.gB, 4) : 1.0;
         }
     }
     FSTAMP(0);
@@ -382,21 +436,9 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
     const double beta = rg.mx[c], q = rg.mx[off_qs + c];
     const double mu = rl_f64(cur.gB, 0), rs2 = rl_f64(cur.gB, 1), step = rl_f64(cur.gB, 2);
     const int ptype = __builtin_amdgcn_readfirstlane(cur.pt);
-    // ---- everything this step had requested is in: the stores of the step before go out now (see Deferred), and the round
-    // ---- of the LDS window of the stream rings that chain 0's wave owes per step is requested (stored behind the evaluation)
+    // ---- everything this step had requested is in: the stores of the step before go out now (see Deferred)
     drain_vmem();
-    flow_issue(cs, df, lane, launch);
-    PfRegs pf;
-    pf.p = -1;
-    int fill_to = 0;
-    if (ext) {
-        const int fl = sh.fill;
-        // (this step is chain c's: the iteration's base lies 4 c .. 6 c positions back; the other waves may still read `back`
-        // positions behind it, and want `look` positions ahead of it)
-        fill_to = min(min(p - 4 * c + look, sh.avail), p - 6 * c - back + M + 1);
-        if (fill_to > fl + 64) fill_to = fl + 64;
-        if (fill_to > fl) pf_load(pf, cs, sh, fl + lane, fill_to);
-    }
+    flow_issue(H, df, lane, launch);
     const double L_cur = sh.L[c];
     const double x_new = x_old + g * step;                      // cls_model.f90:172
     const double da = x_new - mu, db = x_old - mu;
@@ -413,7 +455,7 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
     if (c == nc_ - 1) {                                         // where this iteration's swap starts, and what it draws there
         const int E = p + cnt, k4 = iter & 3;
         int i1, i2, nd;
-        flow_swap_at(cs, sh, rg, E, 1 << 30, i1, i2, nd);
+        flow_swap_at(H.n_all, rg, E, 1 << 30, i1, i2, nd);
         if (lane == 0) {
             sh.sw_i1[k4] = i1; sh.sw_i2[k4] = i2; sh.sw_nd[k4] = nd;
             if (nd > 0) { sh.sw_r[k4] = rg.U[(E + nd - 1) & M]; sh.sw_logr[k4] = rg.LOGU[(E + nd - 1) & M]; }
@@ -432,7 +474,7 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
         const int rcn = same_it ? W.rc : W.rc1, rpn = same_it ? W.rpos : W.rpos1;
         if (ok != 0 && rpn >= 0 && cn >= rcn && itn <= sh.c.iter_target) {
             const int pn = hop_ahead(rg, rpn, cn - rcn);
-            if (pn + 16 < sh.fill) flow_request<NCH, F32>(f, cs, rg, W, nx, itn, cn, pn, lane);
+            if (pn + 16 < sh.fill) flow_request<NCH, F32>(H, rg, W, nx, itn, cn, pn, lane);
         }
     }
     // ---- the orders this chain may send ahead after this step (what role P does for all chains in step_body): its next
@@ -467,7 +509,7 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
             const int jgoff = jt == 1 ? 0 : jt == 2 ? nc_ : jt == 3 ? nc_ + nc_ * S_ : 2 * nc_ + nc_ * S_;
             pl.jo = jgoff + c * ((jt == 1 || jt == 3) ? 1 : S_) + ji;
             pl.jx_old = rg.mx[pl.jo];                                         // LDS mirror (this step's own commit: below)
-            pl.jstep = rg.mir_steps ? rg.mstep[pl.jo] : cs.stall[pl.jo + opaque_zero()];
+            pl.jstep = rg.mir_steps ? rg.mstep[pl.jo] : H.stall[pl.jo + opaque_zero()];
             pl.jg = rg.pg[pj & M];
             pl.mode = mode; pl.pj = pj; pl.jt = jt; pl.ji = ji; pl.mid = d1x | (d1z << 3); pl.o_mid = off_hy + c * nh + d1y;
         }
@@ -482,8 +524,8 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
             const double py[2] = {hy, cmp == 1 ? x_new : hy};
             const double pz[2] = {hz, cmp == 2 ? x_new : hz};
             double out[2];
-            if constexpr (NCH > 0) event_misfit<NCH, 2, F32>(f, ob, lane, st, px, py, pz, beta, q, out);
-            else event_misfit_generic<2>(f, ev, lane, s_sx, s_sy, s_sz, tc, ac, 0, -1, 0.0, px, py, pz, beta, q, out);
+            if constexpr (NCH > 0) event_misfit<NCH, 2, F32>(H, ob, lane, st, px, py, pz, beta, q, out);
+            else event_misfit_generic<2>(H, ev, lane, s_sx, s_sy, s_sz, tc, ac, 0, -1, 0.0, px, py, pz, beta, q, out);
             L_new = L_cur + wave_sum1(out[0] - out[1]);
         } else {
             need_full = 1;
@@ -499,17 +541,17 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
             // every chain-state store of this wave has landed before a worker can see the order (write-through stores,
             // drained here; an order sent ahead names the commit the workers have to see instead)
             if (!pre) drain_vmem();
-            if (!pre && lane < cs.slot_rep * kGranPerSlot) {
+            if (!pre && lane < H.slot_rep * kGranPerSlot) {
                 const int gi = lane & 7;
                 const unsigned long long xb = (unsigned long long)__double_as_longlong(x_new);
                 const unsigned pay = gi == 0 ? (unsigned)launch : gi == 1 ? ((unsigned)type | ((unsigned)idx << 3))
                                    : gi == 2 ? (unsigned)(xb >> 32) : gi == 3 ? (unsigned)xb
                                    : gi == 4 ? 0xffffffffu : 0u;          // no commit to wait for (drained above), nothing left out
-                st_gran(cs.slots + (size_t)(lane >> 3) * cs.slot_stride + c * kGranPerSlot + gi, tag, pay);
+                st_gran(H.slots + (size_t)(lane >> 3) * H.slot_stride + c * kGranPerSlot + gi, tag, pay);
             }
             // ---- the workers' partial sums: tagged granules, fixed summation order; two rounds of loads in flight --
-            const unsigned long long *pg = cs.pgran + (size_t)c * cs.n_wg * cs.pgran_stride;
-            const int pgs = cs.pgran_stride;
+            const unsigned long long *pg = H.pgran + (size_t)c * H.n_wg * H.pgran_stride;
+            const int pgs = H.pgran_stride;
             double part = 0.0;
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz
             constexpr int kSweep = 4;                 // <= 256 workers (host-checked)
@@ -520,14 +562,14 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
                 for (int j = 0; j < kSweep; ++j) {
                     const int k = j * 64 + lane;
                     hi[b][j] = 0; lo[b][j] = 0;
-                    if (k < cs.n_wg) { hi[b][j] = ld_agent(pg + (size_t)pgs * k); lo[b][j] = ld_agent(pg + (size_t)pgs * k + 1); }
+                    if (k < H.n_wg) { hi[b][j] = ld_agent(pg + (size_t)pgs * k); lo[b][j] = ld_agent(pg + (size_t)pgs * k + 1); }
                 }
             };
             auto complete = [&](int b) __attribute__((always_inline)) {
                 bool got = true;
 #pragma unroll
                 for (int j = 0; j < kSweep; ++j)
-                    if (j * 64 + lane < cs.n_wg) got = got && (unsigned)(hi[b][j] >> 32) == tag && (unsigned)(lo[b][j] >> 32) == tag;
+                    if (j * 64 + lane < H.n_wg) got = got && (unsigned)(hi[b][j] >> 32) == tag && (unsigned)(lo[b][j] >> 32) == tag;
                 return __all(got);
             };
             // an order sent two steps ahead was answered a step ago: its granules are requested now, under the evaluation
@@ -548,7 +590,7 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
                     }
                     const double pxd[1] = {d_ex}, pyd[1] = {d_ey}, pzd[1] = {d_ez};
                     double outd[1];
-                    event_misfit<NCH, 1, F32>(f, ob, lane, st, pxd, pyd, pzd, type == 1 ? x_new : beta, type == 3 ? x_new : q, outd);
+                    event_misfit<NCH, 1, F32>(H, ob, lane, st, pxd, pyd, pzd, type == 1 ? x_new : beta, type == 3 ? x_new : q, outd);
                     own_lane = outd[0];
                 }
             }
@@ -581,14 +623,23 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
 #endif
 #pragma unroll
             for (int j = 0; j < kSweep; ++j)            // fixed order: worker lane, lane + 64, ...
-                if (j * 64 < cs.n_wg)
-                    part += (j * 64 + lane < cs.n_wg) ? (which == 0 ? gran_f64(hi[0][j], lo[0][j]) : gran_f64(hi[1][j], lo[1][j])) : 0.0;
-            L_new = -wave_sum1(part + own_lane) - f.const_sum;       // cls_forward.f90:277-300
+                if (j * 64 < H.n_wg)
+                    part += (j * 64 + lane < H.n_wg) ? (which == 0 ? gran_f64(hi[0][j], lo[0][j]) : gran_f64(hi[1][j], lo[1][j])) : 0.0;
+            L_new = -wave_sum1(part + own_lane) - H.const_sum;       // cls_forward.f90:277-300
         }
     }
-    if (ext && fill_to > sh.fill) {
-        pf_store(pf, rg);
-        if (lane == 0) lds_st(&sh.fill, fill_to);
+    // ---- the round of the LDS window of the stream rings that chain 0's wave owes per step: requested here, behind the
+    // ---- evaluation (whose registers are free again), stored at the end of the step
+    PfRegs pf;
+    pf.p = -1;
+    int fill_to = 0;
+    if (ext) {
+        const int fl = sh.fill;
+        // (this step is chain c's: the iteration's base lies 4 c .. 6 c positions back; the other waves may still read `back`
+        // positions behind it, and want `look` positions ahead of it)
+        fill_to = min(min(p - 4 * c + look, sh.avail), p - 6 * c - back + M + 1);
+        if (fill_to > fl + 64) fill_to = fl + 64;
+        if (fill_to > fl) flow_pf_load(pf, sh, fl + lane, fill_to);
     }
     FSTAMP(2);
 
@@ -602,8 +653,8 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
             const int e = lds_ld(&sh.epoch);
             if (__builtin_expect(e != W.epoch, 0)) {
                 bool stands = false;
-                if (!flow_adopt(cs, sh, rg, W, e, iter, c, true, stands)) continue;
-                flow_void_books(cs, sh, wave, NW, nc_, lane);
+                if (!flow_adopt(H, sh, rg, W, e, iter, c, true, stands)) continue;
+                flow_void_books(H, sh, wave, NW, nc_, lane);
                 df.ord_c = -1;                   // (an order not yet issued is void with the book)
                 nx.p = -1;                       // (requested for a position of the old epoch)
                 if (!stands) return kFlowRestart;
@@ -629,7 +680,7 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
     double T = sh.T4[par][c], rT = sh.rT4[par][c];        // (first iteration of a launch: written by the prologue)
     if (iter - 1 > sh.i0) {
         T = sh.T4[ppar][c]; rT = sh.rT4[ppar][c];
-        if (cs.n_procs * nc_ > 1) {
+        if (H.n_all > 1) {
             // (written by the last chain's wave before it published its check; this step's turn has seen that check)
             const int i1 = lds_ld(&sh.sw_i1[ppar]), i2 = sh.sw_i2[ppar];
             if (c == i1 || c == i2) {
@@ -671,7 +722,7 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
     if (acc) {
         // the store to the chain's state in memory: at the start of the wave's next step (Deferred) -- unless this step's
         // sample record is about to read the state back
-        if (rec_now && cool) { if (lane == 0) st_agent(cs.xall + o, x_new); }
+        if (rec_now && cool) { if (lane == 0) st_agent(H.xall + o, x_new); }
         else { df.commit_o = o; df.commit_x = x_new; }
         flow_patch<N>(nx, c, type, idx, evt, o, x_new, lane, nc_, S_, nh);
     }
@@ -686,8 +737,8 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
         }
         bool stands = false;
         // (this wave's own view: as any wave whose step stands before the anchor; a later rejection may already have moved on)
-        while (!flow_adopt(cs, sh, rg, W, lds_ld(&sh.epoch), iter, c, true, stands)) { }
-        flow_void_books(cs, sh, wave, NW, nc_, lane);
+        while (!flow_adopt(H, sh, rg, W, lds_ld(&sh.epoch), iter, c, true, stands)) { }
+        flow_void_books(H, sh, wave, NW, nc_, lane);
         df.ord_c = -1;
         nx.p = -1;
     }
@@ -751,9 +802,13 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
             df.ord_rep = mode == 2 ? (unsigned)pl.o_mid + 1u : 0u;
         }
     }
+    if (ext && fill_to > sh.fill) {
+        pf_store(pf, rg);
+        if (lane == 0) lds_st(&sh.fill, fill_to);
+    }
 #ifdef HTM_STAMPS
     FSTAMP(5);
-    if (lane == 0 && cs.stamps) {
+    if (lane == 0 && H.stamps) {
         unsigned long long *a = sh.stamp_acc + 12 * (wave & 7);
         if (need_full) { a[6] += t_last - t_step0; a[8] += 1; a[10] += t_wait; }
         else { for (int k = 0; k < 6; ++k) a[k] += st_acc[k]; a[7] += 1; }
@@ -816,6 +871,9 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
         sh.epoch = 0; sh.anch[0] = 0ull; sh.anch[1] = 0ull;
         sh.i0 = sh.c.iter_done; sh.last_iter = sh.c.iter_target; sh.stop_code = 0;
         sh.n_full_w = 0ull; sh.n_part_w = 0ull;
+        sh.sd.raw = cs.stream.raw; sh.sd.U = cs.stream.U; sh.sd.LOGU = cs.stream.LOGU; sh.sd.G = cs.stream.G; sh.sd.dec = cs.stream.dec;
+        sh.sd.pg = cs.stream.pg; sh.sd.pr = cs.stream.pr; sh.sd.plogr = cs.stream.plogr; sh.sd.hop = cs.stream.hop; sh.sd.sw = cs.stream.sw;
+        sh.sd.mask = cs.stream.mask; sh.sd.gen = cs.stream.gen; sh.sd.hop_end = cs.stream.hop_end;
     }
     __syncthreads();
     const int i0 = sh.i0;
@@ -843,10 +901,12 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
     const int n_int = cs.n_interval;
     int rec_phase = (i0 + 1) % n_int;                            // iteration % n_interval, kept by increments
 
+    FlowHot H;
+    flow_hot_load(f, cs, H);
     FlowWave W;
     W.epoch = 0; W.akey = 0; W.rc = 0; W.rpos = 0;
-    W.rc1 = 0; W.rpos1 = flow_next_base(cs, sh, rg, 0, nc, sh.fill);
-    W.B2 = flow_next_base(cs, sh, rg, W.rpos1, nc, sh.fill);
+    W.rc1 = 0; W.rpos1 = flow_next_base(H.n_all, rg, 0, nc, sh.fill);
+    W.B2 = flow_next_base(H.n_all, rg, W.rpos1, nc, sh.fill);
     constexpr int N = NCH > 0 ? NCH : 1;
     // station coordinates of this wave's lanes: resident in registers for the whole launch
     double rsx[N], rsy[N], rsz[N];
@@ -875,16 +935,16 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
             const int e = lds_ld(&sh.epoch);
             if (__builtin_expect(e != W.epoch, 0)) {
                 bool stands = false;
-                if (!flow_adopt(cs, sh, rg, W, e, iter, c, false, stands)) continue;
-                flow_void_books(cs, sh, wave, NW, nc, lane);
+                if (!flow_adopt(H, sh, rg, W, e, iter, c, false, stands)) continue;
+                flow_void_books(H, sh, wave, NW, nc, lane);
                 df.ord_c = -1;
                 nx.p = -1;
             }
         }
         if (iter > lds_ld(&sh.last_iter) || sh.c.err != 0) break;
         if (__builtin_expect(W.rpos1 < 0 || W.B2 < 0, 0)) {      // predictions the window did not cover when they were made
-            if (W.rpos1 < 0) { W.rpos1 = flow_next_base(cs, sh, rg, W.rpos, nc - W.rc, sh.fill); W.rc1 = 0; }
-            if (W.B2 < 0 && W.rpos1 >= 0) W.B2 = flow_next_base(cs, sh, rg, W.rpos1, nc - W.rc1, sh.fill);
+            if (W.rpos1 < 0) { W.rpos1 = flow_next_base(H.n_all, rg, W.rpos, nc - W.rc, sh.fill); W.rc1 = 0; }
+            if (W.B2 < 0 && W.rpos1 >= 0) W.B2 = flow_next_base(H.n_all, rg, W.rpos1, nc - W.rc1, sh.fill);
         }
         if (__builtin_expect(nx.p < 0 || nx.it != iter || nx.c != c || nx.epoch != W.epoch, 0)) {
             // nothing (valid) was requested ahead for this step -- first step of a launch, after an epoch change, or the
@@ -902,8 +962,8 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
                 if (dead) { if (lane == 0 && sh.c.err == 0) sh.c.err = -13; break; }
             }
             // (the request reads the chain's state: a commit still waiting to be issued goes out first)
-            flow_issue(cs, df, lane, launch);
-            flow_request<NCH, F32>(f, cs, rg, W, nx, iter, c, p, lane);
+            flow_issue(H, df, lane, launch);
+            flow_request<NCH, F32>(H, rg, W, nx, iter, c, p, lane);
         }
         const StepIn<N> cur = nx;
         if (wave == 0 && c == 0 && lane == 0) {
@@ -914,7 +974,7 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
             else if (sh.avail < cur.p + 3 * wd + 32) code = 2;
             if (code && lds_ld(&sh.last_iter) > iter) { sh.stop_code = code; lds_st(&sh.last_iter, iter); }
         }
-        const int r = flow_step<NCH, F32>(f, cs, sh, rg, W, cur, nx, df, rsx, rsy, rsz, s_sx, s_sy, s_sz, lane, wave, NW, launch,
+        const int r = flow_step<NCH, F32>(H, cs, sh, rg, W, cur, nx, df, rsx, rsy, rsz, s_sx, s_sy, s_sz, lane, wave, NW, launch,
                                           wave == 0, look, back, rec_phase == 1);
         if (r == kFlowRestart) continue;
         if (r == kFlowAbort) break;
@@ -925,17 +985,17 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
             iter += 1;
             rec_phase = rec_phase + 1 == n_int ? 0 : rec_phase + 1;
             if (W.rpos1 < 0) {    // (the window did not cover the prediction when it was made: it does now)
-                W.rpos1 = flow_next_base(cs, sh, rg, W.rpos, nc - W.rc, 1 << 30); W.rc1 = 0;
+                W.rpos1 = flow_next_base(H.n_all, rg, W.rpos, nc - W.rc, 1 << 30); W.rc1 = 0;
                 W.B2 = -1;
             }
             W.rc = W.rc1; W.rpos = W.rpos1;
-            W.rc1 = 0; W.rpos1 = W.B2 >= 0 ? W.B2 : flow_next_base(cs, sh, rg, W.rpos, nc - W.rc, sh.fill);
-            W.B2 = flow_next_base(cs, sh, rg, W.rpos1, nc, sh.fill);
+            W.rc1 = 0; W.rpos1 = W.B2 >= 0 ? W.B2 : flow_next_base(H.n_all, rg, W.rpos, nc - W.rc, sh.fill);
+            W.B2 = flow_next_base(H.n_all, rg, W.rpos1, nc, sh.fill);
         }
     }
-    flow_issue(cs, df, lane, launch);      // the last step's stores
+    flow_issue(H, df, lane, launch);      // the last step's stores
 #ifdef HTM_STAMPS
-    if (lane == 0 && cs.stamps && wave < 8) sh.stamp_acc[12 * wave + 11] += __builtin_amdgcn_s_memtime() - t_loop0;
+    if (lane == 0 && H.stamps && wave < 8) sh.stamp_acc[12 * wave + 11] += __builtin_amdgcn_s_memtime() - t_loop0;
 #endif
     __syncthreads();
 #ifdef HTM_STAMPS
