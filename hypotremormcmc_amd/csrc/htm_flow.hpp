@@ -25,6 +25,8 @@
 #pragma once
 #include "htm_step.hpp"
 
+#define HTM_G __attribute__((address_space(1)))      // the global address space, stated where the compiler cannot infer it
+
 namespace htm {
 
 struct FlowShared : StepShared {
@@ -58,18 +60,23 @@ __device__ __forceinline__ void flow_pf_load(PfRegs &r, const FlowShared &sh, in
     if (p < limit) {
         const StreamDev &sd = sh.sd;
         const long long g = (sh.origin + p) & sd.mask;
-        r.U = sd.U[g]; r.LOGU = sd.LOGU[g]; r.pg = sd.pg[g]; r.pr = sd.pr[g]; r.plogr = sd.plogr[g];
-        r.dec = reinterpret_cast<const i32x4 *>(sd.dec)[g]; r.sw = reinterpret_cast<const i32x4 *>(sd.sw)[g];
-        const i32x4 *hs = reinterpret_cast<const i32x4 *>(sd.hop + g * kHops);
+        typedef const double HTM_G *gd; typedef const i32x4 HTM_G *gv;      // (pointers read from LDS: the address space is stated)
+        r.U = ((gd)sd.U)[g]; r.LOGU = ((gd)sd.LOGU)[g]; r.pg = ((gd)sd.pg)[g]; r.pr = ((gd)sd.pr)[g]; r.plogr = ((gd)sd.plogr)[g];
+        r.dec = ((gv)sd.dec)[g]; r.sw = ((gv)sd.sw)[g];
+        const gv hs = (gv)(sd.hop + g * kHops);
         r.h0 = hs[0]; r.h1 = hs[1];
         r.p = p;
     }
 }
 
+// a wave-uniform value that reached a vector register (read from LDS, or the result of a vector compare) back in a scalar
+// one: branches on it are scalar branches and the arithmetic behind it scalar arithmetic, not lane-masked code
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 // LDS words shared between the waves: relaxed accesses in program order.  LDS operations of a wave are executed in
 // issue order and the LDS is one serialisation point for the workgroup, so "release" and "acquire" are compiler
 // barriers here, not waits for outstanding memory operations.
-__device__ __forceinline__ int lds_ld(const int *p) { const int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); asm volatile("" ::: "memory"); return v; }
+__device__ __forceinline__ int lds_ld(const int *p) { const int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); asm volatile("" ::: "memory"); return uni(v); }   // (every int read this way is at a wave-uniform address)
 __device__ __forceinline__ unsigned long long lds_ld(const unsigned long long *p) { const unsigned long long v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); asm volatile("" ::: "memory"); return v; }
 __device__ __forceinline__ void lds_st(int *p, int v) { asm volatile("" ::: "memory"); __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_st(unsigned long long *p, unsigned long long v) { asm volatile("" ::: "memory"); __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -85,6 +92,8 @@ struct FlowWave {                 // a wave's predictions (wave-uniform)
 // a v_readlane) -- read at their uses (htm_step.hpp's rule for the 256-register kernels) each group of them is a scalar-cache
 // round trip the wave waits for: a dozen per step, ~2.4 k of its 12 k cycles.  Member names as in FwdDev / ChainsDev, so that
 // the forward model's templates (event_misfit, load_obs_regs) take it in place of the forward object.
+// (launder() keeps the global address space visible: a pointer that went through a register move the compiler cannot see
+// through would be accessed with FLAT instructions otherwise -- which also count as LDS operations in every lgkmcnt wait)
 struct FlowHot {
     int S, E, use_time, use_amp;
     const double *t_obs, *t_prec, *a_obs, *a_prec, *rpsum_t, *rpsum_a;
@@ -99,7 +108,7 @@ struct FlowHot {
     unsigned long long *stamps;
 };
 template <class T>
-__device__ __forceinline__ void launder(T *&p) { asm volatile("" : "+s"(p)); }
+__device__ __forceinline__ void launder(T *&p) { T HTM_G *q = (T HTM_G *)p; asm volatile("" : "+s"(q)); p = (T *)q; }
 __device__ __forceinline__ void launder(int &v) { asm volatile("" : "+s"(v)); }
 __device__ __forceinline__ void flow_hot_load(FwRef f_, CsRef cs_, FlowHot &H)
 {
@@ -145,13 +154,14 @@ __device__ __forceinline__ bool flow_swap_at(int n_all, const Ring &rg, int E, i
     if (n_all <= 1) return true;
     if (E + 2 >= limit) return false;
     const i32x4 sw = reinterpret_cast<const i32x4 *>(rg.sw)[E & rg.mask];
-    if (sw.z > 0) { i1 = sw.x; i2 = sw.y; nd = sw.z + 1; return E + nd < limit; }
+    const int swz = uni(sw.z);
+    if (swz > 0) { i1 = uni(sw.x); i2 = uni(sw.y); nd = swz + 1; return E + nd < limit; }
     int pos = E;
-    i1 = (int)(rg.U[pos & rg.mask] * n_all);          // (= rand_u * n_proc * n_chain, cls_parallel.f90:226: one rank here)
+    i1 = uni((int)(rg.U[pos & rg.mask] * n_all));     // (= rand_u * n_proc * n_chain, cls_parallel.f90:226: one rank here)
     pos++;
     for (;;) {
         if (pos + 1 >= limit) return false;
-        i2 = (int)(rg.U[pos & rg.mask] * n_all);
+        i2 = uni((int)(rg.U[pos & rg.mask] * n_all));
         pos++;
         if (i1 != i2) break;
     }
@@ -163,7 +173,7 @@ __device__ __forceinline__ bool flow_swap_at(int n_all, const Ring &rg, int E, i
 __device__ __forceinline__ int flow_next_base(int n_all, const Ring &rg, int pos, int n, int limit)
 {
     if (pos < 0) return -1;
-    const int E = hop_ahead(rg, pos, n);
+    const int E = uni(hop_ahead(rg, pos, n));
     int i1, i2, nd;
     if (E + 16 >= limit || !flow_swap_at(n_all, rg, E, limit, i1, i2, nd)) return -1;
     return E + nd;
@@ -174,8 +184,8 @@ __device__ __forceinline__ int flow_next_base(int n_all, const Ring &rg, int pos
 __device__ __forceinline__ void flow_from_anchor(const FlowHot &H, const FlowShared &sh, const Ring &rg, unsigned long long a, int &ia, int &ca, int &ap)
 {
     const int nc = H.n_chains;
-    const int key = (int)(unsigned)(a >> 32), pos = (int)(unsigned)a;
-    ia = sh.i0 + key / nc; ca = key - (key / nc) * nc; ap = pos;
+    const int key = uni((int)(unsigned)(a >> 32)), pos = uni((int)(unsigned)a);
+    ia = uni(sh.i0) + key / nc; ca = key - (key / nc) * nc; ap = pos;
     if (ca == 0) {
         int i1, i2, nd;
         flow_swap_at(H.n_all, rg, pos, 1 << 30, i1, i2, nd);     // (the rejected step's own wave read these positions: covered)
@@ -187,7 +197,7 @@ __device__ __forceinline__ void flow_from_anchor(const FlowHot &H, const FlowSha
 __device__ __forceinline__ void flow_void_books(const FlowHot &H, FlowShared &sh, int wave, int NW, int nc, int lane)
 {
     for (int c = wave; c < nc; c += NW) {
-        if (sh.ob_pos[c] != -1) {
+        if (uni(sh.ob_pos[c]) != -1) {
             if (lane == 0) {
                 for (int r = 0; r < H.slot_rep; ++r) st_gran(H.slots + (size_t)r * H.slot_stride + c * kGranPerSlot, 0u, 0u);   // (void_slot)
                 sh.ob_pos[c] = -1;
@@ -204,11 +214,11 @@ __device__ __forceinline__ bool flow_adopt(const FlowHot &H, FlowShared &sh, con
     const int nc = H.n_chains;
     const unsigned long long a = lds_ld(&sh.anch[e & 1]);
     if (lds_ld(&sh.epoch) != e) return false;
-    const int akey = (int)(unsigned)(a >> 32);
-    const int key = (it - sh.i0) * nc + c;
+    const int akey = uni((int)(unsigned)(a >> 32));
+    const int key = (it - uni(sh.i0)) * nc + c;
     int ia, ca, ap;
     flow_from_anchor(H, sh, rg, a, ia, ca, ap);
-    const int limit = sh.fill;
+    const int limit = uni(sh.fill);
     stands = in_turn && key < akey;
     W.epoch = e; W.akey = akey;
     if (!stands) {
@@ -396,8 +406,8 @@ __device__ __forceinline__ int flow_step(const FlowHot &H, CsRef cs_, FlowShared
     const int ev = partial ? evt - 1 : 0;
     const double *tc = H.xall + off_tc + c * S_, *ac = H.xall + off_ac + c * S_;
     // the book of this chain: is this step's order out already, and how
-    const int book_pos = sh.ob_pos[c], book_mode = sh.ob_mode[c], book_mid = sh.ob_mid[c];
-    const unsigned book_tag = sh.ob_tag[c];
+    const int book_pos = uni(sh.ob_pos[c]), book_mode = uni(sh.ob_mode[c]), book_mid = uni(sh.ob_mid[c]);
+    const unsigned book_tag = (unsigned)uni((int)sh.ob_tag[c]);
     const bool pre = !partial && book_pos == p;
     const int pre_mode = pre ? book_mode : 0;
     // a full-evaluation step whose order went out two steps ahead adds the event of the step in between itself (below):
@@ -448,9 +458,11 @@ __device__ __forceinline__ int flow_step(const FlowHot &H, CsRef cs_, FlowShared
         if (x_new <= mu) { lpr = (double)-1.0e+30f; ok = 0; }
         else lpr = lpr + log(x_new - mu) - log(x_old - mu);
     }
+    ok = uni(ok);
     const double r = ok ? r_ring : 0.0, logr = ok ? logr_ring : 0.0;
     const int cnt = dec_w - 1 + ok;                             // the judge draw happens only if prior_ok
-    const int key = (iter - sh.i0) * nc_ + c;
+    const int i0_ = uni(sh.i0), fill_ = uni(sh.fill), it_target = uni(sh.c.iter_target);
+    const int key = (iter - i0_) * nc_ + c;
     // ---- the step has passed (or failed) its prior check: the later steps may go ahead on it
     if (c == nc_ - 1) {                                         // where this iteration's swap starts, and what it draws there
         const int E = p + cnt, k4 = iter & 3;
@@ -472,9 +484,9 @@ __device__ __forceinline__ int flow_step(const FlowHot &H, CsRef cs_, FlowShared
         const bool same_it = cn > c;
         const int itn = same_it ? iter : iter + 1;
         const int rcn = same_it ? W.rc : W.rc1, rpn = same_it ? W.rpos : W.rpos1;
-        if (ok != 0 && rpn >= 0 && cn >= rcn && itn <= sh.c.iter_target) {
-            const int pn = hop_ahead(rg, rpn, cn - rcn);
-            if (pn + 16 < sh.fill) flow_request<NCH, F32>(H, rg, W, nx, itn, cn, pn, lane);
+        if (ok != 0 && rpn >= 0 && cn >= rcn && itn <= it_target) {
+            const int pn = uni(hop_ahead(rg, rpn, cn - rcn));
+            if (pn + 16 < fill_) flow_request<NCH, F32>(H, rg, W, nx, itn, cn, pn, lane);
         }
     }
     // ---- the orders this chain may send ahead after this step (what role P does for all chains in step_body): its next
@@ -484,25 +496,26 @@ __device__ __forceinline__ int flow_step(const FlowHot &H, CsRef cs_, FlowShared
     // ---- the order was written for, and an epoch change voids the book.
     PlanIn pl;
     pl.mode = 0; pl.epoch = W.epoch; pl.pj = 0; pl.jt = 0; pl.ji = 0; pl.jo = 0; pl.mid = 0; pl.o_mid = -1; pl.jx_old = 0.0; pl.jstep = 0.0; pl.jg = 0.0;
-    if (rg.mir_n > 0 && (book_pos == -1 || book_pos == p) && ok != 0 && iter + 1 <= sh.c.iter_target) {
-        const int lim = sh.fill - 8;
+    if (rg.mir_n > 0 && (book_pos == -1 || book_pos == p) && ok != 0 && iter + 1 <= it_target) {
+        const int lim = fill_ - 8;
         int p1 = -1, d1x = 0, d1y = 0, d1z = 0;
         if (nx.p >= 0 && nx.c == c) { p1 = nx.p; d1x = nx.type; d1y = nx.idx; d1z = nx.evt; }     // (a wave with one chain)
         else if (W.rpos1 >= 0 && c >= W.rc1) {
-            p1 = hop_ahead(rg, W.rpos1, c - W.rc1);
+            p1 = uni(hop_ahead(rg, W.rpos1, c - W.rc1));
             if (p1 < lim) {
                 const i32x4 d1 = reinterpret_cast<const i32x4 *>(rg.dec)[p1 & M];
-                d1x = d1.x; d1y = d1.y; d1z = d1.z;
+                d1x = uni(d1.x); d1y = uni(d1.y); d1z = uni(d1.z);
             } else p1 = -1;
         }
         const bool w1 = p1 >= 0;
         const bool job1 = w1 && d1x >= 1 && d1x <= 4;
         int mode = job1 ? 1 : 0, pj = p1, jt = d1x, ji = d1y;
-        if (HTM_ALLOW2 && NCH > 0 && w1 && !job1 && iter + 2 <= sh.c.iter_target && W.B2 >= 0) {
-            const int p2 = hop_ahead(rg, W.B2, c);
+        if (HTM_ALLOW2 && NCH > 0 && w1 && !job1 && iter + 2 <= it_target && W.B2 >= 0) {
+            const int p2 = uni(hop_ahead(rg, W.B2, c));
             if (p2 < lim) {
                 const i32x4 d2 = reinterpret_cast<const i32x4 *>(rg.dec)[p2 & M];
-                if (d2.x >= 1 && d2.x <= 4) { mode = 2; pj = p2; jt = d2.x; ji = d2.y; }
+                const int d2x = uni(d2.x);
+                if (d2x >= 1 && d2x <= 4) { mode = 2; pj = p2; jt = d2x; ji = uni(d2.y); }
             }
         }
         if (mode) {
@@ -646,7 +659,7 @@ __device__ __forceinline__ int flow_step(const FlowHot &H, CsRef cs_, FlowShared
     // ---- the step's turn: every step before it in stream order has passed its check in this epoch (or lies before the
     // ---- epoch's anchor: checked earlier, final).  Lanes <-> chains.
     {
-        const int key_i = (iter - sh.i0) * nc_, key_m = key_i - nc_;
+        const int key_i = (iter - i0_) * nc_, key_m = key_i - nc_;
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         for (unsigned spin = 0;; ++spin) {
             const unsigned long long pv = lane < nc_ ? lds_ld(&sh.prog[lane]) : 0ull;
@@ -678,14 +691,14 @@ __device__ __forceinline__ int flow_step(const FlowHot &H, CsRef cs_, FlowShared
     // ---- here by the waves of the two chains it concerns -- each evaluates the same expression on the same values
     const int par = iter & 3, ppar = (iter - 1) & 3;
     double T = sh.T4[par][c], rT = sh.rT4[par][c];        // (first iteration of a launch: written by the prologue)
-    if (iter - 1 > sh.i0) {
+    if (iter - 1 > i0_) {
         T = sh.T4[ppar][c]; rT = sh.rT4[ppar][c];
         if (H.n_all > 1) {
             // (written by the last chain's wave before it published its check; this step's turn has seen that check)
-            const int i1 = lds_ld(&sh.sw_i1[ppar]), i2 = sh.sw_i2[ppar];
+            const int i1 = lds_ld(&sh.sw_i1[ppar]), i2 = uni(sh.sw_i2[ppar]);
             if (c == i1 || c == i2) {
                 const int o2 = c == i1 ? i2 : i1;
-                const int want = (iter - 1 - sh.i0) * nc_ + o2;
+                const int want = (iter - 1 - i0_) * nc_ + o2;
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                 for (unsigned spin = 0; lds_ld(&sh.done[o2]) < want; ++spin) {
                     if ((spin & 15u) == 15u) {
@@ -701,11 +714,11 @@ __device__ __forceinline__ int flow_step(const FlowHot &H, CsRef cs_, FlowShared
             }
         }
     }
-    const int acc = (ok != 0 && metropolis(L_new, L_cur, rT, lpr, r, logr)) ? 1 : 0;       // cls_mcmc.f90:193-203
+    const int acc = uni((ok != 0 && metropolis(L_new, L_cur, rT, lpr, r, logr)) ? 1 : 0);       // cls_mcmc.f90:193-203
     // this wave's chain-state stores of EARLIER steps have landed before this step's commit goes out: an order sent after
     // the commit names only the commit itself for the workers to wait for
     drain_vmem();
-    const int cool = (T < 1.0 + kEps) ? 1 : 0;
+    const int cool = uni((T < 1.0 + kEps) ? 1 : 0);
     const double L_post = acc ? L_new : L_cur;
     if (lane == 0) {
         sh.T4[par][c] = T; sh.rT4[par][c] = rT;
@@ -743,8 +756,8 @@ __device__ __forceinline__ int flow_step(const FlowHot &H, CsRef cs_, FlowShared
         nx.p = -1;
     }
     // ---- records of this step (hypo_tremor_mcmc.f90:270-280): slots by LDS atomics, put in order on the host
-    if (__builtin_expect(sh.c.slog_cap > 0, 0)) {
-        const int row = sh.c.slog_n + (iter - sh.i0 - 1) * nc_ + c;
+    if (__builtin_expect(uni(sh.c.slog_cap) > 0, 0)) {
+        const int row = uni(sh.c.slog_n) + (iter - i0_ - 1) * nc_ + c;
         if (lane == 0 && row < sh.c.slog_cap) {
             int32_t *ir = cs.slog_i + 8 * (size_t)row;
             double *dr = cs.slog_d + 4 * (size_t)row;
@@ -778,7 +791,7 @@ __device__ __forceinline__ int flow_step(const FlowHot &H, CsRef cs_, FlowShared
         }
     }
     // ---- the order looked up above goes out, if this epoch still stands and the book is free
-    if (pl.mode != 0 && pl.epoch == W.epoch && sh.ob_pos[c] == -1) {
+    if (pl.mode != 0 && pl.epoch == W.epoch && uni(sh.ob_pos[c]) == -1) {
         int mode = pl.mode;
         const double jx_old = (acc && o == pl.jo) ? x_new : pl.jx_old;        // (this step's own commit of that very element)
         const double jx_new = jx_old + pl.jg * pl.jstep;                       // cls_model.f90:172, as the step will compute it
@@ -941,7 +954,7 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
                 nx.p = -1;
             }
         }
-        if (iter > lds_ld(&sh.last_iter) || sh.c.err != 0) break;
+        if (iter > lds_ld(&sh.last_iter) || lds_ld(&sh.c.err) != 0) break;
         if (__builtin_expect(W.rpos1 < 0 || W.B2 < 0, 0)) {      // predictions the window did not cover when they were made
             if (W.rpos1 < 0) { W.rpos1 = flow_next_base(H.n_all, rg, W.rpos, nc - W.rc, sh.fill); W.rc1 = 0; }
             if (W.B2 < 0 && W.rpos1 >= 0) W.B2 = flow_next_base(H.n_all, rg, W.rpos1, nc - W.rc1, sh.fill);
@@ -949,7 +962,7 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
         if (__builtin_expect(nx.p < 0 || nx.it != iter || nx.c != c || nx.epoch != W.epoch, 0)) {
             // nothing (valid) was requested ahead for this step -- first step of a launch, after an epoch change, or the
             // window did not reach: look its position up and request its inputs now
-            const int p = hop_ahead(rg, W.rpos, c - W.rc);
+            const int p = uni(hop_ahead(rg, W.rpos, c - W.rc));
             if (__builtin_expect(p + 16 >= lds_ld(&sh.fill), 0)) {
                 // the window covers every step that can run (chain 0's wave keeps it 3 iterations ahead); a fail-stop
                 if (wave == 0) { if (lane == 0) sh.c.err = -13; break; }
