@@ -260,6 +260,7 @@ __device__ __forceinline__ void flow_request(const FlowHot &H, const Ring &rg, c
                                              int it, int c, int p, int lane)
 {
     const int M = rg.mask;
+    asm volatile("" : "+v"(lane));
     n.it = it; n.c = c; n.p = p; n.epoch = W.epoch;
     const double *xall_ = H.xall, *muall_ = H.muall, *rs2all_ = H.rs2all, *stall_ = H.stall;
     const int *ptall_ = H.ptall;
@@ -387,11 +388,14 @@ __device__ __forceinline__ int flow_step(const FlowHot &H, CsRef cs_, FlowShared
 {
     constexpr int N = NCH > 0 ? NCH : 1;
     CsRef cs = rebase(cs_);      // (cold paths only: records, diagnostics; the loop's arguments are in H)
+    // (lane predicates -- lane == 0, lane < n, ... -- are one compare where they are used; as loop invariants the compiler
+    // keeps each as a 64-bit mask in a spilled scalar pair: two v_readlane per use)
+    asm volatile("" : "+v"(lane));
     const int M = rg.mask;
     const int c = cur.c, iter = cur.it;
     const int p = cur.p;
 #ifdef HTM_STAMPS
-    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_last = __builtin_amdgcn_s_memtime(), t_wait = 0;
     const unsigned long long t_step0 = t_last;
 #endif
@@ -446,9 +450,11 @@ __device__ __forceinline__ int flow_step(const FlowHot &H, CsRef cs_, FlowShared
     const double beta = rg.mx[c], q = rg.mx[off_qs + c];
     const double mu = rl_f64(cur.gB, 0), rs2 = rl_f64(cur.gB, 1), step = rl_f64(cur.gB, 2);
     const int ptype = __builtin_amdgcn_readfirstlane(cur.pt);
+    FSTAMP(6);
     // ---- everything this step had requested is in: the stores of the step before go out now (see Deferred)
     drain_vmem();
     flow_issue(H, df, lane, launch);
+    FSTAMP(7);
     const double L_cur = sh.L[c];
     const double x_new = x_old + g * step;                      // cls_model.f90:172
     const double da = x_new - mu, db = x_old - mu;
@@ -459,6 +465,7 @@ __device__ __forceinline__ int flow_step(const FlowHot &H, CsRef cs_, FlowShared
         else lpr = lpr + log(x_new - mu) - log(x_old - mu);
     }
     ok = uni(ok);
+    FSTAMP(8);
     const double r = ok ? r_ring : 0.0, logr = ok ? logr_ring : 0.0;
     const int cnt = dec_w - 1 + ok;                             // the judge draw happens only if prior_ok
     const int i0_ = uni(sh.i0), fill_ = uni(sh.fill), it_target = uni(sh.c.iter_target);
@@ -476,6 +483,7 @@ __device__ __forceinline__ int flow_step(const FlowHot &H, CsRef cs_, FlowShared
     }
     if (lane == 0)
         lds_st(&sh.prog[c], ((unsigned long long)(((unsigned)W.epoch << 1) | (ok ? 0u : 1u)) << 32) | (unsigned)key);
+    FSTAMP(9);
     // ---- the wave's NEXT step: where it starts (a prediction in this epoch), and the request of its inputs -- in flight
     // ---- under this step's evaluation, turn and commit
     nx.p = -1;
@@ -494,6 +502,7 @@ __device__ __forceinline__ int flow_step(const FlowHot &H, CsRef cs_, FlowShared
     // ---- after it (two steps ahead: the workers leave the event of the step in between out, this wave adds it).
     // ---- Looked up here from positions alone; sent after the commit.  A step uses an order only if it starts exactly where
     // ---- the order was written for, and an epoch change voids the book.
+    FSTAMP(10);
     PlanIn pl;
     pl.mode = 0; pl.epoch = W.epoch; pl.pj = 0; pl.jt = 0; pl.ji = 0; pl.jo = 0; pl.mid = 0; pl.o_mid = -1; pl.jx_old = 0.0; pl.jstep = 0.0; pl.jg = 0.0;
     if (rg.mir_n > 0 && (book_pos == -1 || book_pos == p) && ok != 0 && iter + 1 <= it_target) {
@@ -824,7 +833,7 @@ __device__ __forceinline__ int flow_step(const FlowHot &H, CsRef cs_, FlowShared
     if (lane == 0 && H.stamps) {
         unsigned long long *a = sh.stamp_acc + 12 * (wave & 7);
         if (need_full) { a[6] += t_last - t_step0; a[8] += 1; a[10] += t_wait; }
-        else { for (int k = 0; k < 6; ++k) a[k] += st_acc[k]; a[7] += 1; }
+        else { for (int k = 0; k < 6; ++k) a[k] += st_acc[k]; a[7] += 1; if (wave == 3) for (int k = 6; k < 11; ++k) atomicAdd((unsigned long long *)&H.stamps[96 + k], st_acc[k]); }
     }
 #endif
     return p + cnt;
