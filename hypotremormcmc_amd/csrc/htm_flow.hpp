@@ -25,8 +25,6 @@
 #pragma once
 #include "htm_step.hpp"
 
-#define HTM_G __attribute__((address_space(1)))      // the global address space, stated where the compiler cannot infer it
-
 namespace htm {
 
 struct FlowShared : StepShared {
@@ -50,33 +48,12 @@ struct FlowShared : StepShared {
     int ob_pos[kMaxChains], ob_mode[kMaxChains], ob_mid[kMaxChains];     // ob_mid: type | event << 3 of the step in between (mode 2)
     unsigned ob_tag[kMaxChains];
     unsigned long long n_full_w, n_part_w;
-    StreamDev sd;                          // the stream rings' addresses (chain 0's wave extends the LDS window from them every step)
 };
-
-// pf_load (htm_step.hpp) with the rings' addresses taken from LDS instead of the kernarg segment
-__device__ __forceinline__ void flow_pf_load(PfRegs &r, const FlowShared &sh, int p, int limit)
-{
-    r.p = -1;
-    if (p < limit) {
-        const StreamDev &sd = sh.sd;
-        const long long g = (sh.origin + p) & sd.mask;
-        typedef const double HTM_G *gd; typedef const i32x4 HTM_G *gv;      // (pointers read from LDS: the address space is stated)
-        r.U = ((gd)sd.U)[g]; r.LOGU = ((gd)sd.LOGU)[g]; r.pg = ((gd)sd.pg)[g]; r.pr = ((gd)sd.pr)[g]; r.plogr = ((gd)sd.plogr)[g];
-        r.dec = ((gv)sd.dec)[g]; r.sw = ((gv)sd.sw)[g];
-        const gv hs = (gv)(sd.hop + g * kHops);
-        r.h0 = hs[0]; r.h1 = hs[1];
-        r.p = p;
-    }
-}
-
-// a wave-uniform value that reached a vector register (read from LDS, or the result of a vector compare) back in a scalar
-// one: branches on it are scalar branches and the arithmetic behind it scalar arithmetic, not lane-masked code
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // LDS words shared between the waves: relaxed accesses in program order.  LDS operations of a wave are executed in
 // issue order and the LDS is one serialisation point for the workgroup, so "release" and "acquire" are compiler
 // barriers here, not waits for outstanding memory operations.
-__device__ __forceinline__ int lds_ld(const int *p) { const int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); asm volatile("" ::: "memory"); return uni(v); }   // (every int read this way is at a wave-uniform address)
+__device__ __forceinline__ int lds_ld(const int *p) { const int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); asm volatile("" ::: "memory"); return v; }
 __device__ __forceinline__ unsigned long long lds_ld(const unsigned long long *p) { const unsigned long long v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); asm volatile("" ::: "memory"); return v; }
 __device__ __forceinline__ void lds_st(int *p, int v) { asm volatile("" ::: "memory"); __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_st(unsigned long long *p, unsigned long long v) { asm volatile("" ::: "memory"); __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -88,57 +65,11 @@ struct FlowWave {                 // a wave's predictions (wave-uniform)
     int B2;                       // base of the iteration after that (orders sent ahead only); -1 = not known
 };
 
-// The kernel arguments the loop uses at every step, read ONCE per launch and kept in scalar registers (or their spill lanes:
-// a v_readlane) -- read at their uses (htm_step.hpp's rule for the 256-register kernels) each group of them is a scalar-cache
-// round trip the wave waits for: a dozen per step, ~2.4 k of its 12 k cycles.  Member names as in FwdDev / ChainsDev, so that
-// the forward model's templates (event_misfit, load_obs_regs) take it in place of the forward object.
-// (launder() keeps the global address space visible: a pointer that went through a register move the compiler cannot see
-// through would be accessed with FLAT instructions otherwise -- which also count as LDS operations in every lgkmcnt wait)
-struct FlowHot {
-    int S, E, use_time, use_amp;
-    const double *t_obs, *t_prec, *a_obs, *a_prec, *rpsum_t, *rpsum_a;
-    const float *t_obs32, *t_prec32, *a_obs32, *a_prec32;
-    double const_sum;
-    int n_chains, n_all;
-    double *xall;
-    const double *muall, *rs2all, *stall;
-    const int *ptall;
-    unsigned long long *slots, *pgran;
-    int slot_rep, slot_stride, n_wg, pgran_stride;
-    unsigned long long *stamps;
-};
-template <class T>
-__device__ __forceinline__ void launder(T *&p) { T HTM_G *q = (T HTM_G *)p; asm volatile("" : "+s"(q)); p = (T *)q; }
-__device__ __forceinline__ void launder(int &v) { asm volatile("" : "+s"(v)); }
-__device__ __forceinline__ void flow_hot_load(FwRef f_, CsRef cs_, FlowHot &H)
-{
-    CsRef cs = rebase(cs_);
-    FwRef f = rebase(f_);
-    H.S = f.S; H.E = f.E; H.use_time = f.use_time; H.use_amp = f.use_amp;
-    H.t_obs = f.t_obs; H.t_prec = f.t_prec; H.a_obs = f.a_obs; H.a_prec = f.a_prec; H.rpsum_t = f.rpsum_t; H.rpsum_a = f.rpsum_a;
-    H.t_obs32 = f.t_obs32; H.t_prec32 = f.t_prec32; H.a_obs32 = f.a_obs32; H.a_prec32 = f.a_prec32;
-    H.const_sum = f.const_sum;
-    H.n_chains = cs.n_chains; H.n_all = cs.n_procs * cs.n_chains;
-    H.xall = cs.xall; H.muall = cs.muall; H.rs2all = cs.rs2all; H.stall = cs.stall; H.ptall = cs.ptall;
-    H.slots = cs.slots; H.pgran = cs.pgran;
-    H.slot_rep = cs.slot_rep; H.slot_stride = cs.slot_stride; H.n_wg = cs.n_wg; H.pgran_stride = cs.pgran_stride;
-    H.stamps = cs.stamps;
-    // (opaque from here on: a value the compiler can re-load from the kernarg segment it would rather re-load than keep)
-    launder(H.S); launder(H.E); launder(H.use_time); launder(H.use_amp);
-    launder(H.t_obs); launder(H.t_prec); launder(H.a_obs); launder(H.a_prec); launder(H.rpsum_t); launder(H.rpsum_a);
-    launder(H.t_obs32); launder(H.t_prec32); launder(H.a_obs32); launder(H.a_prec32);
-    launder(H.n_chains); launder(H.n_all);
-    launder(H.xall); launder(H.muall); launder(H.rs2all); launder(H.stall); launder(H.ptall);
-    launder(H.slots); launder(H.pgran);
-    launder(H.slot_rep); launder(H.slot_stride); launder(H.n_wg); launder(H.pgran_stride);
-    launder(H.stamps);
-}
-
 #ifdef HTM_STAMPS
 // diagnostic cycle accounting of the free-running master (tools/flow_stamps.py): per wave, [k] ticks of phase k summed over its
 // partial-update steps (0 front: loads issued, 1 proposal + check published, 2 evaluation, 3 turn, 4 swap + decision + commit,
 // 5 records + orders), 6 ticks of its full-evaluation steps, 7 / 8 the two counts, 9 ticks between steps (loop top), 10 wait part of 6
-#define FSTAMP(k) do { if (lane == 0 && H.stamps) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_acc[k] += n_ - t_last; t_last = n_; } } while (0)
+#define FSTAMP(k) do { if (lane == 0 && cs.stamps) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_acc[k] += n_ - t_last; t_last = n_; } } while (0)
 #else
 #define FSTAMP(k) do { } while (0)
 #endif
@@ -148,20 +79,21 @@ constexpr int kFlowAbort = -2;    // flow_step: a wait gave up (sh.c.err is set)
 
 // select_pair + the judge_swap draw starting at E (cls_parallel.f90:226-230, :163): pair, draws used in all (single rank:
 // this rank draws both).  The stream service has the usual case precomputed (sw ring); more than 12 redraws follow the stream.
-__device__ __forceinline__ bool flow_swap_at(int n_all, const Ring &rg, int E, int limit, int &i1, int &i2, int &nd)
+__device__ __forceinline__ bool flow_swap_at(CsRef cs_, const StepShared &sh, const Ring &rg, int E, int limit, int &i1, int &i2, int &nd)
 {
+    CsRef cs = rebase(cs_);
+    const int n_all = cs.n_procs * cs.n_chains;
     i1 = -1; i2 = -1; nd = 0;
     if (n_all <= 1) return true;
     if (E + 2 >= limit) return false;
     const i32x4 sw = reinterpret_cast<const i32x4 *>(rg.sw)[E & rg.mask];
-    const int swz = uni(sw.z);
-    if (swz > 0) { i1 = uni(sw.x); i2 = uni(sw.y); nd = swz + 1; return E + nd < limit; }
+    if (sw.z > 0) { i1 = sw.x; i2 = sw.y; nd = sw.z + 1; return E + nd < limit; }
     int pos = E;
-    i1 = uni((int)(rg.U[pos & rg.mask] * n_all));     // (= rand_u * n_proc * n_chain, cls_parallel.f90:226: one rank here)
+    i1 = (int)(rg.U[pos & rg.mask] * cs.n_procs * cs.n_chains);
     pos++;
     for (;;) {
         if (pos + 1 >= limit) return false;
-        i2 = uni((int)(rg.U[pos & rg.mask] * n_all));
+        i2 = (int)(rg.U[pos & rg.mask] * cs.n_procs * cs.n_chains);
         pos++;
         if (i1 != i2) break;
     }
@@ -170,38 +102,36 @@ __device__ __forceinline__ bool flow_swap_at(int n_all, const Ring &rg, int E, i
 }
 
 // base of the next iteration when n chain steps of this one remain from pos; -1 if the window does not cover it
-__device__ __forceinline__ int flow_next_base(int n_all, const Ring &rg, int pos, int n, int limit)
+__device__ __forceinline__ int flow_next_base(CsRef cs, const StepShared &sh, const Ring &rg, int pos, int n, int limit)
 {
     if (pos < 0) return -1;
-    const int E = uni(hop_ahead(rg, pos, n));
+    const int E = hop_ahead(rg, pos, n);
     int i1, i2, nd;
-    if (E + 16 >= limit || !flow_swap_at(n_all, rg, E, limit, i1, i2, nd)) return -1;
+    if (E + 16 >= limit || !flow_swap_at(cs, sh, rg, E, limit, i1, i2, nd)) return -1;
     return E + nd;
 }
 
 // the anchor as (iteration, chain, position of that chain's step).  A rejected LAST step of an iteration leaves pos = the
 // end of that iteration's chain steps: chain 0 of the next iteration starts after the swap's draws.
-__device__ __forceinline__ void flow_from_anchor(const FlowHot &H, const FlowShared &sh, const Ring &rg, unsigned long long a, int &ia, int &ca, int &ap)
+__device__ __forceinline__ void flow_from_anchor(CsRef cs_, const FlowShared &sh, const Ring &rg, unsigned long long a, int &ia, int &ca, int &ap)
 {
-    const int nc = H.n_chains;
-    const int key = uni((int)(unsigned)(a >> 32)), pos = uni((int)(unsigned)a);
-    ia = uni(sh.i0) + key / nc; ca = key - (key / nc) * nc; ap = pos;
+    CsRef cs = rebase(cs_);
+    const int nc = cs.n_chains;
+    const int key = (int)(unsigned)(a >> 32), pos = (int)(unsigned)a;
+    ia = sh.i0 + key / nc; ca = key - (key / nc) * nc; ap = pos;
     if (ca == 0) {
         int i1, i2, nd;
-        flow_swap_at(H.n_all, rg, pos, 1 << 30, i1, i2, nd);     // (the rejected step's own wave read these positions: covered)
+        flow_swap_at(cs, sh, rg, pos, 1 << 30, i1, i2, nd);     // (the rejected step's own wave read these positions: covered)
         ap = pos + nd;
     }
 }
 
 // every order this wave has out for its chains is void (their positions were predicted in another epoch): the workers are told
-__device__ __forceinline__ void flow_void_books(const FlowHot &H, FlowShared &sh, int wave, int NW, int nc, int lane)
+__device__ __forceinline__ void flow_void_books(CsRef cs, FlowShared &sh, int wave, int NW, int nc, int lane)
 {
     for (int c = wave; c < nc; c += NW) {
-        if (uni(sh.ob_pos[c]) != -1) {
-            if (lane == 0) {
-                for (int r = 0; r < H.slot_rep; ++r) st_gran(H.slots + (size_t)r * H.slot_stride + c * kGranPerSlot, 0u, 0u);   // (void_slot)
-                sh.ob_pos[c] = -1;
-            }
+        if (sh.ob_pos[c] != -1) {
+            if (lane == 0) { void_slot(cs, c); sh.ob_pos[c] = -1; }
         }
     }
 }
@@ -209,133 +139,42 @@ __device__ __forceinline__ void flow_void_books(const FlowHot &H, FlowShared &sh
 // this wave adopts epoch e (read from sh.epoch a moment ago).  `standing`: its current step (it, c) has passed its check and lies
 // before the anchor -- it stands, and everything the wave runs after it starts at or after the anchor; else the current
 // step itself starts at or after the anchor.  Returns false if the epoch moved on meanwhile (the caller looks again).
-__device__ __forceinline__ bool flow_adopt(const FlowHot &H, FlowShared &sh, const Ring &rg, FlowWave &W, int e, int it, int c, bool in_turn, bool &stands)
+__device__ __forceinline__ bool flow_adopt(CsRef cs_, FlowShared &sh, const Ring &rg, FlowWave &W, int e, int it, int c, bool in_turn, bool &stands)
 {
-    const int nc = H.n_chains;
+    CsRef cs = rebase(cs_);
+    const int nc = cs.n_chains;
     const unsigned long long a = lds_ld(&sh.anch[e & 1]);
     if (lds_ld(&sh.epoch) != e) return false;
-    const int akey = uni((int)(unsigned)(a >> 32));
-    const int key = (it - uni(sh.i0)) * nc + c;
+    const int akey = (int)(unsigned)(a >> 32);
+    const int key = (it - sh.i0) * nc + c;
     int ia, ca, ap;
-    flow_from_anchor(H, sh, rg, a, ia, ca, ap);
-    const int limit = uni(sh.fill);
+    flow_from_anchor(cs, sh, rg, a, ia, ca, ap);
+    const int limit = sh.fill;
     stands = in_turn && key < akey;
     W.epoch = e; W.akey = akey;
     if (!stands) {
         // the current step starts at or after the anchor: same iteration, or the anchor sits in the iteration before
         if (ia == it) { W.rc = ca; W.rpos = ap; }
-        else { W.rc = 0; W.rpos = flow_next_base(H.n_all, rg, ap, nc - ca, 1 << 30); }
-        W.rc1 = 0; W.rpos1 = flow_next_base(H.n_all, rg, W.rpos, nc - W.rc, limit);
-        W.B2 = flow_next_base(H.n_all, rg, W.rpos1, nc, limit);
+        else { W.rc = 0; W.rpos = flow_next_base(cs, sh, rg, ap, nc - ca, 1 << 30); }
+        W.rc1 = 0; W.rpos1 = flow_next_base(cs, sh, rg, W.rpos, nc - W.rc, limit);
+        W.B2 = flow_next_base(cs, sh, rg, W.rpos1, nc, limit);
     } else if (ia == it) {
         W.rc = ca; W.rpos = ap;                         // (the wave's later chains of this iteration)
-        W.rc1 = 0; W.rpos1 = flow_next_base(H.n_all, rg, ap, nc - ca, limit);
-        W.B2 = flow_next_base(H.n_all, rg, W.rpos1, nc, limit);
+        W.rc1 = 0; W.rpos1 = flow_next_base(cs, sh, rg, ap, nc - ca, limit);
+        W.B2 = flow_next_base(cs, sh, rg, W.rpos1, nc, limit);
     } else {                                            // the anchor is a step of the next iteration
         W.rc1 = ca; W.rpos1 = ap;
-        W.B2 = flow_next_base(H.n_all, rg, ap, nc - ca, limit);
+        W.B2 = flow_next_base(cs, sh, rg, ap, nc - ca, limit);
     }
     return true;
 }
 
-// The inputs of one chain step, REQUESTED ONE STEP AHEAD: where a wave's next step starts and what it proposes is in the
-// stream window long before the step runs, so everything the step reads from memory -- the element it perturbs and the
-// event's coordinates (gA: lane 0, lanes 1..3), prior mean, 1 / (2 sigma^2), step size and the event's reciprocal precision
-// sums (gB: lanes 0..4), the prior type, the event's four observation rows and the chain's station corrections -- is
-// requested with vector loads while the step before it is evaluated (the kernel has the registers: 150 of 256), and the
-// step itself starts with its arithmetic.  What the step in between commits to the same chain is patched into the
-// registers (flow_patch); vs, qs and the elements of the full-evaluation types come from the LDS mirror at use.
-template <int N>
-struct StepIn {
-    int it, c, p, epoch;          // which step, its predicted start, the epoch of the prediction; p < 0: nothing requested
-    int type, idx, evt, dec_w;    // the decoded proposal (htm_stream.hpp)
-    double g, r, logr;            // its Gaussian, its Metropolis draw and log
-    double gA, gB;
-    int pt;
-    double tob[N], tpr[N], aob[N], apr[N], tc[N], ac[N];
-};
-
-template <int NCH, bool F32>
-__device__ __forceinline__ void flow_request(const FlowHot &H, const Ring &rg, const FlowWave &W, StepIn<(NCH > 0 ? NCH : 1)> &n,
-                                             int it, int c, int p, int lane)
-{
-    const int M = rg.mask;
-    asm volatile("" : "+v"(lane));
-    n.it = it; n.c = c; n.p = p; n.epoch = W.epoch;
-    const double *xall_ = H.xall, *muall_ = H.muall, *rs2all_ = H.rs2all, *stall_ = H.stall;
-    const int *ptall_ = H.ptall;
-    const int nc_ = H.n_chains, S_ = H.S, nh = 3 * H.E;
-    const i32x4 dec = reinterpret_cast<const i32x4 *>(rg.dec)[p & M];
-    const int type = __builtin_amdgcn_readfirstlane(dec.x), idx = __builtin_amdgcn_readfirstlane(dec.y);
-    const int evt = __builtin_amdgcn_readfirstlane(dec.z);
-    n.type = type; n.idx = idx; n.evt = evt; n.dec_w = __builtin_amdgcn_readfirstlane(dec.w);
-    n.g = rg.pg[p & M]; n.r = rg.pr[p & M]; n.logr = rg.plogr[p & M];
-    const bool partial = evt > 0 && it > 1;       // hypo_tremor_mcmc.f90:246
-    const int off_tc = nc_, off_qs = nc_ + nc_ * S_, off_ac = 2 * nc_ + nc_ * S_, off_hy = 2 * nc_ + 2 * nc_ * S_;
-    const int goff = type == 1 ? 0 : type == 2 ? off_tc : type == 3 ? off_qs : type == 4 ? off_ac : off_hy;
-    const int gnx = (type == 1 || type == 3) ? 1 : (type == 2 || type == 4) ? S_ : nh;
-    const int o = goff + c * gnx + idx;
-    const int ev = evt > 0 ? evt - 1 : 0;
-    const int o_h = off_hy + c * nh + 3 * ev;
-    int ga = o;
-    ga = lane == 1 ? o_h : ga; ga = lane == 2 ? o_h + 1 : ga; ga = lane == 3 ? o_h + 2 : ga;
-    n.gA = xall_[ga];
-    const double *pb = muall_ + o;
-    pb = lane == 1 ? rs2all_ + o : pb; pb = lane == 2 ? stall_ + o : pb;
-    pb = lane == 3 ? H.rpsum_t + ev : pb; pb = lane == 4 ? H.rpsum_a + ev : pb;
-    n.gB = *pb;
-    n.pt = ptall_[o + opaque_zero()];             // (a vector load: scalar loads in flight would hold up every LDS wait)
-    if (partial) {
-        if constexpr (NCH > 0) {
-            const double *tc = xall_ + off_tc + c * S_, *ac = xall_ + off_ac + c * S_;
-            const size_t base = (size_t)ev * (size_t)H.S;
-            const bool ut = H.use_time != 0, ua = H.use_amp != 0;
-#pragma unroll
-            for (int k = 0; k < NCH; ++k) {
-                const int j = lane + 64 * k;
-                const bool valid = j < H.S;
-                n.tob[k] = n.tpr[k] = n.aob[k] = n.apr[k] = 0.0; n.tc[k] = 0.0; n.ac[k] = 0.0;
-                if (valid) {
-                    n.tc[k] = tc[j]; n.ac[k] = ac[j];
-                    if constexpr (F32) {
-                        if (ut) { n.tob[k] = (double)H.t_obs32[base + j]; n.tpr[k] = (double)H.t_prec32[base + j]; }
-                        if (ua) { n.aob[k] = (double)H.a_obs32[base + j]; n.apr[k] = (double)H.a_prec32[base + j]; }
-                    } else {
-                        if (ut) { n.tob[k] = H.t_obs[base + j]; n.tpr[k] = H.t_prec[base + j]; }
-                        if (ua) { n.aob[k] = H.a_obs[base + j]; n.apr[k] = H.a_prec[base + j]; }
-                    }
-                }
-            }
-        }
-    }
-}
-
-// what the step that has just been committed (chain c, accepted, element o := x_new) changes in the inputs requested for
-// the wave's next step, if that is a step of the same chain
-template <int N>
-__device__ __forceinline__ void flow_patch(StepIn<N> &n, int c, int type, int idx, int evt, int o, double x_new, int lane,
-                                           int nc_, int S_, int nh)
-{
-    if (n.p < 0 || n.c != c) return;
-    if (type >= 5) {
-        if (n.type >= 5) {
-            const int off_hy = 2 * nc_ + 2 * nc_ * S_;
-            const int on = off_hy + c * nh + n.idx;
-            if (on == o && lane == 0) n.gA = x_new;
-            if (n.evt == evt && lane == 1 + (idx - 3 * (evt - 1))) n.gA = x_new;
-        }
-    } else if (type == 2 || type == 4) {
-#pragma unroll
-        for (int k = 0; k < N; ++k)
-            if (lane + 64 * k == idx) { if (type == 2) n.tc[k] = x_new; else n.ac[k] = x_new; }
-    }
-}
-
 // The global stores of a step -- its commit and the order it sends ahead -- are ISSUED AT THE START OF THE WAVE'S NEXT STEP,
-// behind that step's first use of its requested inputs.  Vector-memory operations of a wave complete in issue order and a
-// write-through store is acknowledged by memory (~1 us): a step that waits for its inputs right after the commit store of
-// the step before waits for that acknowledgement (measured: 2.5 k of a step's 12 k cycles).  Issued here, the stores are
-// younger than everything the step waits for; they are a step old by the time anything waits behind them.
+// right behind that step's loads.  Vector-memory operations of a wave complete in issue order and a write-through store is
+// acknowledged by memory (~1 us): a step that loads its inputs right after the commit store of the step before gets them
+// only when that store has been acknowledged (measured: 2.5 k of a step's 12 k cycles went there).  Issued behind the loads,
+// the stores are younger than everything the step waits for, and a step old by the time anything waits behind them.  What
+// the pending commit changes in the step's own inputs is patched into the registers (it is the same chain's, or nothing).
 struct Deferred {
     int commit_o;                 // element to write, -1: none
     double commit_x;
@@ -343,14 +182,15 @@ struct Deferred {
     unsigned ord_tag, ord_w1, ord_co, ord_rep;
     double ord_x, ord_cx;
 };
-__device__ __forceinline__ void flow_issue(const FlowHot &H, Deferred &df, int lane, unsigned long long launch)
+__device__ __forceinline__ void flow_issue(CsRef cs_, Deferred &df, int lane, unsigned long long launch)
 {
+    CsRef cs = rebase(cs_);
     if (df.commit_o >= 0) {
-        if (lane == 0) st_agent(H.xall + df.commit_o, df.commit_x);
+        if (lane == 0) st_agent(cs.xall + df.commit_o, df.commit_x);
         df.commit_o = -1;
     }
     if (df.ord_c >= 0) {
-        if (lane < H.slot_rep * kGranPerSlot) {
+        if (lane < cs.slot_rep * kGranPerSlot) {
             const int gi = lane & 7;
             const unsigned long long xb = (unsigned long long)__double_as_longlong(df.ord_x);
             const unsigned long long cb = (unsigned long long)__double_as_longlong(df.ord_cx);
@@ -359,65 +199,81 @@ __device__ __forceinline__ void flow_issue(const FlowHot &H, Deferred &df, int l
                                : gi == 4 ? df.ord_co                                    // the commit the workers must see, or ~0
                                : gi == 5 ? (unsigned)(cb >> 32) : gi == 6 ? (unsigned)cb
                                : df.ord_rep;                                            // element of the step in between (+1; 0 = none)
-            st_gran(H.slots + (size_t)(lane >> 3) * H.slot_stride + df.ord_c * kGranPerSlot + gi, df.ord_tag, pay);
+            st_gran(cs.slots + (size_t)(lane >> 3) * cs.slot_stride + df.ord_c * kGranPerSlot + gi, df.ord_tag, pay);
         }
         df.ord_c = -1;
     }
 }
 
-// the orders a chain may send ahead, looked up from positions alone while the step is evaluated; what depends on the
-// step's outcome is filled in after its commit (flow_step)
-struct PlanIn {
-    int mode, pj, jt, ji, jo, mid, o_mid, epoch;
-    double jx_old, jstep, jg;
-};
-
-// One chain step: its inputs were requested a step ago (cur); proposal, the request of the wave's NEXT step's inputs (nx),
-// evaluation, the step's turn, decision, commit, records and the orders of the chain's coming full evaluations (the
-// free-running counterpart of chain_pass).  All 64 lanes execute with identical (uniform) values; lane <-> station only inside
+// One chain step from its front to its commit and the orders of the chain's coming full evaluations (the free-running
+// counterpart of chain_pass).  All 64 lanes execute with identical (uniform) values; lane <-> station only inside
 // event_misfit.  `ext`: this wave keeps the LDS window of the stream ahead (chain 0's wave, one round of <= 64 positions
-// per step, in flight under the step's arithmetic).  Returns the stream position after the step, kFlowRestart or kFlowAbort.
+// per step, in flight under the step's own loads).  Returns the stream position after the step, kFlowRestart or kFlowAbort.
 template <int NCH, bool F32>
-__device__ __forceinline__ int flow_step(const FlowHot &H, CsRef cs_, FlowShared &sh, const Ring &rg, FlowWave &W,
-                                         const StepIn<(NCH > 0 ? NCH : 1)> &cur, StepIn<(NCH > 0 ? NCH : 1)> &nx, Deferred &df,
-                                         const double (&rsx)[(NCH > 0 ? NCH : 1)], const double (&rsy)[(NCH > 0 ? NCH : 1)],
-                                         const double (&rsz)[(NCH > 0 ? NCH : 1)],
-                                         const double *s_sx, const double *s_sy, const double *s_sz,
+__device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, const Ring &rg, FlowWave &W, Deferred &df,
+                                         const double *s_sx, const double *s_sy, const double *s_sz, int c, int p, int iter,
                                          int lane, int wave, int NW, unsigned long long launch, bool ext, int look, int back,
                                          bool rec_now)
 {
-    constexpr int N = NCH > 0 ? NCH : 1;
-    CsRef cs = rebase(cs_);      // (cold paths only: records, diagnostics; the loop's arguments are in H)
-    // (lane predicates -- lane == 0, lane < n, ... -- are one compare where they are used; as loop invariants the compiler
-    // keeps each as a 64-bit mask in a spilled scalar pair: two v_readlane per use)
-    asm volatile("" : "+v"(lane));
+    CsRef cs = rebase(cs_);
+    FwRef f = rebase(f_);
     const int M = rg.mask;
-    const int c = cur.c, iter = cur.it;
-    const int p = cur.p;
+    p = __builtin_amdgcn_readfirstlane(p);
 #ifdef HTM_STAMPS
-    unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long t_last = __builtin_amdgcn_s_memtime(), t_wait = 0;
     const unsigned long long t_step0 = t_last;
 #endif
-    const int nc_ = H.n_chains, S_ = H.S, nh = 3 * H.E;
-    const int type = cur.type, idx = cur.idx, evt = cur.evt, dec_w = cur.dec_w;
-    const double g = cur.g, r_ring = cur.r, logr_ring = cur.logr;
+    // ---- the LDS window of the stream rings, one round per step of chain 0's wave: requested first, stored behind the
+    // ---- step's own loads (which return after it: vector-memory operations complete in order)
+    PfRegs pf;
+    pf.p = -1;
+    int fill_to = 0;
+    if (ext) {
+        const int fl = sh.fill;
+        // (this step is chain c's: the iteration's base lies 4 c .. 6 c positions back; the other waves may still read `back`
+        // positions behind it, and want `look` positions ahead of it)
+        fill_to = min(min(p - 4 * c + look, sh.avail), p - 6 * c - back + M + 1);
+        if (fill_to > fl + 64) fill_to = fl + 64;
+        if (fill_to > fl) pf_load(pf, cs, sh, fl + lane, fill_to);
+    }
+    const double *xall_ = cs.xall, *muall_ = cs.muall, *rs2all_ = cs.rs2all, *stall_ = cs.stall;
+    const int *ptall_ = cs.ptall;
+    const int nc_ = cs.n_chains, S_ = cs.S, nh = 3 * cs.E;
+    const i32x4 dec = reinterpret_cast<const i32x4 *>(rg.dec)[p & M];      // decoded ahead of time (htm_stream.hpp)
+    asm volatile("" : "+s"(xall_), "+s"(muall_), "+s"(rs2all_), "+s"(stall_), "+s"(ptall_));
+    const int type = __builtin_amdgcn_readfirstlane(dec.x), idx = __builtin_amdgcn_readfirstlane(dec.y);
+    const int evt = __builtin_amdgcn_readfirstlane(dec.z), dec_w = __builtin_amdgcn_readfirstlane(dec.w);
+    const double g = rg.pg[p & M], r_ring = rg.pr[p & M], logr_ring = rg.plogr[p & M];
     const bool partial = evt > 0 && iter > 1;       // hypo_tremor_mcmc.f90:246
     const int off_tc = nc_, off_qs = nc_ + nc_ * S_, off_ac = 2 * nc_ + nc_ * S_, off_hy = 2 * nc_ + 2 * nc_ * S_;
     const int goff = type == 1 ? 0 : type == 2 ? off_tc : type == 3 ? off_qs : type == 4 ? off_ac : off_hy;
     const int gnx = (type == 1 || type == 3) ? 1 : (type == 2 || type == 4) ? S_ : nh;
     const int o = goff + c * gnx + idx;             // element of the rank's parameter vector this step perturbs
     const int ev = partial ? evt - 1 : 0;
-    const double *tc = H.xall + off_tc + c * S_, *ac = H.xall + off_ac + c * S_;
+    const int o_h = off_hy + c * nh + 3 * ev;
+    int goffs = o;
+    goffs = lane == 1 ? o_h : goffs; goffs = lane == 2 ? o_h + 1 : goffs; goffs = lane == 3 ? o_h + 2 : goffs;
+    goffs = lane == 4 ? c : goffs; goffs = lane == 5 ? off_qs + c : goffs;
+    const double gathered_v = xall_[goffs];
+    const double mu = ld_const(muall_ + o), rs2 = ld_const(rs2all_ + o), step = ld_const(stall_ + o);
+    const int ptype = ld_const(ptall_ + o);
+    const double *tc = xall_ + off_tc + c * S_, *ac = xall_ + off_ac + c * S_;
+    StaRegs<(NCH > 0 ? NCH : 1)> st;
+    ObsRegs<(NCH > 0 ? NCH : 1)> ob;
+    if (partial) {
+        if constexpr (NCH > 0) {
+            load_sta_regs<NCH>(st, f.S, lane, s_sx, s_sy, s_sz, tc, ac, 0, -1, 0.0);
+            load_obs_regs<NCH, F32>(ob, f, ev, lane);      // in flight while the proposal is worked out
+        }
+    }
     // the book of this chain: is this step's order out already, and how
-    const int book_pos = uni(sh.ob_pos[c]), book_mode = uni(sh.ob_mode[c]), book_mid = uni(sh.ob_mid[c]);
-    const unsigned book_tag = (unsigned)uni((int)sh.ob_tag[c]);
+    const int book_pos = sh.ob_pos[c], book_mode = sh.ob_mode[c], book_mid = sh.ob_mid[c];
+    const unsigned book_tag = sh.ob_tag[c];
     const bool pre = !partial && book_pos == p;
     const int pre_mode = pre ? book_mode : 0;
     // a full-evaluation step whose order went out two steps ahead adds the event of the step in between itself (below):
-    // its inputs are requested now
-    StaRegs<N> st;
-    ObsRegs<N> ob;
+    // its inputs are requested now, into the registers a partial update would use
     int d_e = 0;
     double d_ex = 0.0, d_ey = 0.0, d_ez = 0.0;
     const bool own_evt = NCH > 0 && pre_mode == 2 && (book_mid & 7) >= 5;
@@ -425,36 +281,44 @@ __device__ __forceinline__ int flow_step(const FlowHot &H, CsRef cs_, FlowShared
         if (__builtin_expect(own_evt, 0)) {
             d_e = __builtin_amdgcn_readfirstlane(book_mid >> 3) - 1;
             const int vzd = opaque_zero();
-            const double *hypd = H.xall + off_hy + c * nh + 3 * d_e;
+            const double *hypd = xall_ + off_hy + c * nh + 3 * d_e;
             d_ex = ld_state(hypd, vzd); d_ey = ld_state(hypd + 1, vzd); d_ez = ld_state(hypd + 2, vzd);
-            // (the step in between is the chain's latest: if its commit is still waiting to be issued, memory has the old value)
-            const int od = off_hy + c * nh + 3 * d_e;
-            if (df.commit_o == od) d_ex = df.commit_x;
-            if (df.commit_o == od + 1) d_ey = df.commit_x;
-            if (df.commit_o == od + 2) d_ez = df.commit_x;
-            load_sta_regs<NCH>(st, H.S, lane, s_sx, s_sy, s_sz, tc, ac, 0, -1, 0.0);
-            load_obs_regs<NCH, F32>(ob, H, d_e, lane);
-        } else if (partial) {
-#pragma unroll
-            for (int k = 0; k < NCH; ++k) {
-                st.sx[k] = rsx[k]; st.sy[k] = rsy[k]; st.sz[k] = rsz[k]; st.tc[k] = cur.tc[k]; st.ac[k] = cur.ac[k];
-                ob.tob[k] = cur.tob[k]; ob.tpr[k] = cur.tpr[k]; ob.aob[k] = cur.aob[k]; ob.apr[k] = cur.apr[k];
-            }
-            ob.rpst = H.use_time ? rl_f64(cur.gB, 3) : 1.0;
-            ob.rpsa = H.use_amp ? rl_f64(cur.gB, 4) : 1.0;
+            load_sta_regs<NCH>(st, f.S, lane, s_sx, s_sy, s_sz, tc, ac, 0, -1, 0.0);
+            load_obs_regs<NCH, F32>(ob, f, d_e, lane);
         }
     }
+    // ---- every load of this step is on its way: the stores of the step before go out behind them (see Deferred); what the
+    // ---- pending commit changes in this step's inputs -- it is this chain's own latest commit, or another chain's -- is
+    // ---- patched in below
+    const int pend_o = df.commit_o;
+    const double pend_x = df.commit_x;
+    flow_issue(cs, df, lane, launch);
     FSTAMP(0);
-    const double x_old = type >= 5 ? rl_f64(cur.gA, 0) : rg.mx[o];       // (types 1..4: the LDS mirror, kept current by the commits)
-    const double hx = rl_f64(cur.gA, 1), hy = rl_f64(cur.gA, 2), hz = rl_f64(cur.gA, 3);
-    const double beta = rg.mx[c], q = rg.mx[off_qs + c];
-    const double mu = rl_f64(cur.gB, 0), rs2 = rl_f64(cur.gB, 1), step = rl_f64(cur.gB, 2);
-    const int ptype = __builtin_amdgcn_readfirstlane(cur.pt);
-    FSTAMP(6);
-    // ---- everything this step had requested is in: the stores of the step before go out now (see Deferred)
-    drain_vmem();
-    flow_issue(H, df, lane, launch);
-    FSTAMP(7);
+    double x_old = rl_f64(gathered_v, 0);
+    double hx = rl_f64(gathered_v, 1), hy = rl_f64(gathered_v, 2), hz = rl_f64(gathered_v, 3);
+    double beta = rl_f64(gathered_v, 4), q = rl_f64(gathered_v, 5);
+    if (__builtin_expect(pend_o >= 0, 1)) {
+        if (pend_o == o) x_old = pend_x;
+        if (pend_o == o_h) hx = pend_x;
+        if (pend_o == o_h + 1) hy = pend_x;
+        if (pend_o == o_h + 2) hz = pend_x;
+        if (pend_o == c) beta = pend_x;
+        if (pend_o == off_qs + c) q = pend_x;
+        if constexpr (NCH > 0) {
+            const int jt = pend_o - (off_tc + c * S_), ja = pend_o - (off_ac + c * S_);
+            if ((jt >= 0 && jt < S_) || (ja >= 0 && ja < S_)) {
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) {
+                    if (lane + 64 * k == jt) st.tc[k] = pend_x;
+                    if (lane + 64 * k == ja) st.ac[k] = pend_x;
+                }
+            }
+            const int od = off_hy + c * nh + 3 * d_e;
+            if (pend_o == od) d_ex = pend_x;
+            if (pend_o == od + 1) d_ey = pend_x;
+            if (pend_o == od + 2) d_ez = pend_x;
+        }
+    }
     const double L_cur = sh.L[c];
     const double x_new = x_old + g * step;                      // cls_model.f90:172
     const double da = x_new - mu, db = x_old - mu;
@@ -464,78 +328,28 @@ __device__ __forceinline__ int flow_step(const FlowHot &H, CsRef cs_, FlowShared
         if (x_new <= mu) { lpr = (double)-1.0e+30f; ok = 0; }
         else lpr = lpr + log(x_new - mu) - log(x_old - mu);
     }
-    ok = uni(ok);
-    FSTAMP(8);
     const double r = ok ? r_ring : 0.0, logr = ok ? logr_ring : 0.0;
     const int cnt = dec_w - 1 + ok;                             // the judge draw happens only if prior_ok
-    const int i0_ = uni(sh.i0), fill_ = uni(sh.fill), it_target = uni(sh.c.iter_target);
-    const int key = (iter - i0_) * nc_ + c;
+    const int key = (iter - sh.i0) * nc_ + c;
     // ---- the step has passed (or failed) its prior check: the later steps may go ahead on it
     if (c == nc_ - 1) {                                         // where this iteration's swap starts, and what it draws there
         const int E = p + cnt, k4 = iter & 3;
         int i1, i2, nd;
-        flow_swap_at(H.n_all, rg, E, 1 << 30, i1, i2, nd);
+        flow_swap_at(cs, sh, rg, E, 1 << 30, i1, i2, nd);
         if (lane == 0) {
             sh.sw_i1[k4] = i1; sh.sw_i2[k4] = i2; sh.sw_nd[k4] = nd;
             if (nd > 0) { sh.sw_r[k4] = rg.U[(E + nd - 1) & M]; sh.sw_logr[k4] = rg.LOGU[(E + nd - 1) & M]; }
             lds_st(&sh.Eof[k4], E);
         }
     }
-    if (lane == 0)
+    if (lane == 0) {
         lds_st(&sh.prog[c], ((unsigned long long)(((unsigned)W.epoch << 1) | (ok ? 0u : 1u)) << 32) | (unsigned)key);
-    FSTAMP(9);
-    // ---- the wave's NEXT step: where it starts (a prediction in this epoch), and the request of its inputs -- in flight
-    // ---- under this step's evaluation, turn and commit
-    nx.p = -1;
-    {
-        const int cn = c + NW < nc_ ? c + NW : wave;
-        const bool same_it = cn > c;
-        const int itn = same_it ? iter : iter + 1;
-        const int rcn = same_it ? W.rc : W.rc1, rpn = same_it ? W.rpos : W.rpos1;
-        if (ok != 0 && rpn >= 0 && cn >= rcn && itn <= it_target) {
-            const int pn = uni(hop_ahead(rg, rpn, cn - rcn));
-            if (pn + 16 < fill_) flow_request<NCH, F32>(H, rg, W, nx, itn, cn, pn, lane);
-        }
     }
-    // ---- the orders this chain may send ahead after this step (what role P does for all chains in step_body): its next
-    // ---- step's if that needs the full evaluation (one step ahead), else -- that step being a hypocentre step -- the one
-    // ---- after it (two steps ahead: the workers leave the event of the step in between out, this wave adds it).
-    // ---- Looked up here from positions alone; sent after the commit.  A step uses an order only if it starts exactly where
-    // ---- the order was written for, and an epoch change voids the book.
-    FSTAMP(10);
-    PlanIn pl;
-    pl.mode = 0; pl.epoch = W.epoch; pl.pj = 0; pl.jt = 0; pl.ji = 0; pl.jo = 0; pl.mid = 0; pl.o_mid = -1; pl.jx_old = 0.0; pl.jstep = 0.0; pl.jg = 0.0;
-    if (rg.mir_n > 0 && (book_pos == -1 || book_pos == p) && ok != 0 && iter + 1 <= it_target) {
-        const int lim = fill_ - 8;
-        int p1 = -1, d1x = 0, d1y = 0, d1z = 0;
-        if (nx.p >= 0 && nx.c == c) { p1 = nx.p; d1x = nx.type; d1y = nx.idx; d1z = nx.evt; }     // (a wave with one chain)
-        else if (W.rpos1 >= 0 && c >= W.rc1) {
-            p1 = uni(hop_ahead(rg, W.rpos1, c - W.rc1));
-            if (p1 < lim) {
-                const i32x4 d1 = reinterpret_cast<const i32x4 *>(rg.dec)[p1 & M];
-                d1x = uni(d1.x); d1y = uni(d1.y); d1z = uni(d1.z);
-            } else p1 = -1;
-        }
-        const bool w1 = p1 >= 0;
-        const bool job1 = w1 && d1x >= 1 && d1x <= 4;
-        int mode = job1 ? 1 : 0, pj = p1, jt = d1x, ji = d1y;
-        if (HTM_ALLOW2 && NCH > 0 && w1 && !job1 && iter + 2 <= it_target && W.B2 >= 0) {
-            const int p2 = uni(hop_ahead(rg, W.B2, c));
-            if (p2 < lim) {
-                const i32x4 d2 = reinterpret_cast<const i32x4 *>(rg.dec)[p2 & M];
-                const int d2x = uni(d2.x);
-                if (d2x >= 1 && d2x <= 4) { mode = 2; pj = p2; jt = d2x; ji = uni(d2.y); }
-            }
-        }
-        if (mode) {
-            const int jgoff = jt == 1 ? 0 : jt == 2 ? nc_ : jt == 3 ? nc_ + nc_ * S_ : 2 * nc_ + nc_ * S_;
-            pl.jo = jgoff + c * ((jt == 1 || jt == 3) ? 1 : S_) + ji;
-            pl.jx_old = rg.mx[pl.jo];                                         // LDS mirror (this step's own commit: below)
-            pl.jstep = rg.mir_steps ? rg.mstep[pl.jo] : H.stall[pl.jo + opaque_zero()];
-            pl.jg = rg.pg[pj & M];
-            pl.mode = mode; pl.pj = pj; pl.jt = jt; pl.ji = ji; pl.mid = d1x | (d1z << 3); pl.o_mid = off_hy + c * nh + d1y;
-        }
+    if (ext && fill_to > sh.fill) {                             // (the window's loads were issued before the step's: they are there)
+        pf_store(pf, rg);
+        if (lane == 0) lds_st(&sh.fill, fill_to);
     }
+
     FSTAMP(1);
     double L_new = 0.0;
     int need_full = 0;
@@ -546,8 +360,8 @@ __device__ __forceinline__ int flow_step(const FlowHot &H, CsRef cs_, FlowShared
             const double py[2] = {hy, cmp == 1 ? x_new : hy};
             const double pz[2] = {hz, cmp == 2 ? x_new : hz};
             double out[2];
-            if constexpr (NCH > 0) event_misfit<NCH, 2, F32>(H, ob, lane, st, px, py, pz, beta, q, out);
-            else event_misfit_generic<2>(H, ev, lane, s_sx, s_sy, s_sz, tc, ac, 0, -1, 0.0, px, py, pz, beta, q, out);
+            if constexpr (NCH > 0) event_misfit<NCH, 2, F32>(f, ob, lane, st, px, py, pz, beta, q, out);
+            else event_misfit_generic<2>(f, ev, lane, s_sx, s_sy, s_sz, tc, ac, 0, -1, 0.0, px, py, pz, beta, q, out);
             L_new = L_cur + wave_sum1(out[0] - out[1]);
         } else {
             need_full = 1;
@@ -563,17 +377,17 @@ __device__ __forceinline__ int flow_step(const FlowHot &H, CsRef cs_, FlowShared
             // every chain-state store of this wave has landed before a worker can see the order (write-through stores,
             // drained here; an order sent ahead names the commit the workers have to see instead)
             if (!pre) drain_vmem();
-            if (!pre && lane < H.slot_rep * kGranPerSlot) {
+            if (!pre && lane < cs.slot_rep * kGranPerSlot) {
                 const int gi = lane & 7;
                 const unsigned long long xb = (unsigned long long)__double_as_longlong(x_new);
                 const unsigned pay = gi == 0 ? (unsigned)launch : gi == 1 ? ((unsigned)type | ((unsigned)idx << 3))
                                    : gi == 2 ? (unsigned)(xb >> 32) : gi == 3 ? (unsigned)xb
                                    : gi == 4 ? 0xffffffffu : 0u;          // no commit to wait for (drained above), nothing left out
-                st_gran(H.slots + (size_t)(lane >> 3) * H.slot_stride + c * kGranPerSlot + gi, tag, pay);
+                st_gran(cs.slots + (size_t)(lane >> 3) * cs.slot_stride + c * kGranPerSlot + gi, tag, pay);
             }
             // ---- the workers' partial sums: tagged granules, fixed summation order; two rounds of loads in flight --
-            const unsigned long long *pg = H.pgran + (size_t)c * H.n_wg * H.pgran_stride;
-            const int pgs = H.pgran_stride;
+            const unsigned long long *pg = cs.pgran + (size_t)c * cs.n_wg * cs.pgran_stride;
+            const int pgs = cs.pgran_stride;
             double part = 0.0;
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz
             constexpr int kSweep = 4;                 // <= 256 workers (host-checked)
@@ -584,14 +398,14 @@ __device__ __forceinline__ int flow_step(const FlowHot &H, CsRef cs_, FlowShared
                 for (int j = 0; j < kSweep; ++j) {
                     const int k = j * 64 + lane;
                     hi[b][j] = 0; lo[b][j] = 0;
-                    if (k < H.n_wg) { hi[b][j] = ld_agent(pg + (size_t)pgs * k); lo[b][j] = ld_agent(pg + (size_t)pgs * k + 1); }
+                    if (k < cs.n_wg) { hi[b][j] = ld_agent(pg + (size_t)pgs * k); lo[b][j] = ld_agent(pg + (size_t)pgs * k + 1); }
                 }
             };
             auto complete = [&](int b) __attribute__((always_inline)) {
                 bool got = true;
 #pragma unroll
                 for (int j = 0; j < kSweep; ++j)
-                    if (j * 64 + lane < H.n_wg) got = got && (unsigned)(hi[b][j] >> 32) == tag && (unsigned)(lo[b][j] >> 32) == tag;
+                    if (j * 64 + lane < cs.n_wg) got = got && (unsigned)(hi[b][j] >> 32) == tag && (unsigned)(lo[b][j] >> 32) == tag;
                 return __all(got);
             };
             // an order sent two steps ahead was answered a step ago: its granules are requested now, under the evaluation
@@ -612,7 +426,7 @@ __device__ __forceinline__ int flow_step(const FlowHot &H, CsRef cs_, FlowShared
                     }
                     const double pxd[1] = {d_ex}, pyd[1] = {d_ey}, pzd[1] = {d_ez};
                     double outd[1];
-                    event_misfit<NCH, 1, F32>(H, ob, lane, st, pxd, pyd, pzd, type == 1 ? x_new : beta, type == 3 ? x_new : q, outd);
+                    event_misfit<NCH, 1, F32>(f, ob, lane, st, pxd, pyd, pzd, type == 1 ? x_new : beta, type == 3 ? x_new : q, outd);
                     own_lane = outd[0];
                 }
             }
@@ -645,40 +459,26 @@ __device__ __forceinline__ int flow_step(const FlowHot &H, CsRef cs_, FlowShared
 #endif
 #pragma unroll
             for (int j = 0; j < kSweep; ++j)            // fixed order: worker lane, lane + 64, ...
-                if (j * 64 < H.n_wg)
-                    part += (j * 64 + lane < H.n_wg) ? (which == 0 ? gran_f64(hi[0][j], lo[0][j]) : gran_f64(hi[1][j], lo[1][j])) : 0.0;
-            L_new = -wave_sum1(part + own_lane) - H.const_sum;       // cls_forward.f90:277-300
+                if (j * 64 < cs.n_wg)
+                    part += (j * 64 + lane < cs.n_wg) ? (which == 0 ? gran_f64(hi[0][j], lo[0][j]) : gran_f64(hi[1][j], lo[1][j])) : 0.0;
+            L_new = -wave_sum1(part + own_lane) - f.const_sum;       // cls_forward.f90:277-300
         }
-    }
-    // ---- the round of the LDS window of the stream rings that chain 0's wave owes per step: requested here, behind the
-    // ---- evaluation (whose registers are free again), stored at the end of the step
-    PfRegs pf;
-    pf.p = -1;
-    int fill_to = 0;
-    if (ext) {
-        const int fl = sh.fill;
-        // (this step is chain c's: the iteration's base lies 4 c .. 6 c positions back; the other waves may still read `back`
-        // positions behind it, and want `look` positions ahead of it)
-        fill_to = min(min(p - 4 * c + look, sh.avail), p - 6 * c - back + M + 1);
-        if (fill_to > fl + 64) fill_to = fl + 64;
-        if (fill_to > fl) flow_pf_load(pf, sh, fl + lane, fill_to);
     }
     FSTAMP(2);
 
     // ---- the step's turn: every step before it in stream order has passed its check in this epoch (or lies before the
     // ---- epoch's anchor: checked earlier, final).  Lanes <-> chains.
     {
-        const int key_i = (iter - i0_) * nc_, key_m = key_i - nc_;
+        const int key_i = (iter - sh.i0) * nc_, key_m = key_i - nc_;
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         for (unsigned spin = 0;; ++spin) {
             const unsigned long long pv = lane < nc_ ? lds_ld(&sh.prog[lane]) : 0ull;
             const int e = lds_ld(&sh.epoch);
             if (__builtin_expect(e != W.epoch, 0)) {
                 bool stands = false;
-                if (!flow_adopt(H, sh, rg, W, e, iter, c, true, stands)) continue;
-                flow_void_books(H, sh, wave, NW, nc_, lane);
+                if (!flow_adopt(cs, sh, rg, W, e, iter, c, true, stands)) continue;
+                flow_void_books(cs, sh, wave, NW, nc_, lane);
                 df.ord_c = -1;                   // (an order not yet issued is void with the book)
-                nx.p = -1;                       // (requested for a position of the old epoch)
                 if (!stands) return kFlowRestart;
                 continue;
             }
@@ -700,14 +500,14 @@ __device__ __forceinline__ int flow_step(const FlowHot &H, CsRef cs_, FlowShared
     // ---- here by the waves of the two chains it concerns -- each evaluates the same expression on the same values
     const int par = iter & 3, ppar = (iter - 1) & 3;
     double T = sh.T4[par][c], rT = sh.rT4[par][c];        // (first iteration of a launch: written by the prologue)
-    if (iter - 1 > i0_) {
+    if (iter - 1 > sh.i0) {
         T = sh.T4[ppar][c]; rT = sh.rT4[ppar][c];
-        if (H.n_all > 1) {
+        if (cs.n_procs * nc_ > 1) {
             // (written by the last chain's wave before it published its check; this step's turn has seen that check)
-            const int i1 = lds_ld(&sh.sw_i1[ppar]), i2 = uni(sh.sw_i2[ppar]);
+            const int i1 = lds_ld(&sh.sw_i1[ppar]), i2 = sh.sw_i2[ppar];
             if (c == i1 || c == i2) {
                 const int o2 = c == i1 ? i2 : i1;
-                const int want = (iter - 1 - i0_) * nc_ + o2;
+                const int want = (iter - 1 - sh.i0) * nc_ + o2;
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                 for (unsigned spin = 0; lds_ld(&sh.done[o2]) < want; ++spin) {
                     if ((spin & 15u) == 15u) {
@@ -723,11 +523,11 @@ __device__ __forceinline__ int flow_step(const FlowHot &H, CsRef cs_, FlowShared
             }
         }
     }
-    const int acc = uni((ok != 0 && metropolis(L_new, L_cur, rT, lpr, r, logr)) ? 1 : 0);       // cls_mcmc.f90:193-203
+    const int acc = (ok != 0 && metropolis(L_new, L_cur, rT, lpr, r, logr)) ? 1 : 0;       // cls_mcmc.f90:193-203
     // this wave's chain-state stores of EARLIER steps have landed before this step's commit goes out: an order sent after
     // the commit names only the commit itself for the workers to wait for
     drain_vmem();
-    const int cool = uni((T < 1.0 + kEps) ? 1 : 0);
+    const int cool = (T < 1.0 + kEps) ? 1 : 0;
     const double L_post = acc ? L_new : L_cur;
     if (lane == 0) {
         sh.T4[par][c] = T; sh.rT4[par][c] = rT;
@@ -744,9 +544,8 @@ __device__ __forceinline__ int flow_step(const FlowHot &H, CsRef cs_, FlowShared
     if (acc) {
         // the store to the chain's state in memory: at the start of the wave's next step (Deferred) -- unless this step's
         // sample record is about to read the state back
-        if (rec_now && cool) { if (lane == 0) st_agent(H.xall + o, x_new); }
+        if (rec_now && cool) { if (lane == 0) st_agent(cs.xall + o, x_new); }
         else { df.commit_o = o; df.commit_x = x_new; }
-        flow_patch<N>(nx, c, type, idx, evt, o, x_new, lane, nc_, S_, nh);
     }
     FSTAMP(4);
     // ---- a rejected prior: this step was one draw shorter than the hop tables assume.  Everything after it starts
@@ -759,14 +558,13 @@ __device__ __forceinline__ int flow_step(const FlowHot &H, CsRef cs_, FlowShared
         }
         bool stands = false;
         // (this wave's own view: as any wave whose step stands before the anchor; a later rejection may already have moved on)
-        while (!flow_adopt(H, sh, rg, W, lds_ld(&sh.epoch), iter, c, true, stands)) { }
-        flow_void_books(H, sh, wave, NW, nc_, lane);
+        while (!flow_adopt(cs, sh, rg, W, lds_ld(&sh.epoch), iter, c, true, stands)) { }
+        flow_void_books(cs, sh, wave, NW, nc_, lane);
         df.ord_c = -1;
-        nx.p = -1;
     }
     // ---- records of this step (hypo_tremor_mcmc.f90:270-280): slots by LDS atomics, put in order on the host
-    if (__builtin_expect(uni(sh.c.slog_cap) > 0, 0)) {
-        const int row = uni(sh.c.slog_n) + (iter - i0_ - 1) * nc_ + c;
+    if (__builtin_expect(sh.c.slog_cap > 0, 0)) {
+        const int row = sh.c.slog_n + (iter - sh.i0 - 1) * nc_ + c;
         if (lane == 0 && row < sh.c.slog_cap) {
             int32_t *ir = cs.slog_i + 8 * (size_t)row;
             double *dr = cs.slog_d + 4 * (size_t)row;
@@ -799,41 +597,61 @@ __device__ __forceinline__ int flow_step(const FlowHot &H, CsRef cs_, FlowShared
             }
         }
     }
-    // ---- the order looked up above goes out, if this epoch still stands and the book is free
-    if (pl.mode != 0 && pl.epoch == W.epoch && uni(sh.ob_pos[c]) == -1) {
-        int mode = pl.mode;
-        const double jx_old = (acc && o == pl.jo) ? x_new : pl.jx_old;        // (this step's own commit of that very element)
-        const double jx_new = jx_old + pl.jg * pl.jstep;                       // cls_model.f90:172, as the step will compute it
-        if (cs.rayleigh14) {                                                  // a Rayleigh prior among vs/qs/corrections (:178-187)
-            if (ld_const(cs.ptall + pl.jo) == 1 && jx_new <= ld_const(cs.muall + pl.jo)) mode = 0;      // prior rejects: no evaluation
-        }
-        // two ahead: the workers wait for this step's commit by reading its value back; the step in between must not
-        // be able to overwrite that very element before they look
-        if (mode == 2 && acc && o == pl.o_mid) mode = 0;
-        if (mode) {
-            unsigned long long tk = 0;
-            if (lane == 0) {
-                tk = (atomicAdd(&sh.c.jobs_total, 1ull) + 1ull) & 0x7fffffffull;
-                if (tk == 0) tk = 0x7fffffffull;
-                sh.ob_pos[c] = pl.pj; sh.ob_tag[c] = (unsigned)tk; sh.ob_mode[c] = mode; sh.ob_mid[c] = pl.mid;
+    // ---- orders of this chain's coming full evaluations (what role P does for all chains in step_body): the next step's
+    // ---- if it needs one (one step ahead), else -- that step being a hypocentre step -- the one after it (two steps ahead:
+    // ---- the workers leave the event of the step in between out, this wave adds it).  Positions are predictions; a step
+    // ---- uses an order only if it starts exactly where the order was written for, and an epoch change voids the book.
+    if (rg.mir_n > 0 && sh.ob_pos[c] == -1 && iter + 1 <= sh.c.iter_target) {
+        const int lim = sh.fill - 8;
+        // this chain's next step is its step of the next iteration (this wave's other chains of this iteration come first)
+        const int p1 = (W.rpos1 >= 0 && c >= W.rc1) ? hop_ahead(rg, W.rpos1, c - W.rc1) : -1;
+        const bool w1 = p1 >= 0 && p1 < lim;
+        const i32x4 d1 = reinterpret_cast<const i32x4 *>(rg.dec)[(w1 ? p1 : 0) & M];
+        const bool job1 = w1 && d1.x >= 1 && d1.x <= 4;
+        int mode = job1 ? 1 : 0;
+        int pj = p1;
+        int jt = d1.x, ji = d1.y;
+        if (HTM_ALLOW2 && NCH > 0 && w1 && !job1 && iter + 2 <= sh.c.iter_target && W.B2 >= 0) {
+            const int p2 = hop_ahead(rg, W.B2, c);
+            if (p2 < lim) {
+                const i32x4 d2 = reinterpret_cast<const i32x4 *>(rg.dec)[p2 & M];
+                if (d2.x >= 1 && d2.x <= 4) { mode = 2; pj = p2; jt = d2.x; ji = d2.y; }
             }
-            const unsigned tag = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)tk);
-            df.ord_c = c; df.ord_tag = tag; df.ord_w1 = (unsigned)pl.jt | ((unsigned)pl.ji << 3);
-            df.ord_x = jx_new; df.ord_cx = x_new;
-            df.ord_co = acc ? (unsigned)o : 0xffffffffu;
-            df.ord_rep = mode == 2 ? (unsigned)pl.o_mid + 1u : 0u;
         }
-    }
-    if (ext && fill_to > sh.fill) {
-        pf_store(pf, rg);
-        if (lane == 0) lds_st(&sh.fill, fill_to);
+        if (mode) {
+            const int jgoff = jt == 1 ? 0 : jt == 2 ? nc_ : jt == 3 ? nc_ + nc_ * S_ : 2 * nc_ + nc_ * S_;
+            const int jo = jgoff + c * ((jt == 1 || jt == 3) ? 1 : S_) + ji;
+            const double jx_old = rg.mx[jo];                                  // LDS mirror, kept current by this wave's commits
+            const double jstep = rg.mir_steps ? rg.mstep[jo] : ld_const(cs.stall + jo);
+            const double jx_new = jx_old + rg.pg[pj & M] * jstep;             // cls_model.f90:172, as the step will compute it
+            if (cs.rayleigh14) {                                              // a Rayleigh prior among vs/qs/corrections (:178-187)
+                if (ld_const(cs.ptall + jo) == 1 && jx_new <= ld_const(cs.muall + jo)) mode = 0;      // prior rejects: no evaluation
+            }
+            // two ahead: the workers wait for this step's commit by reading its value back; the step in between must not
+            // be able to overwrite that very element before they look
+            const int o_mid = off_hy + c * nh + d1.y;
+            if (mode == 2 && acc && o == o_mid) mode = 0;
+            if (mode) {
+                unsigned long long tk = 0;
+                if (lane == 0) {
+                    tk = (atomicAdd(&sh.c.jobs_total, 1ull) + 1ull) & 0x7fffffffull;
+                    if (tk == 0) tk = 0x7fffffffull;
+                    sh.ob_pos[c] = pj; sh.ob_tag[c] = (unsigned)tk; sh.ob_mode[c] = mode; sh.ob_mid[c] = d1.x | (d1.z << 3);
+                }
+                const unsigned tag = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)tk);
+                df.ord_c = c; df.ord_tag = tag; df.ord_w1 = (unsigned)jt | ((unsigned)ji << 3);
+                df.ord_x = jx_new; df.ord_cx = x_new;
+                df.ord_co = acc ? (unsigned)o : 0xffffffffu;
+                df.ord_rep = mode == 2 ? (unsigned)o_mid + 1u : 0u;
+            }
+        }
     }
 #ifdef HTM_STAMPS
     FSTAMP(5);
-    if (lane == 0 && H.stamps) {
+    if (lane == 0 && cs.stamps) {
         unsigned long long *a = sh.stamp_acc + 12 * (wave & 7);
         if (need_full) { a[6] += t_last - t_step0; a[8] += 1; a[10] += t_wait; }
-        else { for (int k = 0; k < 6; ++k) a[k] += st_acc[k]; a[7] += 1; if (wave == 3) for (int k = 6; k < 11; ++k) atomicAdd((unsigned long long *)&H.stamps[96 + k], st_acc[k]); }
+        else { for (int k = 0; k < 6; ++k) a[k] += st_acc[k]; a[7] += 1; }
     }
 #endif
     return p + cnt;
@@ -893,9 +711,6 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
         sh.epoch = 0; sh.anch[0] = 0ull; sh.anch[1] = 0ull;
         sh.i0 = sh.c.iter_done; sh.last_iter = sh.c.iter_target; sh.stop_code = 0;
         sh.n_full_w = 0ull; sh.n_part_w = 0ull;
-        sh.sd.raw = cs.stream.raw; sh.sd.U = cs.stream.U; sh.sd.LOGU = cs.stream.LOGU; sh.sd.G = cs.stream.G; sh.sd.dec = cs.stream.dec;
-        sh.sd.pg = cs.stream.pg; sh.sd.pr = cs.stream.pr; sh.sd.plogr = cs.stream.plogr; sh.sd.hop = cs.stream.hop; sh.sd.sw = cs.stream.sw;
-        sh.sd.mask = cs.stream.mask; sh.sd.gen = cs.stream.gen; sh.sd.hop_end = cs.stream.hop_end;
     }
     __syncthreads();
     const int i0 = sh.i0;
@@ -923,28 +738,12 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
     const int n_int = cs.n_interval;
     int rec_phase = (i0 + 1) % n_int;                            // iteration % n_interval, kept by increments
 
-    FlowHot H;
-    flow_hot_load(f, cs, H);
     FlowWave W;
     W.epoch = 0; W.akey = 0; W.rc = 0; W.rpos = 0;
-    W.rc1 = 0; W.rpos1 = flow_next_base(H.n_all, rg, 0, nc, sh.fill);
-    W.B2 = flow_next_base(H.n_all, rg, W.rpos1, nc, sh.fill);
-    constexpr int N = NCH > 0 ? NCH : 1;
-    // station coordinates of this wave's lanes: resident in registers for the whole launch
-    double rsx[N], rsy[N], rsz[N];
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        const int j = lane + 64 * k;
-        const bool valid = NCH > 0 && j < f.S;
-        rsx[k] = valid ? s_sx[j] : 0.0; rsy[k] = valid ? s_sy[j] : 0.0; rsz[k] = valid ? s_sz[j] : 0.0;
-    }
+    W.rc1 = 0; W.rpos1 = flow_next_base(cs, sh, rg, 0, nc, sh.fill);
+    W.B2 = flow_next_base(cs, sh, rg, W.rpos1, nc, sh.fill);
     Deferred df;
     df.commit_o = -1; df.commit_x = 0.0; df.ord_c = -1; df.ord_tag = 0; df.ord_w1 = 0; df.ord_co = 0; df.ord_rep = 0; df.ord_x = 0.0; df.ord_cx = 0.0;
-    StepIn<N> nx;                     // the inputs of the wave's next step, requested while the step before it runs
-    nx.p = -1; nx.it = 0; nx.c = 0; nx.epoch = 0; nx.type = 5; nx.idx = 0; nx.evt = 1; nx.dec_w = 6;
-    nx.g = 0.0; nx.r = 0.0; nx.logr = 0.0; nx.gA = 0.0; nx.gB = 0.0; nx.pt = 0;
-#pragma unroll
-    for (int k = 0; k < N; ++k) { nx.tob[k] = nx.tpr[k] = nx.aob[k] = nx.apr[k] = 0.0; nx.tc[k] = nx.ac[k] = 0.0; }
     int iter = i0 + 1;
     int c = wave;
     bool alive = wave < nc;
@@ -957,47 +756,38 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
             const int e = lds_ld(&sh.epoch);
             if (__builtin_expect(e != W.epoch, 0)) {
                 bool stands = false;
-                if (!flow_adopt(H, sh, rg, W, e, iter, c, false, stands)) continue;
-                flow_void_books(H, sh, wave, NW, nc, lane);
+                if (!flow_adopt(cs, sh, rg, W, e, iter, c, false, stands)) continue;
+                flow_void_books(cs, sh, wave, NW, nc, lane);
                 df.ord_c = -1;
-                nx.p = -1;
             }
         }
-        if (iter > lds_ld(&sh.last_iter) || lds_ld(&sh.c.err) != 0) break;
+        if (iter > lds_ld(&sh.last_iter) || sh.c.err != 0) break;
         if (__builtin_expect(W.rpos1 < 0 || W.B2 < 0, 0)) {      // predictions the window did not cover when they were made
-            if (W.rpos1 < 0) { W.rpos1 = flow_next_base(H.n_all, rg, W.rpos, nc - W.rc, sh.fill); W.rc1 = 0; }
-            if (W.B2 < 0 && W.rpos1 >= 0) W.B2 = flow_next_base(H.n_all, rg, W.rpos1, nc - W.rc1, sh.fill);
+            if (W.rpos1 < 0) { W.rpos1 = flow_next_base(cs, sh, rg, W.rpos, nc - W.rc, sh.fill); W.rc1 = 0; }
+            if (W.B2 < 0 && W.rpos1 >= 0) W.B2 = flow_next_base(cs, sh, rg, W.rpos1, nc - W.rc1, sh.fill);
         }
-        if (__builtin_expect(nx.p < 0 || nx.it != iter || nx.c != c || nx.epoch != W.epoch, 0)) {
-            // nothing (valid) was requested ahead for this step -- first step of a launch, after an epoch change, or the
-            // window did not reach: look its position up and request its inputs now
-            const int p = uni(hop_ahead(rg, W.rpos, c - W.rc));
-            if (__builtin_expect(p + 16 >= lds_ld(&sh.fill), 0)) {
-                // the window covers every step that can run (chain 0's wave keeps it 3 iterations ahead); a fail-stop
-                if (wave == 0) { if (lane == 0) sh.c.err = -13; break; }
-                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                bool dead = false;
-                while (p + 16 >= lds_ld(&sh.fill)) {
-                    if (sh.c.err != 0 || __builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) { dead = true; break; }
-                    __builtin_amdgcn_s_sleep(4);
-                }
-                if (dead) { if (lane == 0 && sh.c.err == 0) sh.c.err = -13; break; }
-            }
-            // (the request reads the chain's state: a commit still waiting to be issued goes out first)
-            flow_issue(H, df, lane, launch);
-            flow_request<NCH, F32>(H, rg, W, nx, iter, c, p, lane);
-        }
-        const StepIn<N> cur = nx;
+        const int p = hop_ahead(rg, W.rpos, c - W.rc);
         if (wave == 0 && c == 0 && lane == 0) {
             // chain 0's wave decides where the launch ends: record buffers or produced stream nearly used up.  Everybody
             // learns it before committing a step of this iteration (its turn waits for chain 0's check)
             int code = 0;
             if (sh.c.n_lik + 3 * nc > cs.cap_lik || sh.c.n_smp + 3 * nc > cs.cap_smp) code = 1;
-            else if (sh.avail < cur.p + 3 * wd + 32) code = 2;
+            else if (sh.avail < p + 3 * wd + 32) code = 2;
             if (code && lds_ld(&sh.last_iter) > iter) { sh.stop_code = code; lds_st(&sh.last_iter, iter); }
         }
-        const int r = flow_step<NCH, F32>(H, cs, sh, rg, W, cur, nx, df, rsx, rsy, rsz, s_sx, s_sy, s_sz, lane, wave, NW, launch,
-                                          wave == 0, look, back, rec_phase == 1);
+        // the window covers this step (chain 0's wave keeps it 3 iterations ahead); a fail-stop, never expected to wait
+        if (__builtin_expect(p + 16 >= lds_ld(&sh.fill), 0)) {
+            if (wave == 0) { if (lane == 0) sh.c.err = -13; break; }
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            bool dead = false;
+            while (p + 16 >= lds_ld(&sh.fill)) {
+                if (sh.c.err != 0 || __builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) { dead = true; break; }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (dead) { if (lane == 0 && sh.c.err == 0) sh.c.err = -13; break; }
+        }
+        const int r = flow_step<NCH, F32>(f, cs, sh, rg, W, df, s_sx, s_sy, s_sz, c, p, iter, lane, wave, NW, launch, wave == 0,
+                                          look, back, rec_phase == 1);
         if (r == kFlowRestart) continue;
         if (r == kFlowAbort) break;
         // ---- this wave's next step
@@ -1007,17 +797,17 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
             iter += 1;
             rec_phase = rec_phase + 1 == n_int ? 0 : rec_phase + 1;
             if (W.rpos1 < 0) {    // (the window did not cover the prediction when it was made: it does now)
-                W.rpos1 = flow_next_base(H.n_all, rg, W.rpos, nc - W.rc, 1 << 30); W.rc1 = 0;
+                W.rpos1 = flow_next_base(cs, sh, rg, W.rpos, nc - W.rc, 1 << 30); W.rc1 = 0;
                 W.B2 = -1;
             }
             W.rc = W.rc1; W.rpos = W.rpos1;
-            W.rc1 = 0; W.rpos1 = W.B2 >= 0 ? W.B2 : flow_next_base(H.n_all, rg, W.rpos, nc - W.rc, sh.fill);
-            W.B2 = flow_next_base(H.n_all, rg, W.rpos1, nc, sh.fill);
+            W.rc1 = 0; W.rpos1 = W.B2 >= 0 ? W.B2 : flow_next_base(cs, sh, rg, W.rpos, nc - W.rc, sh.fill);
+            W.B2 = flow_next_base(cs, sh, rg, W.rpos1, nc, sh.fill);
         }
     }
-    flow_issue(H, df, lane, launch);      // the last step's stores
+    flow_issue(cs, df, lane, launch);      // the last step's stores
 #ifdef HTM_STAMPS
-    if (lane == 0 && H.stamps && wave < 8) sh.stamp_acc[12 * wave + 11] += __builtin_amdgcn_s_memtime() - t_loop0;
+    if (lane == 0 && cs.stamps && wave < 8) sh.stamp_acc[12 * wave + 11] += __builtin_amdgcn_s_memtime() - t_loop0;
 #endif
     __syncthreads();
 #ifdef HTM_STAMPS

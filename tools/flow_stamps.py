@@ -46,6 +46,3 @@ for w in range(min(8, nc)):
     print("%-4d %8d " % (w, b[7]) + " ".join("%9.0f" % x for x in ph) + " %9.0f | %7d %9.0f %9.0f | %9.0f %9.0f" %
           (sum(ph), b[8], b[6] / nj, b[10] / nj, b[11] / max(1.0, iters), (b[11] - inside) / max(1, steps)))
 
-ns3 = max(1, d[12 * 3 + 7])
-print("wave 3, inside 'proposal' (ticks per step): consume %.0f | stores of the step before %.0f | proposal arithmetic %.0f | publish %.0f | request of the next step %.0f | order lookup (rest, to stamp 1) %.0f" %
-      (d[102] / ns3, d[103] / ns3, d[104] / ns3, d[105] / ns3, d[106] / ns3, (d[12 * 3 + 1] - sum(d[102:107])) / ns3))
