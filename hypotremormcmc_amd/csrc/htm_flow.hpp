@@ -25,6 +25,10 @@
 #pragma once
 #include "htm_step.hpp"
 
+#ifndef HTM_TOUCH
+#define HTM_TOUCH 1       // diagnostics: 0 = no touches of the next step's inputs
+#endif
+
 namespace htm {
 
 struct FlowShared : StepShared {
@@ -49,6 +53,24 @@ struct FlowShared : StepShared {
     unsigned ob_tag[kMaxChains];
     unsigned long long n_full_w, n_part_w;
 };
+
+// a wave-uniform value that reached a vector register (read from LDS, or the result of a vector compare) back in a scalar one
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// "Touches": loads whose data nobody reads -- they bring the lines the wave's NEXT step will read (its position and proposal
+// are in the stream window long before it runs) into the vector L1 / the scalar cache / L2 while this step is evaluated; the
+// next step's own loads, issued at its start as ever, then hit.  (Requesting the inputs themselves one step ahead into
+// registers was built and measured: correct, 15 % slower -- the register traffic and patch-ups cost more instructions than
+// the wait they removed, docs/experiments/r03_flow_inputs_one_step_ahead.patch.)  The destination registers stay reserved
+// (touch_release) until a wait has covered the loads: the data arrives whenever it arrives.
+__device__ __forceinline__ void touch_v(const void *p, int &sink) { asm volatile("global_load_dword %0, %1, off" : "=v"(sink) : "v"(p) : "memory"); }
+__device__ __forceinline__ void touch_s(const void *p, int &sink)
+{
+    const unsigned long long a = (unsigned long long)p;        // (the operand must BE in scalar registers: the constraint alone does not move it there)
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+    const void *q = (const void *)(((unsigned long long)hi << 32) | lo);
+    asm volatile("s_load_dword %0, %1, 0x0" : "=s"(sink) : "s"(q) : "memory");
+}
 
 // LDS words shared between the waves: relaxed accesses in program order.  LDS operations of a wave are executed in
 // issue order and the LDS is one serialisation point for the workgroup, so "release" and "acquire" are compiler
@@ -169,48 +191,12 @@ __device__ __forceinline__ bool flow_adopt(CsRef cs_, FlowShared &sh, const Ring
     return true;
 }
 
-// The global stores of a step -- its commit and the order it sends ahead -- are ISSUED AT THE START OF THE WAVE'S NEXT STEP,
-// right behind that step's loads.  Vector-memory operations of a wave complete in issue order and a write-through store is
-// acknowledged by memory (~1 us): a step that loads its inputs right after the commit store of the step before gets them
-// only when that store has been acknowledged (measured: 2.5 k of a step's 12 k cycles went there).  Issued behind the loads,
-// the stores are younger than everything the step waits for, and a step old by the time anything waits behind them.  What
-// the pending commit changes in the step's own inputs is patched into the registers (it is the same chain's, or nothing).
-struct Deferred {
-    int commit_o;                 // element to write, -1: none
-    double commit_x;
-    int ord_c;                    // chain whose order slot to write, -1: none
-    unsigned ord_tag, ord_w1, ord_co, ord_rep;
-    double ord_x, ord_cx;
-};
-__device__ __forceinline__ void flow_issue(CsRef cs_, Deferred &df, int lane, unsigned long long launch)
-{
-    CsRef cs = rebase(cs_);
-    if (df.commit_o >= 0) {
-        if (lane == 0) st_agent(cs.xall + df.commit_o, df.commit_x);
-        df.commit_o = -1;
-    }
-    if (df.ord_c >= 0) {
-        if (lane < cs.slot_rep * kGranPerSlot) {
-            const int gi = lane & 7;
-            const unsigned long long xb = (unsigned long long)__double_as_longlong(df.ord_x);
-            const unsigned long long cb = (unsigned long long)__double_as_longlong(df.ord_cx);
-            const unsigned pay = gi == 0 ? (unsigned)launch : gi == 1 ? df.ord_w1
-                               : gi == 2 ? (unsigned)(xb >> 32) : gi == 3 ? (unsigned)xb
-                               : gi == 4 ? df.ord_co                                    // the commit the workers must see, or ~0
-                               : gi == 5 ? (unsigned)(cb >> 32) : gi == 6 ? (unsigned)cb
-                               : df.ord_rep;                                            // element of the step in between (+1; 0 = none)
-            st_gran(cs.slots + (size_t)(lane >> 3) * cs.slot_stride + df.ord_c * kGranPerSlot + gi, df.ord_tag, pay);
-        }
-        df.ord_c = -1;
-    }
-}
-
 // One chain step from its front to its commit and the orders of the chain's coming full evaluations (the free-running
 // counterpart of chain_pass).  All 64 lanes execute with identical (uniform) values; lane <-> station only inside
 // event_misfit.  `ext`: this wave keeps the LDS window of the stream ahead (chain 0's wave, one round of <= 64 positions
 // per step, in flight under the step's own loads).  Returns the stream position after the step, kFlowRestart or kFlowAbort.
 template <int NCH, bool F32>
-__device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, const Ring &rg, FlowWave &W, Deferred &df,
+__device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, const Ring &rg, FlowWave &W,
                                          const double *s_sx, const double *s_sy, const double *s_sz, int c, int p, int iter,
                                          int lane, int wave, int NW, unsigned long long launch, bool ext, int look, int back,
                                          bool rec_now)
@@ -287,38 +273,10 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
             load_obs_regs<NCH, F32>(ob, f, d_e, lane);
         }
     }
-    // ---- every load of this step is on its way: the stores of the step before go out behind them (see Deferred); what the
-    // ---- pending commit changes in this step's inputs -- it is this chain's own latest commit, or another chain's -- is
-    // ---- patched in below
-    const int pend_o = df.commit_o;
-    const double pend_x = df.commit_x;
-    flow_issue(cs, df, lane, launch);
     FSTAMP(0);
-    double x_old = rl_f64(gathered_v, 0);
-    double hx = rl_f64(gathered_v, 1), hy = rl_f64(gathered_v, 2), hz = rl_f64(gathered_v, 3);
-    double beta = rl_f64(gathered_v, 4), q = rl_f64(gathered_v, 5);
-    if (__builtin_expect(pend_o >= 0, 1)) {
-        if (pend_o == o) x_old = pend_x;
-        if (pend_o == o_h) hx = pend_x;
-        if (pend_o == o_h + 1) hy = pend_x;
-        if (pend_o == o_h + 2) hz = pend_x;
-        if (pend_o == c) beta = pend_x;
-        if (pend_o == off_qs + c) q = pend_x;
-        if constexpr (NCH > 0) {
-            const int jt = pend_o - (off_tc + c * S_), ja = pend_o - (off_ac + c * S_);
-            if ((jt >= 0 && jt < S_) || (ja >= 0 && ja < S_)) {
-#pragma unroll
-                for (int k = 0; k < NCH; ++k) {
-                    if (lane + 64 * k == jt) st.tc[k] = pend_x;
-                    if (lane + 64 * k == ja) st.ac[k] = pend_x;
-                }
-            }
-            const int od = off_hy + c * nh + 3 * d_e;
-            if (pend_o == od) d_ex = pend_x;
-            if (pend_o == od + 1) d_ey = pend_x;
-            if (pend_o == od + 2) d_ez = pend_x;
-        }
-    }
+    const double x_old = rl_f64(gathered_v, 0);
+    const double hx = rl_f64(gathered_v, 1), hy = rl_f64(gathered_v, 2), hz = rl_f64(gathered_v, 3);
+    const double beta = rl_f64(gathered_v, 4), q = rl_f64(gathered_v, 5);
     const double L_cur = sh.L[c];
     const double x_new = x_old + g * step;                      // cls_model.f90:172
     const double da = x_new - mu, db = x_old - mu;
@@ -326,7 +284,7 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
     int ok = 1;
     if (ptype == 1) {                                           // :178-187
         if (x_new <= mu) { lpr = (double)-1.0e+30f; ok = 0; }
-        else lpr = lpr + log(x_new - mu) - log(x_old - mu);
+        else lpr = lpr + htm_log(x_new - mu) - htm_log(x_old - mu);       // (:184-185; htm_device.hpp: < 0.75 ulp, a third of the library routine's instructions)
     }
     const double r = ok ? r_ring : 0.0, logr = ok ? logr_ring : 0.0;
     const int cnt = dec_w - 1 + ok;                             // the judge draw happens only if prior_ok
@@ -348,6 +306,39 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
     if (ext && fill_to > sh.fill) {                             // (the window's loads were issued before the step's: they are there)
         pf_store(pf, rg);
         if (lane == 0) lds_st(&sh.fill, fill_to);
+    }
+    // ---- the wave's NEXT step: where it starts is a prediction in this epoch; what it will read is touched into the caches now
+    int tv0 = 0, tv1 = 0, tv2 = 0, tv3 = 0, tv4 = 0, ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0;
+    bool touched = false;
+#define TOUCH_RELEASE() do { if (touched) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+        asm volatile("" :: "v"(tv0), "v"(tv1), "v"(tv2), "v"(tv3), "v"(tv4), "s"(ts0), "s"(ts1), "s"(ts2), "s"(ts3), "s"(ts4), "s"(ts5)); touched = false; } } while (0)
+    if (HTM_TOUCH && NCH > 0 && ok != 0) {
+        const int cn = c + NW < nc_ ? c + NW : wave;
+        const bool same_it = cn > c;
+        const int itn = same_it ? iter : iter + 1;
+        const int rcn = same_it ? W.rc : W.rc1, rpn = same_it ? W.rpos : W.rpos1;
+        if (rpn >= 0 && cn >= rcn && itn <= uni(sh.c.iter_target)) {
+            const int pn = uni(hop_ahead(rg, rpn, cn - rcn));
+            if (pn + 16 < uni(sh.fill)) {
+                const i32x4 dn = reinterpret_cast<const i32x4 *>(rg.dec)[pn & M];
+                const int tn = uni(dn.x), in_ = uni(dn.y), en = uni(dn.z);
+                const int gon = tn == 1 ? 0 : tn == 2 ? off_tc : tn == 3 ? off_qs : tn == 4 ? off_ac : off_hy;
+                const int gxn = (tn == 1 || tn == 3) ? 1 : (tn == 2 || tn == 4) ? S_ : nh;
+                const int on = gon + cn * gxn + in_;
+                touch_s(muall_ + on, ts0); touch_s(rs2all_ + on, ts1); touch_s(stall_ + on, ts2); touch_s(ptall_ + on, ts3);
+                touch_v(xall_ + on, tv0);
+                if (en > 0 && itn > 1) {
+                    const int evn = en - 1;
+                    const double *rpt = f.rpsum_t, *rpa = f.rpsum_a;
+                    asm volatile("" : "+s"(rpt), "+s"(rpa));
+                    touch_s(rpt + evn, ts4); touch_s(rpa + evn, ts5);
+                    const size_t bn = (size_t)evn * (size_t)f.S + (size_t)(lane < f.S ? lane : f.S - 1);
+                    if constexpr (F32) { touch_v(f.t_obs32 + bn, tv1); touch_v(f.t_prec32 + bn, tv2); touch_v(f.a_obs32 + bn, tv3); touch_v(f.a_prec32 + bn, tv4); }
+                    else { touch_v(f.t_obs + bn, tv1); touch_v(f.t_prec + bn, tv2); touch_v(f.a_obs + bn, tv3); touch_v(f.a_prec + bn, tv4); }
+                }
+                touched = true;
+            }
+        }
     }
 
     FSTAMP(1);
@@ -442,7 +433,7 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
                     if (complete(0)) { which = 0; break; }
                     issue(0);
                     if (complete(1)) { which = 1; break; }
-                    if (sh.c.err != 0) return kFlowAbort;
+                    if (sh.c.err != 0) { TOUCH_RELEASE(); return kFlowAbort; }
                     if (__builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) {
                         if (lane == 0) {
                             sh.c.err = -8;
@@ -450,7 +441,7 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
                             dg[1] = c; dg[2] = tag; dg[3] = pre; dg[4] = pre_mode; dg[5] = iter; dg[6] = p; dg[7] = type; dg[8] = idx;
                             dg[9] = hi[0][0]; dg[10] = lo[0][0]; dg[11] = 1; dg[12] = p; dg[0] = 1;
                         }
-                        return kFlowAbort;
+                        { TOUCH_RELEASE(); return kFlowAbort; }
                     }
                 }
             }
@@ -478,8 +469,7 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
                 bool stands = false;
                 if (!flow_adopt(cs, sh, rg, W, e, iter, c, true, stands)) continue;
                 flow_void_books(cs, sh, wave, NW, nc_, lane);
-                df.ord_c = -1;                   // (an order not yet issued is void with the book)
-                if (!stands) return kFlowRestart;
+                if (!stands) { TOUCH_RELEASE(); return kFlowRestart; }
                 continue;
             }
             const int need = (lane < c ? key_i : key_m) + lane;
@@ -489,8 +479,8 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
                              (pk == need && (pk < W.akey || (ph == ((unsigned)W.epoch << 1))));
             if (__all(okl)) break;
             if ((spin & 15u) == 15u) {
-                if (sh.c.err != 0) return kFlowAbort;
-                if (__builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) { if (lane == 0) sh.c.err = -12; return kFlowAbort; }
+                if (sh.c.err != 0) { TOUCH_RELEASE(); return kFlowAbort; }
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) { if (lane == 0) sh.c.err = -12; { TOUCH_RELEASE(); return kFlowAbort; } }
             }
             __builtin_amdgcn_s_sleep(1);
         }
@@ -511,8 +501,8 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                 for (unsigned spin = 0; lds_ld(&sh.done[o2]) < want; ++spin) {
                     if ((spin & 15u) == 15u) {
-                        if (sh.c.err != 0) return kFlowAbort;
-                        if (__builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) { if (lane == 0) sh.c.err = -12; return kFlowAbort; }
+                        if (sh.c.err != 0) { TOUCH_RELEASE(); return kFlowAbort; }
+                        if (__builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) { if (lane == 0) sh.c.err = -12; { TOUCH_RELEASE(); return kFlowAbort; } }
                     }
                     __builtin_amdgcn_s_sleep(1);
                 }
@@ -527,6 +517,7 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
     // this wave's chain-state stores of EARLIER steps have landed before this step's commit goes out: an order sent after
     // the commit names only the commit itself for the workers to wait for
     drain_vmem();
+    TOUCH_RELEASE();      // (every touch has landed: its registers are free again)
     const int cool = (T < 1.0 + kEps) ? 1 : 0;
     const double L_post = acc ? L_new : L_cur;
     if (lane == 0) {
@@ -534,18 +525,13 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
         if (ok != 0) atomicAdd(need_full ? &sh.n_full_w : &sh.n_part_w, 1ull);      // (a step that is run again left before this point)
         if (cool) sh.np[c * 7 + type - 1] += 1;                 // cls_mcmc.f90:186-189
         if (acc) {                                              // :207-219
+            st_agent(cs.xall + o, x_new);
             if (o < rg.mir_n) rg.mx[o] = x_new;
             sh.L[c] = L_new;
             if (cool) sh.na[c * 7 + type - 1] += 1;
         }
         sh.L4[par][c] = L_post;
         lds_st(&sh.done[c], key);
-    }
-    if (acc) {
-        // the store to the chain's state in memory: at the start of the wave's next step (Deferred) -- unless this step's
-        // sample record is about to read the state back
-        if (rec_now && cool) { if (lane == 0) st_agent(cs.xall + o, x_new); }
-        else { df.commit_o = o; df.commit_x = x_new; }
     }
     FSTAMP(4);
     // ---- a rejected prior: this step was one draw shorter than the hop tables assume.  Everything after it starts
@@ -560,7 +546,6 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
         // (this wave's own view: as any wave whose step stands before the anchor; a later rejection may already have moved on)
         while (!flow_adopt(cs, sh, rg, W, lds_ld(&sh.epoch), iter, c, true, stands)) { }
         flow_void_books(cs, sh, wave, NW, nc_, lane);
-        df.ord_c = -1;
     }
     // ---- records of this step (hypo_tremor_mcmc.f90:270-280): slots by LDS atomics, put in order on the host
     if (__builtin_expect(sh.c.slog_cap > 0, 0)) {
@@ -639,10 +624,17 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
                     sh.ob_pos[c] = pj; sh.ob_tag[c] = (unsigned)tk; sh.ob_mode[c] = mode; sh.ob_mid[c] = d1.x | (d1.z << 3);
                 }
                 const unsigned tag = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)tk);
-                df.ord_c = c; df.ord_tag = tag; df.ord_w1 = (unsigned)jt | ((unsigned)ji << 3);
-                df.ord_x = jx_new; df.ord_cx = x_new;
-                df.ord_co = acc ? (unsigned)o : 0xffffffffu;
-                df.ord_rep = mode == 2 ? (unsigned)o_mid + 1u : 0u;
+                if (lane < cs.slot_rep * kGranPerSlot) {
+                    const int gi = lane & 7;
+                    const unsigned long long xb = (unsigned long long)__double_as_longlong(jx_new);
+                    const unsigned long long cb = (unsigned long long)__double_as_longlong(x_new);
+                    const unsigned pay = gi == 0 ? (unsigned)launch : gi == 1 ? ((unsigned)jt | ((unsigned)ji << 3))
+                                       : gi == 2 ? (unsigned)(xb >> 32) : gi == 3 ? (unsigned)xb
+                                       : gi == 4 ? (acc ? (unsigned)o : 0xffffffffu)              // the commit the workers must see
+                                       : gi == 5 ? (unsigned)(cb >> 32) : gi == 6 ? (unsigned)cb
+                                       : (mode == 2 ? (unsigned)o_mid + 1u : 0u);                  // element of the step in between (+1; 0 = none)
+                    st_gran(cs.slots + (size_t)(lane >> 3) * cs.slot_stride + c * kGranPerSlot + gi, tag, pay);
+                }
             }
         }
     }
@@ -657,6 +649,7 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
     return p + cnt;
 }
 
+#undef TOUCH_RELEASE
 // block 0 of a k_mcmc<NCH, F32, 0> launch when the host selects the free-running master (htm_hip.hip: flow_ok)
 template <int NCH, bool F32>
 __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, int ring_size, int wmax, unsigned long long launch)
@@ -742,8 +735,6 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
     W.epoch = 0; W.akey = 0; W.rc = 0; W.rpos = 0;
     W.rc1 = 0; W.rpos1 = flow_next_base(cs, sh, rg, 0, nc, sh.fill);
     W.B2 = flow_next_base(cs, sh, rg, W.rpos1, nc, sh.fill);
-    Deferred df;
-    df.commit_o = -1; df.commit_x = 0.0; df.ord_c = -1; df.ord_tag = 0; df.ord_w1 = 0; df.ord_co = 0; df.ord_rep = 0; df.ord_x = 0.0; df.ord_cx = 0.0;
     int iter = i0 + 1;
     int c = wave;
     bool alive = wave < nc;
@@ -758,7 +749,6 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
                 bool stands = false;
                 if (!flow_adopt(cs, sh, rg, W, e, iter, c, false, stands)) continue;
                 flow_void_books(cs, sh, wave, NW, nc, lane);
-                df.ord_c = -1;
             }
         }
         if (iter > lds_ld(&sh.last_iter) || sh.c.err != 0) break;
@@ -786,7 +776,7 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
             }
             if (dead) { if (lane == 0 && sh.c.err == 0) sh.c.err = -13; break; }
         }
-        const int r = flow_step<NCH, F32>(f, cs, sh, rg, W, df, s_sx, s_sy, s_sz, c, p, iter, lane, wave, NW, launch, wave == 0,
+        const int r = flow_step<NCH, F32>(f, cs, sh, rg, W, s_sx, s_sy, s_sz, c, p, iter, lane, wave, NW, launch, wave == 0,
                                           look, back, rec_phase == 1);
         if (r == kFlowRestart) continue;
         if (r == kFlowAbort) break;
@@ -805,7 +795,6 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
             W.B2 = flow_next_base(cs, sh, rg, W.rpos1, nc, sh.fill);
         }
     }
-    flow_issue(cs, df, lane, launch);      // the last step's stores
 #ifdef HTM_STAMPS
     if (lane == 0 && cs.stamps && wave < 8) sh.stamp_acc[12 * wave + 11] += __builtin_amdgcn_s_memtime() - t_loop0;
 #endif
