@@ -26,7 +26,7 @@
 #include "htm_step.hpp"
 
 #ifndef HTM_TOUCH
-#define HTM_TOUCH 1       // diagnostics: 0 = no touches of the next step's inputs
+#define HTM_TOUCH 0       // diagnostics: 0 = no touches of the next step's inputs
 #endif
 
 namespace htm {
@@ -75,7 +75,7 @@ __device__ __forceinline__ void touch_s(const void *p, int &sink)
 // LDS words shared between the waves: relaxed accesses in program order.  LDS operations of a wave are executed in
 // issue order and the LDS is one serialisation point for the workgroup, so "release" and "acquire" are compiler
 // barriers here, not waits for outstanding memory operations.
-__device__ __forceinline__ int lds_ld(const int *p) { const int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); asm volatile("" ::: "memory"); return v; }
+__device__ __forceinline__ int lds_ld(const int *p) { const int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); asm volatile("" ::: "memory"); return uni(v); }   // (every int read this way sits at a wave-uniform address)
 __device__ __forceinline__ unsigned long long lds_ld(const unsigned long long *p) { const unsigned long long v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); asm volatile("" ::: "memory"); return v; }
 __device__ __forceinline__ void lds_st(int *p, int v) { asm volatile("" ::: "memory"); __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_st(unsigned long long *p, unsigned long long v) { asm volatile("" ::: "memory"); __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -109,13 +109,14 @@ __device__ __forceinline__ bool flow_swap_at(CsRef cs_, const StepShared &sh, co
     if (n_all <= 1) return true;
     if (E + 2 >= limit) return false;
     const i32x4 sw = reinterpret_cast<const i32x4 *>(rg.sw)[E & rg.mask];
-    if (sw.z > 0) { i1 = sw.x; i2 = sw.y; nd = sw.z + 1; return E + nd < limit; }
+    const int swz = uni(sw.z);
+    if (swz > 0) { i1 = uni(sw.x); i2 = uni(sw.y); nd = swz + 1; return E + nd < limit; }
     int pos = E;
-    i1 = (int)(rg.U[pos & rg.mask] * cs.n_procs * cs.n_chains);
+    i1 = uni((int)(rg.U[pos & rg.mask] * cs.n_procs * cs.n_chains));
     pos++;
     for (;;) {
         if (pos + 1 >= limit) return false;
-        i2 = (int)(rg.U[pos & rg.mask] * cs.n_procs * cs.n_chains);
+        i2 = uni((int)(rg.U[pos & rg.mask] * cs.n_procs * cs.n_chains));
         pos++;
         if (i1 != i2) break;
     }
@@ -127,7 +128,7 @@ __device__ __forceinline__ bool flow_swap_at(CsRef cs_, const StepShared &sh, co
 __device__ __forceinline__ int flow_next_base(CsRef cs, const StepShared &sh, const Ring &rg, int pos, int n, int limit)
 {
     if (pos < 0) return -1;
-    const int E = hop_ahead(rg, pos, n);
+    const int E = uni(hop_ahead(rg, pos, n));
     int i1, i2, nd;
     if (E + 16 >= limit || !flow_swap_at(cs, sh, rg, E, limit, i1, i2, nd)) return -1;
     return E + nd;
@@ -139,8 +140,8 @@ __device__ __forceinline__ void flow_from_anchor(CsRef cs_, const FlowShared &sh
 {
     CsRef cs = rebase(cs_);
     const int nc = cs.n_chains;
-    const int key = (int)(unsigned)(a >> 32), pos = (int)(unsigned)a;
-    ia = sh.i0 + key / nc; ca = key - (key / nc) * nc; ap = pos;
+    const int key = uni((int)(unsigned)(a >> 32)), pos = uni((int)(unsigned)a);
+    ia = uni(sh.i0) + key / nc; ca = key - (key / nc) * nc; ap = pos;
     if (ca == 0) {
         int i1, i2, nd;
         flow_swap_at(cs, sh, rg, pos, 1 << 30, i1, i2, nd);     // (the rejected step's own wave read these positions: covered)
@@ -152,7 +153,7 @@ __device__ __forceinline__ void flow_from_anchor(CsRef cs_, const FlowShared &sh
 __device__ __forceinline__ void flow_void_books(CsRef cs, FlowShared &sh, int wave, int NW, int nc, int lane)
 {
     for (int c = wave; c < nc; c += NW) {
-        if (sh.ob_pos[c] != -1) {
+        if (uni(sh.ob_pos[c]) != -1) {
             if (lane == 0) { void_slot(cs, c); sh.ob_pos[c] = -1; }
         }
     }
@@ -167,11 +168,11 @@ __device__ __forceinline__ bool flow_adopt(CsRef cs_, FlowShared &sh, const Ring
     const int nc = cs.n_chains;
     const unsigned long long a = lds_ld(&sh.anch[e & 1]);
     if (lds_ld(&sh.epoch) != e) return false;
-    const int akey = (int)(unsigned)(a >> 32);
-    const int key = (it - sh.i0) * nc + c;
+    const int akey = uni((int)(unsigned)(a >> 32));
+    const int key = (it - uni(sh.i0)) * nc + c;
     int ia, ca, ap;
     flow_from_anchor(cs, sh, rg, a, ia, ca, ap);
-    const int limit = sh.fill;
+    const int limit = uni(sh.fill);
     stands = in_turn && key < akey;
     W.epoch = e; W.akey = akey;
     if (!stands) {
@@ -216,10 +217,10 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
     pf.p = -1;
     int fill_to = 0;
     if (ext) {
-        const int fl = sh.fill;
+        const int fl = uni(sh.fill);
         // (this step is chain c's: the iteration's base lies 4 c .. 6 c positions back; the other waves may still read `back`
         // positions behind it, and want `look` positions ahead of it)
-        fill_to = min(min(p - 4 * c + look, sh.avail), p - 6 * c - back + M + 1);
+        fill_to = min(min(p - 4 * c + look, uni(sh.avail)), p - 6 * c - back + M + 1);
         if (fill_to > fl + 64) fill_to = fl + 64;
         if (fill_to > fl) pf_load(pf, cs, sh, fl + lane, fill_to);
     }
@@ -254,8 +255,8 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
         }
     }
     // the book of this chain: is this step's order out already, and how
-    const int book_pos = sh.ob_pos[c], book_mode = sh.ob_mode[c], book_mid = sh.ob_mid[c];
-    const unsigned book_tag = sh.ob_tag[c];
+    const int book_pos = uni(sh.ob_pos[c]), book_mode = uni(sh.ob_mode[c]), book_mid = uni(sh.ob_mid[c]);
+    const unsigned book_tag = (unsigned)uni((int)sh.ob_tag[c]);
     const bool pre = !partial && book_pos == p;
     const int pre_mode = pre ? book_mode : 0;
     // a full-evaluation step whose order went out two steps ahead adds the event of the step in between itself (below):
@@ -286,9 +287,11 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
         if (x_new <= mu) { lpr = (double)-1.0e+30f; ok = 0; }
         else lpr = lpr + htm_log(x_new - mu) - htm_log(x_old - mu);       // (:184-185; htm_device.hpp: < 0.75 ulp, a third of the library routine's instructions)
     }
+    ok = uni(ok);
     const double r = ok ? r_ring : 0.0, logr = ok ? logr_ring : 0.0;
     const int cnt = dec_w - 1 + ok;                             // the judge draw happens only if prior_ok
-    const int key = (iter - sh.i0) * nc_ + c;
+    const int i0_ = uni(sh.i0);
+    const int key = (iter - i0_) * nc_ + c;
     // ---- the step has passed (or failed) its prior check: the later steps may go ahead on it
     if (c == nc_ - 1) {                                         // where this iteration's swap starts, and what it draws there
         const int E = p + cnt, k4 = iter & 3;
@@ -303,7 +306,7 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
     if (lane == 0) {
         lds_st(&sh.prog[c], ((unsigned long long)(((unsigned)W.epoch << 1) | (ok ? 0u : 1u)) << 32) | (unsigned)key);
     }
-    if (ext && fill_to > sh.fill) {                             // (the window's loads were issued before the step's: they are there)
+    if (ext && fill_to > uni(sh.fill)) {                             // (the window's loads were issued before the step's: they are there)
         pf_store(pf, rg);
         if (lane == 0) lds_st(&sh.fill, fill_to);
     }
@@ -460,7 +463,7 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
     // ---- the step's turn: every step before it in stream order has passed its check in this epoch (or lies before the
     // ---- epoch's anchor: checked earlier, final).  Lanes <-> chains.
     {
-        const int key_i = (iter - sh.i0) * nc_, key_m = key_i - nc_;
+        const int key_i = (iter - i0_) * nc_, key_m = key_i - nc_;
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         for (unsigned spin = 0;; ++spin) {
             const unsigned long long pv = lane < nc_ ? lds_ld(&sh.prog[lane]) : 0ull;
@@ -490,14 +493,14 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
     // ---- here by the waves of the two chains it concerns -- each evaluates the same expression on the same values
     const int par = iter & 3, ppar = (iter - 1) & 3;
     double T = sh.T4[par][c], rT = sh.rT4[par][c];        // (first iteration of a launch: written by the prologue)
-    if (iter - 1 > sh.i0) {
+    if (iter - 1 > i0_) {
         T = sh.T4[ppar][c]; rT = sh.rT4[ppar][c];
         if (cs.n_procs * nc_ > 1) {
             // (written by the last chain's wave before it published its check; this step's turn has seen that check)
-            const int i1 = lds_ld(&sh.sw_i1[ppar]), i2 = sh.sw_i2[ppar];
+            const int i1 = lds_ld(&sh.sw_i1[ppar]), i2 = uni(sh.sw_i2[ppar]);
             if (c == i1 || c == i2) {
                 const int o2 = c == i1 ? i2 : i1;
-                const int want = (iter - 1 - sh.i0) * nc_ + o2;
+                const int want = (iter - 1 - i0_) * nc_ + o2;
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                 for (unsigned spin = 0; lds_ld(&sh.done[o2]) < want; ++spin) {
                     if ((spin & 15u) == 15u) {
@@ -513,12 +516,12 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
             }
         }
     }
-    const int acc = (ok != 0 && metropolis(L_new, L_cur, rT, lpr, r, logr)) ? 1 : 0;       // cls_mcmc.f90:193-203
+    const int acc = uni((ok != 0 && metropolis(L_new, L_cur, rT, lpr, r, logr)) ? 1 : 0);       // cls_mcmc.f90:193-203
     // this wave's chain-state stores of EARLIER steps have landed before this step's commit goes out: an order sent after
     // the commit names only the commit itself for the workers to wait for
     drain_vmem();
     TOUCH_RELEASE();      // (every touch has landed: its registers are free again)
-    const int cool = (T < 1.0 + kEps) ? 1 : 0;
+    const int cool = uni((T < 1.0 + kEps) ? 1 : 0);
     const double L_post = acc ? L_new : L_cur;
     if (lane == 0) {
         sh.T4[par][c] = T; sh.rT4[par][c] = rT;
@@ -548,8 +551,8 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
         flow_void_books(cs, sh, wave, NW, nc_, lane);
     }
     // ---- records of this step (hypo_tremor_mcmc.f90:270-280): slots by LDS atomics, put in order on the host
-    if (__builtin_expect(sh.c.slog_cap > 0, 0)) {
-        const int row = sh.c.slog_n + (iter - sh.i0 - 1) * nc_ + c;
+    if (__builtin_expect(uni(sh.c.slog_cap) > 0, 0)) {
+        const int row = uni(sh.c.slog_n) + (iter - i0_ - 1) * nc_ + c;
         if (lane == 0 && row < sh.c.slog_cap) {
             int32_t *ir = cs.slog_i + 8 * (size_t)row;
             double *dr = cs.slog_d + 4 * (size_t)row;
@@ -586,21 +589,24 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
     // ---- if it needs one (one step ahead), else -- that step being a hypocentre step -- the one after it (two steps ahead:
     // ---- the workers leave the event of the step in between out, this wave adds it).  Positions are predictions; a step
     // ---- uses an order only if it starts exactly where the order was written for, and an epoch change voids the book.
-    if (rg.mir_n > 0 && sh.ob_pos[c] == -1 && iter + 1 <= sh.c.iter_target) {
-        const int lim = sh.fill - 8;
+    const int it_target = uni(sh.c.iter_target);
+    if (rg.mir_n > 0 && uni(sh.ob_pos[c]) == -1 && iter + 1 <= it_target) {
+        const int lim = uni(sh.fill) - 8;
         // this chain's next step is its step of the next iteration (this wave's other chains of this iteration come first)
-        const int p1 = (W.rpos1 >= 0 && c >= W.rc1) ? hop_ahead(rg, W.rpos1, c - W.rc1) : -1;
+        const int p1 = (W.rpos1 >= 0 && c >= W.rc1) ? uni(hop_ahead(rg, W.rpos1, c - W.rc1)) : -1;
         const bool w1 = p1 >= 0 && p1 < lim;
-        const i32x4 d1 = reinterpret_cast<const i32x4 *>(rg.dec)[(w1 ? p1 : 0) & M];
+        const i32x4 d1v = reinterpret_cast<const i32x4 *>(rg.dec)[(w1 ? p1 : 0) & M];
+        struct { int x, y, z; } d1 = {uni(d1v.x), uni(d1v.y), uni(d1v.z)};
         const bool job1 = w1 && d1.x >= 1 && d1.x <= 4;
         int mode = job1 ? 1 : 0;
         int pj = p1;
         int jt = d1.x, ji = d1.y;
-        if (HTM_ALLOW2 && NCH > 0 && w1 && !job1 && iter + 2 <= sh.c.iter_target && W.B2 >= 0) {
-            const int p2 = hop_ahead(rg, W.B2, c);
+        if (HTM_ALLOW2 && NCH > 0 && w1 && !job1 && iter + 2 <= it_target && W.B2 >= 0) {
+            const int p2 = uni(hop_ahead(rg, W.B2, c));
             if (p2 < lim) {
                 const i32x4 d2 = reinterpret_cast<const i32x4 *>(rg.dec)[p2 & M];
-                if (d2.x >= 1 && d2.x <= 4) { mode = 2; pj = p2; jt = d2.x; ji = d2.y; }
+                const int d2x = uni(d2.x);
+                if (d2x >= 1 && d2x <= 4) { mode = 2; pj = p2; jt = d2x; ji = uni(d2.y); }
             }
         }
         if (mode) {
@@ -706,7 +712,7 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
         sh.n_full_w = 0ull; sh.n_part_w = 0ull;
     }
     __syncthreads();
-    const int i0 = sh.i0;
+    const int i0 = uni(sh.i0);
     for (int c = tid; c < kMaxChains; c += blockDim.x) {
         sh.ob_pos[c] = -1;
         sh.prog[c] = (unsigned long long)(unsigned)c;          // key(i0, c), epoch 0, prior ok
@@ -718,8 +724,8 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
             sh.rT4[(i0 + 1) & 3][c] = 1.0 / T; sh.rT4[i0 & 3][c] = 1.0 / T;
         }
     }
-    if (sh.c.iter_done >= sh.c.iter_target || sh.c.stop || sh.c.err) return;      // (uniform)
-    if (sh.avail < 3 * wmax) {                                 // the produced stream does not cover a safe stretch: the host refills
+    if (uni(sh.c.iter_done) >= uni(sh.c.iter_target) || uni(sh.c.stop) || uni(sh.c.err)) return;      // (uniform)
+    if (uni(sh.avail) < 3 * wmax) {                                 // the produced stream does not cover a safe stretch: the host refills
         __syncthreads();
         if (tid == 0) { sh.c.stop = 2; *cs.ctrl = sh.c; }
         return;
@@ -733,8 +739,8 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
 
     FlowWave W;
     W.epoch = 0; W.akey = 0; W.rc = 0; W.rpos = 0;
-    W.rc1 = 0; W.rpos1 = flow_next_base(cs, sh, rg, 0, nc, sh.fill);
-    W.B2 = flow_next_base(cs, sh, rg, W.rpos1, nc, sh.fill);
+    W.rc1 = 0; W.rpos1 = flow_next_base(cs, sh, rg, 0, nc, uni(sh.fill));
+    W.B2 = flow_next_base(cs, sh, rg, W.rpos1, nc, uni(sh.fill));
     int iter = i0 + 1;
     int c = wave;
     bool alive = wave < nc;
@@ -751,18 +757,18 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
                 flow_void_books(cs, sh, wave, NW, nc, lane);
             }
         }
-        if (iter > lds_ld(&sh.last_iter) || sh.c.err != 0) break;
+        if (iter > lds_ld(&sh.last_iter) || lds_ld(&sh.c.err) != 0) break;
         if (__builtin_expect(W.rpos1 < 0 || W.B2 < 0, 0)) {      // predictions the window did not cover when they were made
-            if (W.rpos1 < 0) { W.rpos1 = flow_next_base(cs, sh, rg, W.rpos, nc - W.rc, sh.fill); W.rc1 = 0; }
-            if (W.B2 < 0 && W.rpos1 >= 0) W.B2 = flow_next_base(cs, sh, rg, W.rpos1, nc - W.rc1, sh.fill);
+            if (W.rpos1 < 0) { W.rpos1 = flow_next_base(cs, sh, rg, W.rpos, nc - W.rc, uni(sh.fill)); W.rc1 = 0; }
+            if (W.B2 < 0 && W.rpos1 >= 0) W.B2 = flow_next_base(cs, sh, rg, W.rpos1, nc - W.rc1, uni(sh.fill));
         }
-        const int p = hop_ahead(rg, W.rpos, c - W.rc);
+        const int p = uni(hop_ahead(rg, W.rpos, c - W.rc));
         if (wave == 0 && c == 0 && lane == 0) {
             // chain 0's wave decides where the launch ends: record buffers or produced stream nearly used up.  Everybody
             // learns it before committing a step of this iteration (its turn waits for chain 0's check)
             int code = 0;
-            if (sh.c.n_lik + 3 * nc > cs.cap_lik || sh.c.n_smp + 3 * nc > cs.cap_smp) code = 1;
-            else if (sh.avail < p + 3 * wd + 32) code = 2;
+            if (uni(sh.c.n_lik) + 3 * nc > cs.cap_lik || uni(sh.c.n_smp) + 3 * nc > cs.cap_smp) code = 1;
+            else if (uni(sh.avail) < p + 3 * wd + 32) code = 2;
             if (code && lds_ld(&sh.last_iter) > iter) { sh.stop_code = code; lds_st(&sh.last_iter, iter); }
         }
         // the window covers this step (chain 0's wave keeps it 3 iterations ahead); a fail-stop, never expected to wait
@@ -791,8 +797,8 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
                 W.B2 = -1;
             }
             W.rc = W.rc1; W.rpos = W.rpos1;
-            W.rc1 = 0; W.rpos1 = W.B2 >= 0 ? W.B2 : flow_next_base(cs, sh, rg, W.rpos, nc - W.rc, sh.fill);
-            W.B2 = flow_next_base(cs, sh, rg, W.rpos1, nc, sh.fill);
+            W.rc1 = 0; W.rpos1 = W.B2 >= 0 ? W.B2 : flow_next_base(cs, sh, rg, W.rpos, nc - W.rc, uni(sh.fill));
+            W.B2 = flow_next_base(cs, sh, rg, W.rpos1, nc, uni(sh.fill));
         }
     }
 #ifdef HTM_STAMPS
