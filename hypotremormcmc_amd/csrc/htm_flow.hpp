@@ -50,6 +50,9 @@ struct FlowShared : StepShared {
     unsigned long long n_full_w, n_part_w;
 };
 
+// a wave-uniform value that reached a vector register (read from LDS) back in a scalar one
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 // LDS words shared between the waves: relaxed accesses in program order.  LDS operations of a wave are executed in
 // issue order and the LDS is one serialisation point for the workgroup, so "release" and "acquire" are compiler
 // barriers here, not waits for outstanding memory operations.
@@ -73,6 +76,17 @@ struct FlowWave {                 // a wave's predictions (wave-uniform)
 #else
 #define FSTAMP(k) do { } while (0)
 #endif
+
+// What a wave with ONE chain knows about its next step before the step begins: looked up from the stream window while the
+// current step is evaluated (hop table -> start position -> decoded proposal, Gaussian, judge draw: two dependent LDS round
+// trips that used to open every step, and the same again for the orders sent ahead and for the base of the iteration after
+// next), so that the LDS latencies run under the evaluation instead of in front of it.
+struct FlowNext {
+    int p, it, c, epoch;          // start position of step (it, c), predicted in `epoch`; p < 0: nothing known
+    int type, idx, evt, dec_w;
+    double g, r, logr;
+    int b3;                       // base of iteration it + 2 (what the wave's B2 becomes when it moves on); -1: not known
+};
 
 constexpr int kFlowRestart = -1;  // flow_step: the step's position was disproved before its turn came: run it again
 constexpr int kFlowAbort = -2;    // flow_step: a wait gave up (sh.c.err is set)
@@ -174,7 +188,7 @@ __device__ __forceinline__ bool flow_adopt(CsRef cs_, FlowShared &sh, const Ring
 // event_misfit.  `ext`: this wave keeps the LDS window of the stream ahead (chain 0's wave, one round of <= 64 positions
 // per step, in flight under the step's own loads).  Returns the stream position after the step, kFlowRestart or kFlowAbort.
 template <int NCH, bool F32>
-__device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, const Ring &rg, FlowWave &W,
+__device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, const Ring &rg, FlowWave &W, FlowNext &nx,
                                          const double *s_sx, const double *s_sy, const double *s_sz, int c, int p, int iter,
                                          int lane, int wave, int NW, unsigned long long launch, bool ext, int look, int back,
                                          bool rec_now)
@@ -204,11 +218,20 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
     const double *xall_ = cs.xall, *muall_ = cs.muall, *rs2all_ = cs.rs2all, *stall_ = cs.stall;
     const int *ptall_ = cs.ptall;
     const int nc_ = cs.n_chains, S_ = cs.S, nh = 3 * cs.E;
-    const i32x4 dec = reinterpret_cast<const i32x4 *>(rg.dec)[p & M];      // decoded ahead of time (htm_stream.hpp)
     asm volatile("" : "+s"(xall_), "+s"(muall_), "+s"(rs2all_), "+s"(stall_), "+s"(ptall_));
-    const int type = __builtin_amdgcn_readfirstlane(dec.x), idx = __builtin_amdgcn_readfirstlane(dec.y);
-    const int evt = __builtin_amdgcn_readfirstlane(dec.z), dec_w = __builtin_amdgcn_readfirstlane(dec.w);
-    const double g = rg.pg[p & M], r_ring = rg.pr[p & M], logr_ring = rg.plogr[p & M];
+    // the decoded proposal (htm_stream.hpp), its Gaussian and its judge draw: looked up during the step before (FlowNext), or here
+    int type, idx, evt, dec_w;
+    double g, r_ring, logr_ring;
+    if (nx.p == p && nx.it == iter && nx.c == c && nx.epoch == W.epoch) {
+        type = nx.type; idx = nx.idx; evt = nx.evt; dec_w = nx.dec_w; g = nx.g; r_ring = nx.r; logr_ring = nx.logr;
+    } else {
+        const i32x4 dec = reinterpret_cast<const i32x4 *>(rg.dec)[p & M];
+        // wave-uniform by construction: keep them in scalar registers (addresses and selects become SALU work)
+        type = __builtin_amdgcn_readfirstlane(dec.x); idx = __builtin_amdgcn_readfirstlane(dec.y);
+        evt = __builtin_amdgcn_readfirstlane(dec.z); dec_w = __builtin_amdgcn_readfirstlane(dec.w);
+        g = rg.pg[p & M]; r_ring = rg.pr[p & M]; logr_ring = rg.plogr[p & M];
+    }
+    nx.p = -1;
     const bool partial = evt > 0 && iter > 1;       // hypo_tremor_mcmc.f90:246
     const int off_tc = nc_, off_qs = nc_ + nc_ * S_, off_ac = 2 * nc_ + nc_ * S_, off_hy = 2 * nc_ + 2 * nc_ * S_;
     const int goff = type == 1 ? 0 : type == 2 ? off_tc : type == 3 ? off_qs : type == 4 ? off_ac : off_hy;
@@ -289,6 +312,9 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
     FSTAMP(1);
     double L_new = 0.0;
     int need_full = 0;
+    int la = 0, la_epoch = 0, hA = 0, hB = 0, hE = 0, la_p1 = 0, la_p2 = 0, la_E2 = 0;
+    i32x4 d1v = {0, 0, 0, 0}, d2v = {0, 0, 0, 0}, swv = {0, 0, 0, 0};
+    double la_g = 0.0, la_r = 0.0, la_logr = 0.0;
     if (__builtin_expect(ok != 0, 1)) {
         if (__builtin_expect(partial, 1)) {
             const int cmp = idx - 3 * ev;        // 0 x, 1 y, 2 z of event ev (selects: see htm_step.hpp)
@@ -296,9 +322,30 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
             const double py[2] = {hy, cmp == 1 ? x_new : hy};
             const double pz[2] = {hz, cmp == 2 ? x_new : hz};
             double out[2];
+            // look-ahead, first round trip (a wave with one chain): the hop-table entries that give the start of this chain's
+            // next step, of its step after that, and the end of the iteration after next -- issued here, used behind the evaluation
+            if (NW >= nc_ && W.rpos1 >= 0 && W.B2 >= 0 && c >= W.rc1 && iter + 1 <= sh.c.iter_target && rg.mir_n > 0) {
+                la = 1; la_epoch = W.epoch;
+                const int n1 = c - W.rc1;
+                if (n1 > 0) hA = rg.hop[(W.rpos1 & M) * kHops + n1 - 1];
+                if (c > 0) hB = rg.hop[(W.B2 & M) * kHops + c - 1];
+                hE = rg.hop[(W.B2 & M) * kHops + nc_ - 1];
+            }
             if constexpr (NCH > 0) event_misfit<NCH, 2, F32>(f, ob, lane, st, px, py, pz, beta, q, out);
             else event_misfit_generic<2>(f, ev, lane, s_sx, s_sy, s_sz, tc, ac, 0, -1, 0.0, px, py, pz, beta, q, out);
             L_new = L_cur + wave_sum1(out[0] - out[1]);
+            // look-ahead, second round trip: what the stream holds at those positions -- used after the commit
+            if (la) {
+                la_p1 = W.rpos1 + uni(hA); la_p2 = W.B2 + uni(hB); la_E2 = W.B2 + uni(hE);
+                const int lim = uni(sh.fill) - 16;
+                if (la_p1 < lim && la_p2 < lim && la_E2 + 16 < lim) {
+                    la = 2;
+                    d1v = reinterpret_cast<const i32x4 *>(rg.dec)[la_p1 & M];
+                    d2v = reinterpret_cast<const i32x4 *>(rg.dec)[la_p2 & M];
+                    swv = reinterpret_cast<const i32x4 *>(rg.sw)[la_E2 & M];
+                    la_g = rg.pg[la_p1 & M]; la_r = rg.pr[la_p1 & M]; la_logr = rg.plogr[la_p1 & M];
+                }
+            }
         } else {
             need_full = 1;
             // ---- work order: recognised (sent by this wave one or two steps ago) or sent now -------------------------
@@ -530,21 +577,41 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
     // ---- if it needs one (one step ahead), else -- that step being a hypocentre step -- the one after it (two steps ahead:
     // ---- the workers leave the event of the step in between out, this wave adds it).  Positions are predictions; a step
     // ---- uses an order only if it starts exactly where the order was written for, and an epoch change voids the book.
+    // (the look-ahead stands if no epoch change came between: then the next step's start and proposal go to the next call)
+    const bool la_ok = la == 2 && la_epoch == W.epoch && ok != 0;
+    struct { int x, y, z; } d1 = {0, 0, 0};
+    if (la_ok) {
+        d1.x = uni(d1v.x); d1.y = uni(d1v.y); d1.z = uni(d1v.z);
+        nx.p = la_p1; nx.it = iter + 1; nx.c = c; nx.epoch = W.epoch;
+        nx.type = d1.x; nx.idx = d1.y; nx.evt = d1.z; nx.dec_w = uni(d1v.w);
+        nx.g = la_g; nx.r = la_r; nx.logr = la_logr;
+        const int swz = uni(swv.z);
+        nx.b3 = cs.n_procs * nc_ > 1 ? (swz > 0 ? la_E2 + swz + 1 : -1) : la_E2;
+    }
     if (rg.mir_n > 0 && sh.ob_pos[c] == -1 && iter + 1 <= sh.c.iter_target) {
         const int lim = sh.fill - 8;
-        // this chain's next step is its step of the next iteration (this wave's other chains of this iteration come first)
-        const int p1 = (W.rpos1 >= 0 && c >= W.rc1) ? hop_ahead(rg, W.rpos1, c - W.rc1) : -1;
-        const bool w1 = p1 >= 0 && p1 < lim;
-        const i32x4 d1 = reinterpret_cast<const i32x4 *>(rg.dec)[(w1 ? p1 : 0) & M];
-        const bool job1 = w1 && d1.x >= 1 && d1.x <= 4;
-        int mode = job1 ? 1 : 0;
-        int pj = p1;
-        int jt = d1.x, ji = d1.y;
-        if (HTM_ALLOW2 && NCH > 0 && w1 && !job1 && iter + 2 <= sh.c.iter_target && W.B2 >= 0) {
-            const int p2 = hop_ahead(rg, W.B2, c);
-            if (p2 < lim) {
-                const i32x4 d2 = reinterpret_cast<const i32x4 *>(rg.dec)[p2 & M];
-                if (d2.x >= 1 && d2.x <= 4) { mode = 2; pj = p2; jt = d2.x; ji = d2.y; }
+        int p1 = -1, mode = 0, pj = -1, jt = 0, ji = 0;
+        bool w1 = false, job1 = false;
+        if (la_ok) {
+            p1 = la_p1; w1 = true;
+            job1 = d1.x >= 1 && d1.x <= 4;
+            mode = job1 ? 1 : 0; pj = p1; jt = d1.x; ji = d1.y;
+            const int d2x = uni(d2v.x);
+            if (HTM_ALLOW2 && NCH > 0 && !job1 && iter + 2 <= sh.c.iter_target && d2x >= 1 && d2x <= 4) { mode = 2; pj = la_p2; jt = d2x; ji = uni(d2v.y); }
+        } else {
+            // this chain's next step is its step of the next iteration (this wave's other chains of this iteration come first)
+            p1 = (W.rpos1 >= 0 && c >= W.rc1) ? hop_ahead(rg, W.rpos1, c - W.rc1) : -1;
+            w1 = p1 >= 0 && p1 < lim;
+            const i32x4 d1r = reinterpret_cast<const i32x4 *>(rg.dec)[(w1 ? p1 : 0) & M];
+            d1.x = d1r.x; d1.y = d1r.y; d1.z = d1r.z;
+            job1 = w1 && d1.x >= 1 && d1.x <= 4;
+            mode = job1 ? 1 : 0; pj = p1; jt = d1.x; ji = d1.y;
+            if (HTM_ALLOW2 && NCH > 0 && w1 && !job1 && iter + 2 <= sh.c.iter_target && W.B2 >= 0) {
+                const int p2 = hop_ahead(rg, W.B2, c);
+                if (p2 < lim) {
+                    const i32x4 d2 = reinterpret_cast<const i32x4 *>(rg.dec)[p2 & M];
+                    if (d2.x >= 1 && d2.x <= 4) { mode = 2; pj = p2; jt = d2.x; ji = d2.y; }
+                }
             }
         }
         if (mode) {
@@ -678,6 +745,8 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
     W.epoch = 0; W.akey = 0; W.rc = 0; W.rpos = 0;
     W.rc1 = 0; W.rpos1 = flow_next_base(cs, sh, rg, 0, nc, sh.fill);
     W.B2 = flow_next_base(cs, sh, rg, W.rpos1, nc, sh.fill);
+    FlowNext nx;
+    nx.p = -1; nx.it = 0; nx.c = 0; nx.epoch = 0; nx.type = 5; nx.idx = 0; nx.evt = 1; nx.dec_w = 6; nx.g = 0.0; nx.r = 0.0; nx.logr = 0.0; nx.b3 = -1;
     int iter = i0 + 1;
     int c = wave;
     bool alive = wave < nc;
@@ -699,7 +768,10 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
             if (W.rpos1 < 0) { W.rpos1 = flow_next_base(cs, sh, rg, W.rpos, nc - W.rc, sh.fill); W.rc1 = 0; }
             if (W.B2 < 0 && W.rpos1 >= 0) W.B2 = flow_next_base(cs, sh, rg, W.rpos1, nc - W.rc1, sh.fill);
         }
-        const int p = hop_ahead(rg, W.rpos, c - W.rc);
+        // where the step starts: known from the step before (FlowNext), or from the hop table now
+        const bool known = nx.p >= 0 && nx.it == iter && nx.c == c && nx.epoch == W.epoch;
+        const int p = known ? nx.p : hop_ahead(rg, W.rpos, c - W.rc);
+        if (!known) nx.p = -1;
         if (wave == 0 && c == 0 && lane == 0) {
             // chain 0's wave decides where the launch ends: record buffers or produced stream nearly used up.  Everybody
             // learns it before committing a step of this iteration (its turn waits for chain 0's check)
@@ -709,7 +781,7 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
             if (code && lds_ld(&sh.last_iter) > iter) { sh.stop_code = code; lds_st(&sh.last_iter, iter); }
         }
         // the window covers this step (chain 0's wave keeps it 3 iterations ahead); a fail-stop, never expected to wait
-        if (__builtin_expect(p + 16 >= lds_ld(&sh.fill), 0)) {
+        if (__builtin_expect(!known && p + 16 >= lds_ld(&sh.fill), 0)) {      // (a known start was checked against the window when it was looked up)
             if (wave == 0) { if (lane == 0) sh.c.err = -13; break; }
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
             bool dead = false;
@@ -719,7 +791,7 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
             }
             if (dead) { if (lane == 0 && sh.c.err == 0) sh.c.err = -13; break; }
         }
-        const int r = flow_step<NCH, F32>(f, cs, sh, rg, W, s_sx, s_sy, s_sz, c, p, iter, lane, wave, NW, launch, wave == 0,
+        const int r = flow_step<NCH, F32>(f, cs, sh, rg, W, nx, s_sx, s_sy, s_sz, c, p, iter, lane, wave, NW, launch, wave == 0,
                                           look, back, rec_phase == 1);
         if (r == kFlowRestart) continue;
         if (r == kFlowAbort) break;
@@ -735,7 +807,9 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
             }
             W.rc = W.rc1; W.rpos = W.rpos1;
             W.rc1 = 0; W.rpos1 = W.B2 >= 0 ? W.B2 : flow_next_base(cs, sh, rg, W.rpos, nc - W.rc, sh.fill);
-            W.B2 = flow_next_base(cs, sh, rg, W.rpos1, nc, sh.fill);
+            // (the base of the iteration after next: looked up during the step, or from the tables now)
+            if (nx.p >= 0 && nx.epoch == W.epoch && nx.it == iter && nx.b3 >= 0 && W.rpos1 >= 0) W.B2 = nx.b3;
+            else W.B2 = flow_next_base(cs, sh, rg, W.rpos1, nc, sh.fill);
         }
     }
 #ifdef HTM_STAMPS
