@@ -1756,6 +1756,16 @@ int htm_chains_get_state(htm_chains *hc, int chain, double *hypo, double *t_corr
     return HTM_OK;
 }
 
+int htm_chains_get_loglik(htm_chains *hc, int chain, double *log_likelihood)
+{
+    if (!hc || !log_likelihood) return fail(HTM_EINVAL, "NULL argument");
+    if (chain < 0 || chain >= hc->dev.n_chains) return fail(HTM_EINVAL, "chain %d out of range", chain);
+    int rc = htm_chains_sync(hc);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(log_likelihood, hc->dev.L + chain, sizeof(double), hipMemcpyDeviceToHost));
+    return HTM_OK;
+}
+
 int htm_chains_get_rng(htm_chains *hc, uint32_t state[4])
 {
     if (!hc || !state) return fail(HTM_EINVAL, "NULL argument");

@@ -337,9 +337,8 @@ contains
   !> main loop -- one call into the library, one progress report -- n iterations long instead
   subroutine summary(it)
     integer, intent(in) :: it
-    real(c_double) :: h(3*n_events), tc(n_sta), ac(n_sta), v, q, t, l
-    integer(c_int32_t) :: np(7), na(7)
-    call check(htm_chains_get_state(chains, 0_c_int, h, tc, v, ac, q, t, l, np, na), "htm_chains_get_state")
+    real(c_double) :: l
+    call check(htm_chains_get_loglik(chains, 0_c_int, l), "htm_chains_get_loglik")
     write(*, *) "Iteration    : ", it, "/", para%n_iter
     write(*, *) "Likelihood   : ", l
     write(*, *)

@@ -236,6 +236,9 @@ int htm_chains_get_state(htm_chains *hc, int chain, double *hypo, double *t_corr
                          double *a_corr, double *qs, double *temp, double *log_likelihood,
                          int32_t n_propose[7], int32_t n_accept[7]);
 int htm_chains_get_rng(htm_chains *hc, uint32_t state[4]);
+/* the chain's current log-likelihood alone (one 8-byte copy): what the reference's progress report prints every 1 000
+ * iterations for chain 1 (`mc%one_step_summary`, src/cls_mcmc.f90:230-237) */
+int htm_chains_get_loglik(htm_chains *hc, int chain, double *log_likelihood);
 
 /* What the reference streams to likelihoodRR.out (src/hypo_tremor_mcmc.f90:279): (iteration, value) in
  * file order, plus the chain index that produced it. */
