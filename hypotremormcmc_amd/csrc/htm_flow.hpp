@@ -868,8 +868,18 @@ __global__ __launch_bounds__(512) void k_mcmc(FwdDev f, ChainsDev cs, int mode, 
         __syncthreads();
         if (threadIdx.x == 0) st_agent(&ka.cs.ps->quit, launch + 1ull);
     } else {
-        worker_body<NCH, F32>(ka.f, ka.cs, launch);
+        worker_body<NCH, F32, 8>(ka.f, ka.cs, launch, blockIdx.x - 1);
     }
+}
+
+// The worker blocks as a launch of their own (htm_hip.hip: split_workers), next to a k_mcmc launch of the master block alone:
+// 12 waves per block and the workers' own register budget -- where one wave evaluates many events (10 000 events: 41 MB
+// per full evaluation) the iteration is bound by the workers, and the master's 150-200 registers held them at 8 waves per CU.
+template <int NCH, bool F32 = false>
+__global__ __launch_bounds__(768) void k_workers(FwdDev f, ChainsDev cs, unsigned long long launch)
+{
+    const KArgLayout __attribute__((address_space(4))) &ka = *(const KArgLayout __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+    worker_body<NCH, F32, 12>(ka.f, ka.cs, launch, blockIdx.x);
 }
 
 }  // namespace htm

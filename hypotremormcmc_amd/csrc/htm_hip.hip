@@ -168,6 +168,8 @@ struct htm_chains {
     unsigned long long launch_seq = 0;         // k_mcmc launches of this chain set so far (the kernels' launch index)
     bool persist = true;                       // k_mcmc (master + resident full-evaluation workers) vs k_step + k_full
     bool flow = false;                         // single-rank loop on the free-running master (htm_flow.hpp) instead of step_body
+    bool split = false;                        // worker blocks as a k_workers launch of their own (12 waves per block) beside the master's
+    hipStream_t wstream = nullptr;             // ... on this stream
     ChainsDev dev_np{};                        // view for the non-persistent kernels (partial sums per k_full tile)
     uint32_t init_state[4] = {0, 0, 0, 0};     // mod_random state at stream position 0
     // in-kernel exchange of the swap records (persistent lock-step): this rank's inbox, the peers' inboxes as mapped here
@@ -223,8 +225,18 @@ int launch_full(htm_forward *h, const FullJob &jb, int gy)
 int launch_mcmc(htm_chains *hc, int mode, int target, const double *gathered)
 {
     htm_forward *h = hc->fwd;
-    dim3 grid(1 + hc->dev.n_workers), block(512);
+    dim3 grid(hc->split ? 1 : 1 + hc->dev.n_workers), block(512);
     const unsigned long long seq = ++hc->launch_seq;      // this chain set's k_mcmc launches, counted from 1
+    if (hc->split) {
+        // the worker blocks first, on their own stream: they wait for orders carrying this launch's number and leave when the
+        // master (launched next, one block) says so
+        dim3 wgrid(hc->dev.n_workers), wblock(768);
+        if (h->dev.fp32) { if (h->nch == 1) hipLaunchKernelGGL((k_workers<1, true>), wgrid, wblock, 1024, hc->wstream, h->dev, hc->dev, seq);
+                           else hipLaunchKernelGGL((k_workers<2, true>), wgrid, wblock, 1024, hc->wstream, h->dev, hc->dev, seq); }
+        else if (h->nch == 1) hipLaunchKernelGGL((k_workers<1, false>), wgrid, wblock, 1024, hc->wstream, h->dev, hc->dev, seq);
+        else hipLaunchKernelGGL((k_workers<2, false>), wgrid, wblock, 1024, hc->wstream, h->dev, hc->dev, seq);
+        HIPCHK(hipGetLastError());
+    }
 #define HTM_LAUNCH_MCMC(N, F, K) hipLaunchKernelGGL((k_mcmc<N, F, K>), grid, block, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax, seq)
 #define HTM_LAUNCH_MCMC_K(K)                                                                              \
     do {                                                                                                   \
@@ -731,7 +743,7 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
     HIPCHK(hipMemset(d.desc, 0, sizeof(FullDesc)));
     d.n_workers = std::max(1, std::min(240, (h->E + 7) / 8));
     if (const char *e = getenv("HTM_MAX_WORKERS")) d.n_workers = std::max(1, std::min(d.n_workers, atoi(e)));   // GPUs shared between ranks
-    if ((rc = dev_alloc(hc->pool, &d.partial, (size_t)nc * std::max(h->n_wg, d.n_workers)))) return cleanup(rc);
+    if ((rc = dev_alloc(hc->pool, &d.partial, (size_t)nc * std::max(h->n_wg, 256)))) return cleanup(rc);      // (<= 256 workers whatever the launch shape)
     if ((rc = dev_alloc(hc->pool, &d.ps, 1))) return cleanup(rc);
     HIPCHK(hipMemset(d.ps, 0, sizeof(PSync)));
     {
@@ -748,8 +760,8 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
     }
     if ((rc = dev_alloc(hc->pool, &d.slots, (size_t)d.slot_rep * d.slot_stride))) return cleanup(rc);
     HIPCHK(hipMemset(d.slots, 0, (size_t)d.slot_rep * d.slot_stride * sizeof(unsigned long long)));
-    if ((rc = dev_alloc(hc->pool, &d.pgran, (size_t)nc * d.n_workers * d.pgran_stride))) return cleanup(rc);
-    HIPCHK(hipMemset(d.pgran, 0, (size_t)nc * d.n_workers * d.pgran_stride * sizeof(unsigned long long)));
+    if ((rc = dev_alloc(hc->pool, &d.pgran, (size_t)nc * 256 * d.pgran_stride))) return cleanup(rc);
+    HIPCHK(hipMemset(d.pgran, 0, (size_t)nc * 256 * d.pgran_stride * sizeof(unsigned long long)));
     {
         const char *env = getenv("HTM_PERSIST");
         hc->persist = !(env && env[0] == '0');
@@ -886,11 +898,33 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
             per_cu = std::min(per_cu, pc);
         }
         HIPCHK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
+        // Large event counts (one wave evaluates several events per order: the iteration is bound by the workers): the worker
+        // blocks run as a launch of their own with 12 waves per block and their own registers (k_workers), the master's block
+        // alone in the k_mcmc launch.  HTM_SPLIT_WORKERS=0 / 1 overrides the choice by size.
+        {
+            const char *e = getenv("HTM_SPLIT_WORKERS");
+            const bool by_size = (h->E + 7) / 8 > 240;
+            hc->split = (h->nch == 1 || h->nch == 2) && (e ? atoi(e) != 0 : by_size);
+            if (hc->split) {
+                const void *wfn = h->dev.fp32 ? (h->nch == 1 ? (const void *)k_workers<1, true> : (const void *)k_workers<2, true>)
+                                  : (h->nch == 1 ? (const void *)k_workers<1, false> : (const void *)k_workers<2, false>);
+                int wpc = 0;
+                HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&wpc, wfn, 768, 1024));
+                long wroom = (long)wpc * n_cu - 2;        // (the master's block takes a CU's worth of LDS)
+                if (const char *e2 = getenv("HTM_RANKS_PER_GPU")) { const int k = atoi(e2); if (k > 1) wroom = (long)wpc * n_cu / k - 2; }
+                if (wroom < 1 || hipStreamCreateWithFlags(&hc->wstream, hipStreamNonBlocking) != hipSuccess) hc->split = false;
+                else {
+                    hc->dev.n_workers = (int)std::max<long>(1, std::min<long>(std::min<long>(255, wroom), (h->E + 11) / 12));
+                    if (const char *e3 = getenv("HTM_MAX_WORKERS")) hc->dev.n_workers = std::max(1, std::min(hc->dev.n_workers, atoi(e3)));
+                }
+            }
+        }
         long room = (long)per_cu * n_cu - 1;
         // Several ranks on one GPU (more masters instead of more rounds per master: 4 ranks x 8 chains run 2.7 M steps/s where one
         // rank x 32 chains runs 1.7 M): every rank's blocks must be resident at once, so each takes its share of the CUs
         if (const char *e = getenv("HTM_RANKS_PER_GPU")) { const int k = atoi(e); if (k > 1) room = (long)per_cu * n_cu / k - 1; }
-        if (room < 1) hc->persist = false;      // not even one worker fits next to the master: two-kernel path
+        if (hc->split) { }                      // (sized above)
+        else if (room < 1) hc->persist = false;      // not even one worker fits next to the master: two-kernel path
         else hc->dev.n_workers = (int)std::min<long>(hc->dev.n_workers, room);
     }
     hc->dev.n_wg = hc->dev.n_workers;           // persistent kernel: one partial per worker block
@@ -917,6 +951,7 @@ int htm_chains_destroy(htm_chains *hc)
     (void)hipSetDevice(hc->fwd->device);
     if (hc->side) (void)hipStreamSynchronize(hc->side);
     (void)hipStreamSynchronize(hc->fwd->stream);
+    if (hc->wstream) { (void)hipStreamSynchronize(hc->wstream); (void)hipStreamDestroy(hc->wstream); }
     if (hc->ev_side) (void)hipEventDestroy(hc->ev_side);
     if (hc->side) (void)hipStreamDestroy(hc->side);
     if (hc->gexec) (void)hipGraphExecDestroy(hc->gexec);

@@ -1431,19 +1431,21 @@ __global__ __launch_bounds__(512) void k_step(FwdDev f, ChainsDev cs, int mode, 
 // granules (data is the flag); chain state is read with agent-scope loads after the job word has been seen
 // (the master drained its stores before publishing it).  Leaves when the master has finished (PSync::quit)
 // or after a bounded wait.
-template <int NCH, bool F32>
-__device__ __forceinline__ void worker_body(FwRef f_, CsRef cs_, unsigned long long launch)
+// NWV = waves per worker block: 8 inside a k_mcmc launch (the master's block shape), 12 in a k_workers launch of its own
+// (blocks of 768 threads: three waves per SIMD where the master's registers allow two -- large event counts, htm_hip.hip)
+template <int NCH, bool F32, int NWV = 8>
+__device__ __forceinline__ void worker_body(FwRef f_, CsRef cs_, unsigned long long launch, int w)
 {
     CsRef cs = rebase(cs_);
     FwRef f = rebase(f_);
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double *s_red = reinterpret_cast<double *>(smem);          // [8]
+    double *s_red = reinterpret_cast<double *>(smem);          // [NWV <= 16]
     unsigned *s_tag = reinterpret_cast<unsigned *>(smem + 128);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int w = blockIdx.x - 1, W = cs.n_workers;
+    const int W = cs.n_workers;
     const int nc = cs.n_chains;
-    const int ev0 = w * 8 + wave;
+    const int ev0 = w * NWV + wave;
 
     constexpr int N = NCH > 0 ? NCH : 1;
     StaRegs<N> st;
@@ -1640,8 +1642,8 @@ __device__ __forceinline__ void worker_body(FwRef f_, CsRef cs_, unsigned long l
                     ObsRegs<NCH> ob_cur = ob0, ob_nxt = ob0;
                     double cx = 0.0, cy = 0.0, cz = 0.0, nx = 0.0, ny = 0.0, nz = 0.0;
                     if (ev0 < f.E) { cx = ld_agent(hyp + 3 * ev0); cy = ld_agent(hyp + 3 * ev0 + 1); cz = ld_agent(hyp + 3 * ev0 + 2); }
-                    for (int ev = ev0; ev < f.E; ev += 8 * W) {
-                        const int evn = ev + 8 * W;
+                    for (int ev = ev0; ev < f.E; ev += NWV * W) {
+                        const int evn = ev + NWV * W;
                         if (evn < f.E) {
                             load_obs_regs<NCH, F32>(ob_nxt, f, evn, lane);
                             nx = ld_agent(hyp + 3 * evn); ny = ld_agent(hyp + 3 * evn + 1); nz = ld_agent(hyp + 3 * evn + 2);
@@ -1662,7 +1664,7 @@ __device__ __forceinline__ void worker_body(FwRef f_, CsRef cs_, unsigned long l
                     // evaluated, with a fixed number of loads per request (load_obs_regs_nobranch), so that at E >> 8W two
                     // events' loads fly under the arithmetic of a third: the fp32 forward's arithmetic is too short to cover an
                     // event's loads (configs[4] shape: 837 -> 902 k steps/s).  The last <= 4 events of a wave take the plain path.
-                    const int s8 = 8 * W;
+                    const int s8 = NWV * W;
                     ObsRegs<NCH> b0 = ob0, b1 = ob0, b2 = ob0;
                     double x0 = 0.0, y0 = 0.0, z0 = 0.0, x1 = 0.0, y1 = 0.0, z1 = 0.0, x2 = 0.0, y2 = 0.0, z2 = 0.0;
                     auto fetch = [&](ObsRegs<NCH> &b, double &x, double &y, double &z, int e) __attribute__((always_inline)) {
@@ -1698,7 +1700,7 @@ __device__ __forceinline__ void worker_body(FwRef f_, CsRef cs_, unsigned long l
             } else {
                 // generic station count: corrections are read through plain loads after an agent acquire
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                for (int ev = ev0; ev < f.E; ev += 8 * W) {
+                for (int ev = ev0; ev < f.E; ev += NWV * W) {
                     const bool ov = ev == ov_evt;
                     const double hx = ld_agent(hyp + 3 * ev), hy = ld_agent(hyp + 3 * ev + 1), hz = ld_agent(hyp + 3 * ev + 2);
                     const double px[1] = {(ov && ov_cmp == 0) ? ov_val : hx};
@@ -1719,9 +1721,11 @@ __device__ __forceinline__ void worker_body(FwRef f_, CsRef cs_, unsigned long l
 #ifdef HTM_STAMPS
             if (wstamp) cs.stamps[23] += __builtin_amdgcn_s_memrealtime();
 #endif
-            if (tid == 0)
-                st_gran_f64(cs.pgran + ((size_t)m * cs.n_wg + w) * cs.pgran_stride, tag,
-                            ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) + ((s_red[4] + s_red[5]) + (s_red[6] + s_red[7])));
+            if (tid == 0) {
+                double tot8 = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) + ((s_red[4] + s_red[5]) + (s_red[6] + s_red[7]));
+                if constexpr (NWV == 12) tot8 = tot8 + ((s_red[8] + s_red[9]) + (s_red[10] + s_red[11]));
+                st_gran_f64(cs.pgran + ((size_t)m * cs.n_wg + w) * cs.pgran_stride, tag, tot8);
+            }
             __syncthreads();
         }
     }
