@@ -169,6 +169,8 @@ struct htm_chains {
     bool persist = true;                       // k_mcmc (master + resident full-evaluation workers) vs k_step + k_full
     bool flow = false;                         // single-rank loop on the free-running master (htm_flow.hpp) instead of step_body
     bool split = false;                        // worker blocks as a k_workers launch of their own (12 waves per block) beside the master's
+    bool wide = false;                         // the single-rank loop in blocks of 12 waves (k_mcmc_wide: large event counts)
+    int n_workers8 = 0;                        // worker blocks of the 8-wave launches (lock-step modes) when `wide`
     hipStream_t wstream = nullptr;             // ... on this stream
     ChainsDev dev_np{};                        // view for the non-persistent kernels (partial sums per k_full tile)
     uint32_t init_state[4] = {0, 0, 0, 0};     // mod_random state at stream position 0
@@ -246,7 +248,14 @@ int launch_mcmc(htm_chains *hc, int mode, int target, const double *gathered)
         else HTM_LAUNCH_MCMC(0, false, K);                                                                 \
     } while (0)
     // one instantiation per main loop: the single-rank loop, one lock-step iteration per launch, persistent lock-step
-    if (mode == MODE_RUN && hc->flow) HTM_LAUNCH_MCMC_K(3);
+    if (mode == MODE_RUN && hc->flow && hc->wide) {
+        dim3 wgrid(1 + hc->dev.n_workers), wblock(768);
+        if (h->dev.fp32) { if (h->nch == 1) hipLaunchKernelGGL((k_mcmc_wide<1, true>), wgrid, wblock, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax, seq);
+                           else hipLaunchKernelGGL((k_mcmc_wide<2, true>), wgrid, wblock, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax, seq); }
+        else if (h->nch == 1) hipLaunchKernelGGL((k_mcmc_wide<1, false>), wgrid, wblock, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax, seq);
+        else hipLaunchKernelGGL((k_mcmc_wide<2, false>), wgrid, wblock, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax, seq);
+    }
+    else if (mode == MODE_RUN && hc->flow) HTM_LAUNCH_MCMC_K(3);
     else if (mode == MODE_RUN) HTM_LAUNCH_MCMC_K(0);
     else if (mode == MODE_LOCKRUN) HTM_LAUNCH_MCMC_K(2);
     else HTM_LAUNCH_MCMC_K(1);
@@ -904,7 +913,8 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
         {
             const char *e = getenv("HTM_SPLIT_WORKERS");
             const bool by_size = (h->E + 7) / 8 > 240;
-            hc->split = (h->nch == 1 || h->nch == 2) && (e ? atoi(e) != 0 : by_size);
+            (void)by_size;
+            hc->split = (h->nch == 1 || h->nch == 2) && e && atoi(e) != 0;      // (opt-in: see DESIGN.md 9 -- a relaunch race is open)
             if (hc->split) {
                 const void *wfn = h->dev.fp32 ? (h->nch == 1 ? (const void *)k_workers<1, true> : (const void *)k_workers<2, true>)
                                   : (h->nch == 1 ? (const void *)k_workers<1, false> : (const void *)k_workers<2, false>);
@@ -937,6 +947,26 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
         const int wd = 6 * nc + 16, c_max = 8 * ((nc - 1) / 8);
         hc->flow = hc->persist && d.n_procs == 1 && !(e && e[0] == '0') && d.dbg == 0 && hc->dev.mirror_n > 0 &&
                    hc->ring_size >= 4 * wd + 32 + 2 * c_max + 16;
+        // blocks of 12 waves where one worker wave evaluates several events per order (HTM_WIDE=0 / 1 overrides the choice by size)
+        const char *ew = getenv("HTM_WIDE");
+        const bool by_size = (h->E + 7) / 8 > 240;
+        if (hc->flow && !hc->split && (h->nch == 1 || h->nch == 2) && (ew ? atoi(ew) != 0 : by_size)) {
+            const void *wfn = h->dev.fp32 ? (h->nch == 1 ? (const void *)k_mcmc_wide<1, true> : (const void *)k_mcmc_wide<2, true>)
+                              : (h->nch == 1 ? (const void *)k_mcmc_wide<1, false> : (const void *)k_mcmc_wide<2, false>);
+            int wpc = 0, n_cu = 0;
+            if (hc->step_smem > 48 * 1024) HIPCHK(hipFuncSetAttribute(wfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hc->step_smem));
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&wpc, wfn, 768, hc->step_smem));
+            HIPCHK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
+            long wroom = (long)wpc * n_cu - 1;
+            if (const char *e2 = getenv("HTM_RANKS_PER_GPU")) { const int k = atoi(e2); if (k > 1) wroom = (long)wpc * n_cu / k - 1; }
+            if (wroom >= 1) {
+                hc->wide = true;
+                hc->n_workers8 = hc->dev.n_workers;
+                int nw = (int)std::max<long>(1, std::min<long>(std::min<long>(255, wroom), (h->E + 11) / 12));
+                if (const char *e3 = getenv("HTM_MAX_WORKERS")) nw = std::max(1, std::min(nw, atoi(e3)));
+                hc->dev.n_workers = nw; hc->dev.n_wg = nw;
+            }
+        }
     }
     // first stretch of the random stream (synchronous)
     if ((rc = stream_produce(hc, 1 << 16))) return cleanup(rc);
