@@ -950,7 +950,9 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
         // blocks of 12 waves where one worker wave evaluates several events per order (HTM_WIDE=0 / 1 overrides the choice by size)
         const char *ew = getenv("HTM_WIDE");
         const bool by_size = (h->E + 7) / 8 > 240;
-        if (hc->flow && !hc->split && (h->nch == 1 || h->nch == 2) && (ew ? atoi(ew) != 0 : by_size)) {
+        // (measured at 10 000 x 128 x 16 chains: fp64 856 -> 902 k steps/s; the fp32 workers with their three register
+        // buffers spill 56 registers at 168 and lose a quarter; one station per lane gains nothing: profiles/r03_j_wide.txt)
+        if (hc->flow && !hc->split && (h->nch == 1 || h->nch == 2) && (ew ? atoi(ew) != 0 : (by_size && h->nch == 2 && !h->dev.fp32))) {
             const void *wfn = h->dev.fp32 ? (h->nch == 1 ? (const void *)k_mcmc_wide<1, true> : (const void *)k_mcmc_wide<2, true>)
                               : (h->nch == 1 ? (const void *)k_mcmc_wide<1, false> : (const void *)k_mcmc_wide<2, false>);
             int wpc = 0, n_cu = 0;
