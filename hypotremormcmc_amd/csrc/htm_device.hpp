@@ -324,6 +324,67 @@ __device__ __forceinline__ void event_misfit(const FW &f, const ObsRegs<NCH> &ob
     }
 }
 
+// The same for NM MODELS of one event at once (k_full on stacked models: one event per wave, its observation rows resident):
+// the models differ in position, corrections, vs and qs; their evaluations are independent instruction streams, written
+// side by side so that one model's dependent chains (square root, logarithm, the DPP reductions) run under the other's --
+// one station per lane has no such parallelism of its own.  Same arithmetic per model as event_misfit<NCH, 1>.
+template <int NCH, int NM, bool F32 = false, class FW>
+__device__ __forceinline__ void event_misfit_models(const FW &f, const ObsRegs<NCH> &ob, int lane, const StaRegs<NCH> &geo,
+                                                    const double (&tcm)[NM][NCH], const double (&acm)[NM][NCH],
+                                                    const double (&px)[NM], const double (&py)[NM], const double (&pz)[NM],
+                                                    const double (&beta)[NM], const double (&q)[NM], double (&out)[NM])
+{
+    double rbeta[NM], katt[NM];
+#pragma unroll
+    for (int p = 0; p < NM; ++p) { const double qbeta = q[p] * beta[p]; rbeta[p] = 1.0 / beta[p]; katt[p] = (kPi * kFreq) / qbeta; }
+    const double (&tob)[NCH] = ob.tob, (&tpr)[NCH] = ob.tpr, (&aob)[NCH] = ob.aob, (&apr)[NCH] = ob.apr;
+    double ts[NM][NCH], as[NM][NCH];
+    double red[2 * NM];
+#pragma unroll
+    for (int k = 0; k < 2 * NM; ++k) red[k] = 0.0;
+    const bool ut = f.use_time != 0, ua = f.use_amp != 0;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const bool valid = (lane + 64 * c) < f.S;
+#pragma unroll
+        for (int p = 0; p < NM; ++p) {
+            if constexpr (F32) {
+                const float dx = (float)(px[p] - geo.sx[c]), dy = (float)(py[p] - geo.sy[c]), dz = (float)(pz[p] - geo.sz[c]);
+                float d = __builtin_amdgcn_sqrtf(__builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)));
+                if (!valid) d = 1.0f;
+                const double t = (double)__builtin_fmaf(d, (float)rbeta[p], -(float)tcm[p][c]);
+                const float lg = __builtin_fmaf(__builtin_amdgcn_logf(d), 0.69314718055994531f, (float)acm[p][c]);
+                const double a = (double)(__builtin_fmaf(-d, (float)katt[p], -lg));
+                ts[p][c] = ut ? t : 0.0; as[p][c] = ua ? a : 0.0;
+            } else {
+                const double dx = px[p] - geo.sx[c], dy = py[p] - geo.sy[c], dz = pz[p] - geo.sz[c];
+                double d = htm_sqrt(__builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx)));
+                if (!valid) d = 1.0;
+                const double t = __builtin_fma(d, rbeta[p], -tcm[p][c]);
+                const double a = __builtin_fma(-d, katt[p], -htm_log(d)) - acm[p][c];
+                ts[p][c] = ut ? t : 0.0; as[p][c] = ua ? a : 0.0;
+            }
+            // (a data type that is not used has zero precisions: its terms vanish, as the branches of event_misfit make them)
+            red[2 * p] = __builtin_fma(ut ? tpr[c] : 0.0, ts[p][c] - tob[c], red[2 * p]);
+            red[2 * p + 1] = __builtin_fma(ua ? apr[c] : 0.0, as[p][c] - aob[c], red[2 * p + 1]);
+        }
+    }
+    wave_sum<2 * NM>(red);
+    const double rpst = ob.rpst, rpsa = ob.rpsa;
+#pragma unroll
+    for (int p = 0; p < NM; ++p) {
+        const double t_mean = red[2 * p] * rpst, a_mean = red[2 * p + 1] * rpsa;
+        double m = 0.0;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const double rt = tob[c] - (ts[p][c] - t_mean), ra = aob[c] - (as[p][c] - a_mean);
+            if (ut) m = __builtin_fma(rt * rt, tpr[c], m);
+            if (ua) m = __builtin_fma(ra * ra, apr[c], m);
+        }
+        out[p] = 0.5 * m;
+    }
+}
+
 // Generic-S fallback (n_sta > 64*4): strides over stations, recomputing the synthetics in the second
 // pass instead of holding them in registers.
 template <int NPOS, class FW>

@@ -57,6 +57,44 @@ __global__ __launch_bounds__(256) void k_full(FwdDev f, FullJob jb)
     if constexpr (NCH > 0) {
         if (keep_obs) load_obs_regs<NCH, F32>(ob_keep, f, blockIdx.x * 4 + wave, lane);
     }
+    // Stacked models, one event per wave, its rows resident (the shape of the batched call): TWO models per trip, evaluated
+    // side by side (event_misfit_models) -- with one station per lane a single model's evaluation is one dependent chain
+    // after the other, and the pair shares the trip's two barriers.
+    __shared__ double s_red2[2][4];
+    if constexpr (NCH > 0) {
+        if (!jb.desc && keep_obs) {
+            StaRegs<NCH> geo;
+            load_sta_regs<NCH>(geo, f.S, lane, f.sx, f.sy, f.sz, jb.tc, jb.ac, 0, -1, 0.0);      // (coordinates; the corrections come per model)
+            const int ev = blockIdx.x * 4 + wave;
+            int k = k0;
+            for (; k + kstep < nm; k += 2 * kstep) {
+                const int ms[2] = {k, k + kstep};
+                double tcm[2][NCH], acm[2][NCH], px[2], py[2], pz[2], beta[2], q[2], out[2];
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const double *hyp = jb.hypo + (size_t)ms[p] * jb.hypo_stride;
+                    const double *tc = jb.tc + (size_t)ms[p] * jb.tc_stride, *ac = jb.ac + (size_t)ms[p] * jb.ac_stride;
+                    beta[p] = jb.vs[ms[p]]; q[p] = jb.qs[ms[p]];
+                    px[p] = hyp[3 * ev]; py[p] = hyp[3 * ev + 1]; pz[p] = hyp[3 * ev + 2];
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        const int j = lane + 64 * c;
+                        tcm[p][c] = j < f.S ? tc[j] : 0.0; acm[p][c] = j < f.S ? ac[j] : 0.0;
+                    }
+                }
+                event_misfit_models<NCH, 2, F32>(f, ob_keep, lane, geo, tcm, acm, px, py, pz, beta, q, out);
+                double tot[2] = {out[0], out[1]};
+                wave_sum<2>(tot);
+                if (lane == 0) { s_red2[0][wave] = tot[0]; s_red2[1][wave] = tot[1]; }
+                __syncthreads();
+                if (threadIdx.x < 2)
+                    jb.partial[(size_t)ms[threadIdx.x] * jb.n_wg + blockIdx.x] =
+                        (s_red2[threadIdx.x][0] + s_red2[threadIdx.x][1]) + (s_red2[threadIdx.x][2] + s_red2[threadIdx.x][3]);
+                __syncthreads();
+            }
+            k0 = k;            // (an odd model out takes the single-model trip below)
+        }
+    }
     for (int k = k0; k < nm; k += kstep) {
         const int m = jb.desc ? en.chain : k;
         double beta, q;
