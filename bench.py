@@ -369,12 +369,16 @@ def main(argv=None):
                 traffic_src = os.path.relpath(tf_files[-1], ROOT) + " (separate PMC passes of this command, not this run)"
         except Exception:
             traffic = None
+        nch = 1 if S <= 64 else 2 if S <= 128 else 4 if S <= 256 else 0
         if lockstep:
-            kname = "k_mcmc<1> (lock-step: one iteration per hand-shake with the swap-record exchange)"
+            kname = f"k_mcmc<{nch}, *, 2> (persistent lock-step: one iteration per hand-shake, swap records exchanged inside the kernel)"
+        elif persistent and os.environ.get("HTM_FLOW", "1") != "0":
+            kname = (f"k_mcmc<{nch}, *, 3> (free-running chain master + resident full-evaluation workers: propose + partial/full "
+                     "log-likelihood + judge + swap, one persistent launch)")
         elif persistent:
-            kname = "k_mcmc<1> (propose + partial/full log-likelihood + judge + swap, persistent)"
+            kname = f"k_mcmc<{nch}, *, 0> (chain master with barriers + resident workers, persistent)"
         else:
-            kname = "k_step<1> + k_full<1,false> (graph of the two-kernel path)"
+            kname = f"k_step<{nch}> + k_full<{nch},false> (graph of the two-kernel path)"
         out["roofline"] = {
             "bound": "hbm", "kernel": kname,
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -382,11 +386,12 @@ def main(argv=None):
             "bytes_per_launch": bytes_region / n_launch, "avg_launch_us": st["device_us"] / n_launch,
             "launches": n_launch, "full_evals": st["full_evals"], "partial_evals": st["partial_evals"],
             "device_us_region": st["device_us"],
-            "note": "algorithmic bytes = 2 074 568 B per full evaluation + 4 672 B per single-event partial update "
+            "note": f"algorithmic bytes = {b_full} B per full evaluation + {b_part} B per single-event partial update "
                     "(SURVEY 8d) x the evaluations counted on the device in the timed region (rank 0's GPU), / the HIP-event "
-                    "time of that region on the kernels' stream.  At 8 chains/GPU an iteration is a dependent chain "
-                    "of a few us that touches ~1.7 MB, all of it L2/Infinity-Cache resident: the workload is "
-                    "latency-bound, not HBM-bound (DESIGN.md 5); see roofline_batch64 for the full-evaluation kernel on its own",
+                    "time of that region on the kernels' stream.  At a few chains per GPU an iteration is a dependent chain "
+                    "of a few us whose data (observations, chain state) stays in L2 / Infinity Cache: the workload is bound by "
+                    "instruction issue and latency on the master's CU, not by HBM (DESIGN.md 5); see roofline_batch64 for the "
+                    "full-evaluation kernel on its own",
         }
     if rank == 0 and world == 1 and not args.force_lockstep and not test_engine:
         # ---- the two stages timed separately (fallback two-kernel path, same arithmetic), HIP events per launch

@@ -355,7 +355,8 @@ int full_batch_dev(htm_forward *h, int n_models, const double *d_hypo, const dou
     jb.vs = d_vs; jb.qs = d_qs;
     jb.n_models = n_models;
     jb.partial = h->d_bpartial; jb.n_wg = h->n_wg; jb.epw = h->epw;
-    const int gy = std::max(1, std::min(n_models, 2048 / std::max(1, h->n_wg)));
+    int gy = std::max(1, std::min(n_models, 2048 / std::max(1, h->n_wg)));
+    if (const char *e = getenv("HTM_FULL_BLOCKS")) gy = std::max(1, std::min(n_models, atoi(e) / std::max(1, h->n_wg)));      // (tuning: blocks per launch)
     rc = launch_full(h, jb, gy);
     if (rc) return rc;
     hipLaunchKernelGGL(k_sum_partials, dim3(n_models), dim3(64), 0, h->stream, h->d_bpartial, h->n_wg,

@@ -67,7 +67,7 @@ for sub, cname in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     nl = len(v)
 iters = 5 * 1024
 json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace), python3 bench.py --steps 4 --warmup 1 --iters-per-step 1024 --no-cpu-baseline",
-           "kernel": "htm::k_mcmc<1>", "iterations": iters, "launches": nl,
+           "kernel": "htm::k_mcmc (the launches of the run)", "iterations": iters, "launches": nl,
            "fetch_kb_raw_total": tot["fetch"], "write_kb_total": tot["write"],
            "fetch_bytes_per_iteration_raw": tot["fetch"] * 1024 / iters, "write_bytes_per_iteration": tot["write"] * 1024 / iters,
            "note": "raw counter values; gfx950 FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads (x2 at most); 8-byte-per-lane access widths are uncalibrated"},
