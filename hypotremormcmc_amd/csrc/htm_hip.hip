@@ -169,6 +169,7 @@ struct htm_chains {
     bool persist = true;                       // k_mcmc (master + resident full-evaluation workers) vs k_step + k_full
     bool flow = false;                         // single-rank loop on the free-running master (htm_flow.hpp) instead of step_body
     bool split = false;                        // worker blocks as a k_workers launch of their own (12 waves per block) beside the master's
+    bool ctrl_fresh = false;                   // h_ctrl is the device's control block as of an idle stream (no launch since it was read)
     bool wide = false;                         // the single-rank loop in blocks of 12 waves (k_mcmc_wide: large event counts)
     int n_workers8 = 0;                        // worker blocks of the 8-wave launches (lock-step modes) when `wide`
     hipStream_t wstream = nullptr;             // ... on this stream
@@ -228,6 +229,7 @@ int launch_mcmc(htm_chains *hc, int mode, int target, const double *gathered)
 {
     htm_forward *h = hc->fwd;
     dim3 grid(hc->split ? 1 : 1 + hc->dev.n_workers), block(512);
+    hc->ctrl_fresh = false;
     const unsigned long long seq = ++hc->launch_seq;      // this chain set's k_mcmc launches, counted from 1
     if (hc->split) {
         // the worker blocks first, on their own stream: they wait for orders carrying this launch's number and leave when the
@@ -268,6 +270,7 @@ int launch_mcmc(htm_chains *hc, int mode, int target, const double *gathered)
 int launch_step(htm_chains *hc, int mode, int target, const double *gathered)
 {
     htm_forward *h = hc->fwd;
+    hc->ctrl_fresh = false;
     dim3 grid(1), block(64 * hc->nw);
     if (h->dev.fp32) {
         if (h->nch == 1) hipLaunchKernelGGL((k_step<1, true>), grid, block, hc->step_smem, h->stream, h->dev, hc->dev_np, mode, target, gathered, hc->ring_size, hc->wmax);
@@ -1032,11 +1035,15 @@ static int bounded_stream_sync(htm_chains *hc, const char *what)
 
 static int read_ctrl(htm_chains *hc)
 {
+    // (nothing launched since the last read: the copy is current -- a driver that runs in short slices and asks for the state
+    // in between would pay the copy and the stream synchronisation three times per slice)
+    if (hc->ctrl_fresh && !hc->pending_gathered) return HTM_OK;
     int rc_ = flush_pending(hc);
     if (rc_) return rc_;
     HIPCHK(hipMemcpyAsync(&hc->h_ctrl, hc->dev.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, hc->fwd->stream));
     if ((rc_ = bounded_stream_sync(hc, "waiting for the chain kernels"))) return rc_;
     hc->spos_lo = hc->spos_hi = hc->h_ctrl.spos;
+    hc->ctrl_fresh = true;
     return HTM_OK;
 }
 
@@ -1239,6 +1246,7 @@ int htm_chains_run(htm_chains *hc, int n_iter)
         g = std::min<long long>(g, (long long)(0.9 * fed / it_per_launch));
         g = std::max(1, std::min(g, 512));
         const int before = hc->h_ctrl.iter_done;
+        hc->ctrl_fresh = false;
         for (int k = 0; k < g; ++k) HIPCHK(hipGraphLaunch(hc->gexec, h->stream));
         hc->last_graph_launches += g;
         if ((rc = read_ctrl(hc))) return rc;

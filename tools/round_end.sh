@@ -10,7 +10,7 @@ python3 -c "import json; d=json.load(open('gpurun_out/${T}_bench_lockstep.json')
 ( timeout -k 10 300 python tools/time_fortran.py 1000000 > gpurun_out/${T}_fortran_timing.txt 2>&1 || true )
 cat gpurun_out/${T}_fortran_timing.txt
 rm -f gpurun_out/${T}_rehearsal_one_gpu.jsonl
-for n in 2 4 8; do
+for n in 2 4; do      # (a one-GPU box admits 6 processes on the GPU: no 8-rank rehearsal here)
   ( HTM_BENCH_ONE_GPU=1 timeout -k 10 300 python3 bench.py --gpus $n --steps 4 --warmup 1 --iters-per-step 8192 --no-cpu-baseline >> gpurun_out/${T}_rehearsal_one_gpu.jsonl 2>gpurun_out/${T}_rehearsal_$n.err || echo "rehearsal $n failed" )
 done
 python3 -c "
