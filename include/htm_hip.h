@@ -226,7 +226,9 @@ int htm_chains_iterations_done(htm_chains *hc, int *n);
  * log-likelihoods and proposal counters of every chain.  Priors, step sizes, observations and record
  * buffers are NOT in it: load into a chain set created from the same inputs (shapes are checked).
  * Continuing after load gives the bits of the uninterrupted run.  Not valid while a lock-step iteration is
- * in flight (between step_begin and step_end). */
+ * in flight (between step_begin and step_end).  A load clears this rank's swap-record inbox (its tags are iteration
+ * numbers, and iterations are about to be run again): for a multi-rank job every rank loads, then the ranks meet at a
+ * barrier before the next htm_chains_run_lockstep_direct. */
 int htm_chains_checkpoint_size(htm_chains *hc, size_t *bytes);
 int htm_chains_checkpoint_save(htm_chains *hc, void *blob, size_t bytes);
 int htm_chains_checkpoint_load(htm_chains *hc, const void *blob, size_t bytes);
