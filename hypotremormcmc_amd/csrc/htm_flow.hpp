@@ -48,6 +48,9 @@ struct FlowShared : StepShared {
     int ob_pos[kMaxChains], ob_mode[kMaxChains], ob_mid[kMaxChains];     // ob_mid: type | event << 3 of the step in between (mode 2)
     unsigned ob_tag[kMaxChains];
     unsigned long long n_full_w, n_part_w;
+    // a lock-step rank (k_mcmc<.., 4>): chains of this rank that have committed iteration i (index i & 3: the last one posts the
+    // rank's swap record); the iteration whose records a wave has taken on to collect
+    int xcount[4], xclaim;
 };
 
 // a wave-uniform value that reached a vector register (read from LDS) back in a scalar one
@@ -90,6 +93,7 @@ struct FlowNext {
 
 constexpr int kFlowRestart = -1;  // flow_step: the step's position was disproved before its turn came: run it again
 constexpr int kFlowAbort = -2;    // flow_step: a wait gave up (sh.c.err is set)
+constexpr int kFlowStop = -3;     // flow_step (lock-step rank): the job stops after the iteration before: this step is not taken
 
 // select_pair + the judge_swap draw starting at E (cls_parallel.f90:226-230, :163): pair, draws used in all (single rank:
 // this rank draws both).  The stream service has the usual case precomputed (sw ring); more than 12 redraws follow the stream.
@@ -100,8 +104,14 @@ __device__ __forceinline__ bool flow_swap_at(CsRef cs_, const StepShared &sh, co
     i1 = -1; i2 = -1; nd = 0;
     if (n_all <= 1) return true;
     if (E + 2 >= limit) return false;
+    if (rg.lock && cs.rank != 0) return true;     // lock-step: the pair is rank 0's; this rank draws only if the pair's first chain is its own (a bet: not)
     const i32x4 sw = reinterpret_cast<const i32x4 *>(rg.sw)[E & rg.mask];
-    if (sw.z > 0) { i1 = sw.x; i2 = sw.y; nd = sw.z + 1; return E + nd < limit; }
+    if (sw.z > 0) {
+        i1 = sw.x; i2 = sw.y;
+        // (single rank: this rank draws judge_swap's number too; lock-step rank 0: only if the pair's first chain is its own)
+        nd = sw.z + ((!rg.lock || i1 / cs.n_chains == 0) ? 1 : 0);
+        return E + nd < limit;
+    }
     int pos = E;
     i1 = (int)(rg.U[pos & rg.mask] * cs.n_procs * cs.n_chains);
     pos++;
@@ -111,7 +121,7 @@ __device__ __forceinline__ bool flow_swap_at(CsRef cs_, const StepShared &sh, co
         pos++;
         if (i1 != i2) break;
     }
-    nd = pos - E + 1;
+    nd = pos - E + ((!rg.lock || i1 / cs.n_chains == 0) ? 1 : 0);
     return true;
 }
 
@@ -183,12 +193,78 @@ __device__ __forceinline__ bool flow_adopt(CsRef cs_, FlowShared &sh, const Ring
     return true;
 }
 
+// ---- a lock-step rank (k_mcmc<.., 4>): the swap records of htm_step.hpp's exchange_post / exchange_finish in the free-running loop ----
+// The chain wave that commits the LAST step of iteration `iter` on this rank posts the rank's record -- pair (rank 0's
+// select_pair), this rank's pending judge_swap draw (peeked), (T, L) of all its chains -- into every rank's inbox.
+__device__ __forceinline__ void flow_post_record(CsRef cs_, FlowShared &sh, const Ring &rg, int iter, int lane, int wmax)
+{
+    CsRef cs = rebase(cs_);
+    const int nc = cs.n_chains, M = rg.mask;
+    const int E = lds_ld(&sh.Eof[iter & 3]);          // every chain of the rank has committed: this is where the swap starts
+    int i1 = -1, i2 = -1, nd = 0;
+    flow_swap_at(cs, sh, rg, E, 1 << 30, i1, i2, nd);
+    const int own = (cs.rank == 0 && i1 >= 0 && i1 / nc == 0) ? 1 : 0;
+    const int jp = E + nd - own;                      // position of the pending judge_swap draw (after rank 0's pair draws)
+    if (lane < nc) { sh.xrec[4 + 2 * lane] = sh.temp[lane]; sh.xrec[5 + 2 * lane] = sh.L[lane]; }
+    // this rank asks everybody to stop after this iteration: record buffers or produced stream nearly used up
+    const bool my_stop = sh.c.n_lik + 3 * nc > cs.cap_lik || sh.c.n_smp + 3 * nc > cs.cap_smp || sh.avail < jp + 4 * wmax;
+    if (lane == 0) {
+        sh.xrec[0] = (double)i1; sh.xrec[1] = (double)i2; sh.xrec[2] = rg.U[jp & M]; sh.xrec[3] = (double)iter;
+        sh.c.swap_i1 = i1; sh.c.swap_i2 = i2; sh.c.swap_r = rg.U[jp & M]; sh.c.swap_logr = rg.LOGU[jp & M];
+        sh.c.spos = sh.origin + jp;                   // RNG commit: draws consumed so far (apply_swap adds the judge draw if it is ours)
+        sh.c.stage = ST_WAIT_SWAP;
+        sh.xcount[(iter + 1) & 3] = 0;                // (nobody commits a step of the next iteration before this record is in)
+    }
+    exchange_post(cs, sh, iter, lane, my_stop);
+}
+// One wave (whichever needs the outcome first) collects the n_procs records of iteration `iter`, applies the swap
+// (cls_parallel.f90:118-213), and -- if the judge draw turned out to be this rank's and was not predicted -- anchors the next
+// iteration one position later under a new epoch; then everybody may go on (xdone).
+__device__ __forceinline__ void flow_collect_records(CsRef cs_, FlowShared &sh, const Ring &rg, double *s_gath, int iter, int lane)
+{
+    CsRef cs = rebase(cs_);
+    const int nc = cs.n_chains;
+    const int E = lds_ld(&sh.Eof[iter & 3]);
+    int i1 = -1, i2 = -1, nd = 0;
+    flow_swap_at(cs, sh, rg, E, 1 << 30, i1, i2, nd);        // what this rank PREDICTED the swap to draw here
+    exchange_finish(cs, sh, s_gath, iter, lane, false);
+    if (lane == 0) {
+        const int base = (int)(sh.c.spos - sh.origin);        // where the next iteration really starts
+        if (sh.c.err == 0 && base != E + nd) {
+            const int e1 = sh.epoch + 1;
+            // (anchor of a step 0: `pos` = end of the iteration before + what the prediction adds there, flow_from_anchor)
+            lds_st(&sh.anch[e1 & 1], ((unsigned long long)(unsigned)((iter + 1 - sh.i0) * nc) << 32) | (unsigned)(base - nd));
+            lds_st(&sh.epoch, e1);
+        }
+        if (sh.c.stop != 0 || sh.c.err != 0) lds_st(&sh.last_iter, min(sh.last_iter, iter));
+        __hip_atomic_store(&sh.xdone, iter, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+// every wave, before it needs the outcome of iteration `iter`'s swap (its decision of the next iteration, or leaving the loop)
+__device__ __forceinline__ bool flow_settle(CsRef cs, FlowShared &sh, const Ring &rg, double *s_gath, int iter, int lane)
+{
+    if (iter <= uni(sh.i0) || lds_ld(&sh.xdone) >= iter) return true;
+    int mine = 0;
+    if (lane == 0) mine = atomicCAS(&sh.xclaim, iter - 1, iter) == iter - 1 ? 1 : 0;
+    if (uni(mine)) { flow_collect_records(cs, sh, rg, s_gath, iter, lane); return lds_ld(&sh.c.err) == 0; }
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (unsigned spin = 0; lds_ld(&sh.xdone) < iter; ++spin) {
+        if ((spin & 15u) == 15u) {
+            if (lds_ld(&sh.c.err) != 0) return false;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 2500000000ull) { if (lane == 0) sh.c.err = -10; return false; }
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return lds_ld(&sh.c.err) == 0;
+}
+
 // One chain step from its front to its commit and the orders of the chain's coming full evaluations (the free-running
 // counterpart of chain_pass).  All 64 lanes execute with identical (uniform) values; lane <-> station only inside
 // event_misfit.  `ext`: this wave keeps the LDS window of the stream ahead (chain 0's wave, one round of <= 64 positions
 // per step, in flight under the step's own loads).  Returns the stream position after the step, kFlowRestart or kFlowAbort.
-template <int NCH, bool F32>
+template <int NCH, bool F32, bool LOCK>
 __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, const Ring &rg, FlowWave &W, FlowNext &nx,
+                                         double *s_gath, int wmax,
                                          const double *s_sx, const double *s_sy, const double *s_sz, int c, int p, int iter,
                                          int lane, int wave, int NW, unsigned long long launch, bool ext, int look, int back,
                                          bool rec_now)
@@ -482,7 +558,19 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
     // ---- here by the waves of the two chains it concerns -- each evaluates the same expression on the same values
     const int par = iter & 3, ppar = (iter - 1) & 3;
     double T = sh.T4[par][c], rT = sh.rT4[par][c];        // (first iteration of a launch: written by the prologue)
-    if (iter - 1 > sh.i0) {
+    if constexpr (LOCK) {
+        // a lock-step rank: the swap of the iteration before is decided from ALL ranks' records (flow_settle); it may end the
+        // job (a rank asked everybody to stop, or failed) or move this rank's stream (the judge draw was ours after all)
+        if (!flow_settle(cs, sh, rg, s_gath, iter - 1, lane)) return kFlowAbort;
+        if (iter > lds_ld(&sh.last_iter)) return kFlowStop;
+        if (lds_ld(&sh.epoch) != W.epoch) {
+            bool stands = false;
+            while (!flow_adopt(cs, sh, rg, W, lds_ld(&sh.epoch), iter, c, true, stands)) { }
+            flow_void_books(cs, sh, wave, NW, nc_, lane);
+            if (!stands) return kFlowRestart;
+        }
+        T = sh.temp[c]; rT = sh.rtemp[c];
+    } else if (iter - 1 > sh.i0) {
         T = sh.T4[ppar][c]; rT = sh.rT4[ppar][c];
         if (cs.n_procs * nc_ > 1) {
             // (written by the last chain's wave before it published its check; this step's turn has seen that check)
@@ -523,6 +611,12 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
         }
         sh.L4[par][c] = L_post;
         lds_st(&sh.done[c], key);
+    }
+    if constexpr (LOCK) {
+        // the last chain of the rank to commit this iteration posts the rank's swap record
+        int last = 0;
+        if (lane == 0) last = atomicAdd(&sh.xcount[iter & 3], 1) == nc_ - 1 ? 1 : 0;
+        if (uni(last)) flow_post_record(cs, sh, rg, iter, lane, wmax);
     }
     FSTAMP(4);
     // ---- a rejected prior: this step was one draw shorter than the hop tables assume.  Everything after it starts
@@ -661,7 +755,7 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
 }
 
 // block 0 of a k_mcmc<NCH, F32, 0> launch when the host selects the free-running master (htm_hip.hip: flow_ok)
-template <int NCH, bool F32>
+template <int NCH, bool F32, bool LOCK = false>
 __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, int ring_size, int wmax, unsigned long long launch)
 {
     CsRef cs = rebase(cs_);
@@ -687,6 +781,7 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
     rg.mx = s_gath + kGathStage;
     rg.mstep = rg.mx + rg.mir_n;
     rg.mir_steps = cs.mirror_steps != 0;
+    rg.lock = LOCK ? 1 : 0;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -714,6 +809,7 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
         sh.epoch = 0; sh.anch[0] = 0ull; sh.anch[1] = 0ull;
         sh.i0 = sh.c.iter_done; sh.last_iter = sh.c.iter_target; sh.stop_code = 0;
         sh.n_full_w = 0ull; sh.n_part_w = 0ull;
+        sh.xdone = sh.c.iter_done; sh.xclaim = sh.c.iter_done; sh.xcount[0] = sh.xcount[1] = sh.xcount[2] = sh.xcount[3] = 0;
     }
     __syncthreads();
     const int i0 = sh.i0;
@@ -723,7 +819,7 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
         sh.done[c] = c;
         if (c < nc) {
             const double T = cs.temp[c], L = cs.L[c];
-            sh.L[c] = L;
+            sh.L[c] = L; sh.temp[c] = T; sh.rtemp[c] = 1.0 / T;
             sh.T4[(i0 + 1) & 3][c] = T; sh.T4[i0 & 3][c] = T; sh.L4[i0 & 3][c] = L;
             sh.rT4[(i0 + 1) & 3][c] = 1.0 / T; sh.rT4[i0 & 3][c] = 1.0 / T;
         }
@@ -731,7 +827,7 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
     if (sh.c.iter_done >= sh.c.iter_target || sh.c.stop || sh.c.err) return;      // (uniform)
     if (sh.avail < 3 * wmax) {                                 // the produced stream does not cover a safe stretch: the host refills
         __syncthreads();
-        if (tid == 0) { sh.c.stop = 2; *cs.ctrl = sh.c; }
+        if (tid == 0) { if (LOCK) sh.c.err = -7; else sh.c.stop = 2; *cs.ctrl = sh.c; }      // (lock-step ranks leave a launch only together: the host feeds the stream first)
         return;
     }
     // the draws an iteration can take: 6 per chain step + select_pair's and judge_swap's
@@ -763,7 +859,11 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
                 flow_void_books(cs, sh, wave, NW, nc, lane);
             }
         }
-        if (iter > lds_ld(&sh.last_iter) || sh.c.err != 0) break;
+        if (iter > lds_ld(&sh.last_iter) || sh.c.err != 0) {
+            // (a lock-step rank leaves only when the swap of its last iteration has been applied)
+            if constexpr (LOCK) { if (sh.c.err == 0) flow_settle(cs, sh, rg, s_gath, iter - 1, lane); }
+            break;
+        }
         if (__builtin_expect(W.rpos1 < 0 || W.B2 < 0, 0)) {      // predictions the window did not cover when they were made
             if (W.rpos1 < 0) { W.rpos1 = flow_next_base(cs, sh, rg, W.rpos, nc - W.rc, sh.fill); W.rc1 = 0; }
             if (W.B2 < 0 && W.rpos1 >= 0) W.B2 = flow_next_base(cs, sh, rg, W.rpos1, nc - W.rc1, sh.fill);
@@ -772,7 +872,7 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
         const bool known = nx.p >= 0 && nx.it == iter && nx.c == c && nx.epoch == W.epoch;
         const int p = known ? nx.p : hop_ahead(rg, W.rpos, c - W.rc);
         if (!known) nx.p = -1;
-        if (wave == 0 && c == 0 && lane == 0) {
+        if (!LOCK && wave == 0 && c == 0 && lane == 0) {      // (a lock-step rank asks the others through its swap record: flow_post_record)
             // chain 0's wave decides where the launch ends: record buffers or produced stream nearly used up.  Everybody
             // learns it before committing a step of this iteration (its turn waits for chain 0's check)
             int code = 0;
@@ -791,10 +891,10 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
             }
             if (dead) { if (lane == 0 && sh.c.err == 0) sh.c.err = -13; break; }
         }
-        const int r = flow_step<NCH, F32>(f, cs, sh, rg, W, nx, s_sx, s_sy, s_sz, c, p, iter, lane, wave, NW, launch, wave == 0,
+        const int r = flow_step<NCH, F32, LOCK>(f, cs, sh, rg, W, nx, s_gath, wmax, s_sx, s_sy, s_sz, c, p, iter, lane, wave, NW, launch, wave == 0,
                                           look, back, rec_phase == 1);
         if (r == kFlowRestart) continue;
-        if (r == kFlowAbort) break;
+        if (r == kFlowAbort || r == kFlowStop) break;
         // ---- this wave's next step
         c += NW;
         if (c >= nc) {
@@ -822,6 +922,14 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
 #endif
     // ---- every step up to last_iter is committed: the swap of the last iteration, counters, the launch's end state
     if (tid == 0 && sh.c.err == 0) {
+        if constexpr (LOCK) {
+            // (iteration counter, stream position, temperatures and the stop word were settled with the last swap)
+            const int last = sh.c.iter_done;
+            for (int k = 0; k < nc; ++k) cs.L[k] = sh.L[k];
+            if (sh.c.slog_cap > 0) sh.c.slog_n = min(sh.c.slog_cap, sh.c.slog_n + (last - i0) * nc);
+            sh.c.n_full_evals += (long long)sh.n_full_w;
+            sh.c.n_partial_evals += (long long)sh.n_part_w;
+        } else {
         const int last = min(sh.last_iter, sh.c.iter_target);
         if (last > i0) {
             const int par = last & 3;
@@ -843,6 +951,7 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
             if (last < sh.c.iter_target) sh.c.stop = sh.stop_code;
         }
     }
+    }
     __syncthreads();
     for (int k = tid; k < 7 * nc; k += blockDim.x) {          // flush this launch's counters
         if (sh.np[k]) atomicAdd(&cs.n_propose[k], sh.np[k]);
@@ -862,7 +971,9 @@ __global__ __launch_bounds__(512) void k_mcmc(FwdDev f, ChainsDev cs, int mode, 
     const KArgLayout __attribute__((address_space(4))) &ka = *(const KArgLayout __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
     if (blockIdx.x == 0) {
         // MK 3: the single-rank loop on the free-running master (flow_body); 0: the same loop with barriers (step_body)
-        if constexpr (MK == 3) flow_body<NCH, F32>(ka.f, ka.cs, target_arg, ring_size, wmax, launch);
+        // 4: a lock-step rank (MODE_LOCKRUN, swap records exchanged inside the launch) on the free-running master; 2: with barriers
+        if constexpr (MK == 3) flow_body<NCH, F32, false>(ka.f, ka.cs, target_arg, ring_size, wmax, launch);
+        else if constexpr (MK == 4) flow_body<NCH, F32, true>(ka.f, ka.cs, target_arg, ring_size, wmax, launch);
         else step_body<NCH, true, F32, MK>(ka.f, ka.cs, mode, target_arg, gathered, ring_size, wmax, launch);
         // every exit of the master comes through here (its returns are uniform over the block): release the workers
         __syncthreads();
@@ -882,7 +993,7 @@ __global__ __launch_bounds__(768) void k_mcmc_wide(FwdDev f, ChainsDev cs, int m
 {
     const KArgLayout __attribute__((address_space(4))) &ka = *(const KArgLayout __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
     if (blockIdx.x == 0) {
-        flow_body<NCH, F32>(ka.f, ka.cs, target_arg, ring_size, wmax, launch);
+        flow_body<NCH, F32, false>(ka.f, ka.cs, target_arg, ring_size, wmax, launch);
         __syncthreads();
         if (threadIdx.x == 0) st_agent(&ka.cs.ps->quit, launch + 1ull);
     } else {

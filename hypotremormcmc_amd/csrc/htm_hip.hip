@@ -169,6 +169,7 @@ struct htm_chains {
     bool persist = true;                       // k_mcmc (master + resident full-evaluation workers) vs k_step + k_full
     bool flow = false;                         // single-rank loop on the free-running master (htm_flow.hpp) instead of step_body
     bool split = false;                        // worker blocks as a k_workers launch of their own (12 waves per block) beside the master's
+    bool flow_lock = false;                    // lock-step ranks (MODE_LOCKRUN) on the free-running master too
     bool ctrl_fresh = false;                   // h_ctrl is the device's control block as of an idle stream (no launch since it was read)
     bool wide = false;                         // the single-rank loop in blocks of 12 waves (k_mcmc_wide: large event counts)
     int n_workers8 = 0;                        // worker blocks of the 8-wave launches (lock-step modes) when `wide`
@@ -259,6 +260,7 @@ int launch_mcmc(htm_chains *hc, int mode, int target, const double *gathered)
     }
     else if (mode == MODE_RUN && hc->flow) HTM_LAUNCH_MCMC_K(3);
     else if (mode == MODE_RUN) HTM_LAUNCH_MCMC_K(0);
+    else if (mode == MODE_LOCKRUN && hc->flow_lock) HTM_LAUNCH_MCMC_K(4);
     else if (mode == MODE_LOCKRUN) HTM_LAUNCH_MCMC_K(2);
     else HTM_LAUNCH_MCMC_K(1);
 #undef HTM_LAUNCH_MCMC_K
@@ -899,7 +901,7 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
         // block carries the master's LDS size).  Workers take events round-robin, so fewer of them only take longer.
 #define HTM_MCMC_FN(K) (h->dev.fp32 ? (h->nch == 1 ? (const void *)k_mcmc<1, true, K> : (const void *)k_mcmc<2, true, K>)                  \
                         : h->nch == 1 ? (const void *)k_mcmc<1, false, K> : h->nch == 2 ? (const void *)k_mcmc<2, false, K> : (const void *)k_mcmc<0, false, K>)
-        const void *fns[4] = {HTM_MCMC_FN(0), HTM_MCMC_FN(1), HTM_MCMC_FN(2), HTM_MCMC_FN(3)};
+        const void *fns[5] = {HTM_MCMC_FN(0), HTM_MCMC_FN(1), HTM_MCMC_FN(2), HTM_MCMC_FN(3), HTM_MCMC_FN(4)};
 #undef HTM_MCMC_FN
         if (hc->step_smem > 48 * 1024)
             for (const void *g : fns) HIPCHK(hipFuncSetAttribute(g, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hc->step_smem));
@@ -949,8 +951,10 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
         // debug switches.
         const char *e = getenv("HTM_FLOW");
         const int wd = 6 * nc + 16, c_max = 8 * ((nc - 1) / 8);
-        hc->flow = hc->persist && d.n_procs == 1 && !(e && e[0] == '0') && d.dbg == 0 && hc->dev.mirror_n > 0 &&
-                   hc->ring_size >= 4 * wd + 32 + 2 * c_max + 16;
+        const bool window_ok = hc->persist && !(e && e[0] == '0') && d.dbg == 0 && hc->dev.mirror_n > 0 &&
+                               hc->ring_size >= 4 * wd + 32 + 2 * c_max + 16;
+        hc->flow = window_ok && d.n_procs == 1;
+        hc->flow_lock = window_ok && !(getenv("HTM_FLOW_LOCK") && getenv("HTM_FLOW_LOCK")[0] == '0');      // (MODE_LOCKRUN: any number of ranks)
         // blocks of 12 waves where one worker wave evaluates several events per order (HTM_WIDE=0 / 1 overrides the choice by size)
         const char *ew = getenv("HTM_WIDE");
         const bool by_size = (h->E + 7) / 8 > 240;

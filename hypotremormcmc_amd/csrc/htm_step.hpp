@@ -93,6 +93,7 @@ struct Ring {                     // LDS window of the stream rings, index = rel
     double *mx, *mstep;
     int mir_n;
     bool mir_steps;
+    int lock;                     // htm_flow.hpp: 1 = a lock-step rank (select_pair is rank 0's, judge_swap's draw the pair's first rank's)
 };
 
 constexpr int kPassRestart = -1;  // chain_pass: the swap of the iteration before moved this rank's stream position: start again
@@ -962,7 +963,7 @@ __device__ __forceinline__ void exchange_post(CsRef cs_, const StepShared &sh, i
 
 // the same wave, later: wait for the n_procs records of iteration `iter`, decide the swap, publish sh.xdone = iter.
 // Rows of 64 granules, row = (rank r, chunk k of its record); kXLoads rows in flight.
-__device__ __forceinline__ void exchange_finish(CsRef cs_, StepShared &sh, double *s_gath, int iter, int lane)
+__device__ __forceinline__ void exchange_finish(CsRef cs_, StepShared &sh, double *s_gath, int iter, int lane, bool publish = true)
 {
     CsRef cs = rebase(cs_);
     const int nc = cs.n_chains, RW = 4 + 2 * nc, G = cs.xg, np = cs.n_procs, par = iter & 1;
@@ -1011,7 +1012,7 @@ __device__ __forceinline__ void exchange_finish(CsRef cs_, StepShared &sh, doubl
         }
         if (stop_any && sh.c.stop == 0) sh.c.stop = 3;          // everybody leaves after this iteration
         if (err_any && sh.c.err == 0) sh.c.err = -11;           // a peer reported a failure
-        __hip_atomic_store(&sh.xdone, iter, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (publish) __hip_atomic_store(&sh.xdone, iter, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 }
 
@@ -1058,6 +1059,7 @@ __device__ __forceinline__ void step_body(FwRef f_, CsRef cs_, int mode, int tar
     rg.mx = s_gath + kGathStage;
     rg.mstep = rg.mx + rg.mir_n;
     rg.mir_steps = cs.mirror_steps != 0;
+    rg.lock = 0;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
