@@ -1120,7 +1120,7 @@ static int drain_records(htm_chains *hc)
         HIPCHK(hipMemcpy(hc->smp_data.data() + o * hc->rec_len, d.smp_data, (size_t)ns * hc->rec_len * sizeof(double),
                          hipMemcpyDeviceToHost));
     }
-    if (hc->flow) {
+    if (hc->flow || hc->flow_lock) {
         // the free-running master hands out record slots as its waves get to them: put the drained records into the
         // reference's order, iteration by iteration and chain by chain (hypo_tremor_mcmc.f90:270-280)
         auto order = [](size_t n, const int32_t *it, const int32_t *ch) {
