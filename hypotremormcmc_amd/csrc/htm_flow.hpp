@@ -680,7 +680,9 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
         nx.type = d1.x; nx.idx = d1.y; nx.evt = d1.z; nx.dec_w = uni(d1v.w);
         nx.g = la_g; nx.r = la_r; nx.logr = la_logr;
         const int swz = uni(swv.z);
-        nx.b3 = cs.n_procs * nc_ > 1 ? (swz > 0 ? la_E2 + swz + 1 : -1) : la_E2;
+        // (what the swap at la_E2 draws on THIS rank: flow_swap_at's rule)
+        if (cs.n_procs * nc_ <= 1 || (rg.lock && cs.rank != 0)) nx.b3 = la_E2;
+        else nx.b3 = swz > 0 ? la_E2 + swz + ((!rg.lock || uni(swv.x) / nc_ == 0) ? 1 : 0) : -1;
     }
     if (rg.mir_n > 0 && sh.ob_pos[c] == -1 && iter + 1 <= sh.c.iter_target) {
         const int lim = sh.fill - 8;
