@@ -546,6 +546,11 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
             const bool okl = lane >= nc_ || lane == c || pk > need ||
                              (pk == need && (pk < W.akey || (ph == ((unsigned)W.epoch << 1))));
             if (__all(okl)) break;
+            if constexpr (LOCK) {
+                // the job may have stopped after the iteration before (a wave that learnt it from the swap records has left
+                // without taking its step of this iteration -- whose check this turn would wait for)
+                if (iter > lds_ld(&sh.last_iter)) return kFlowStop;
+            }
             if ((spin & 15u) == 15u) {
                 if (sh.c.err != 0) return kFlowAbort;
                 if (__builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) { if (lane == 0) sh.c.err = -12; return kFlowAbort; }
