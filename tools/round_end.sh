@@ -22,3 +22,7 @@ if [ -f hypotremormcmc_amd/lib/libhtm_hip_stamps.so ]; then
 fi
 ( timeout -k 10 400 python tools/soak_production.py > gpurun_out/${T}_soak_production.txt 2>&1; echo "soak rc $?" )
 tail -5 gpurun_out/${T}_soak_production.txt
+bash tools/shape_table.sh > gpurun_out/${T}_shapes.txt 2>&1
+cat gpurun_out/${T}_shapes.txt
+( timeout -k 10 600 python tools/stress_rejections.py 20000 > gpurun_out/${T}_stress_rejections.txt 2>&1; echo "stress rc $?" )
+tail -1 gpurun_out/${T}_stress_rejections.txt
