@@ -70,6 +70,7 @@ SIGNATURES = {
     "htm_chains_get_state": (C.c_int, [vp, C.c_int, dp, dp, dp, dp, dp, dp, dp, ip, ip]),
     "htm_chains_get_rng": (C.c_int, [vp, up]),
     "htm_chains_get_loglik": (C.c_int, [vp, C.c_int, dp]),
+    "htm_chains_share_gpu": (C.c_int, [vp, C.c_int]),
     "htm_quantiles": (C.c_int, [C.c_int, dp, C.c_long, C.c_long, C.POINTER(C.c_int), dp]),
     "htm_quantiles_dev": (C.c_int, [C.c_int, vp, C.c_long, C.c_long, C.c_long, C.POINTER(C.c_int), vp, vp]),
     "htm_chains_swap_record_host": (C.c_int, [vp, dp]),

@@ -137,6 +137,11 @@ class ChainSet:
     def run_lockstep_direct(self, n_iter: int):
         check(self._lib.htm_chains_run_lockstep_direct(self.handle, int(n_iter)))
 
+    def share_gpu(self, ranks_on_this_gpu: int):
+        """several ranks' persistent launches must be resident on this GPU at once: this rank takes its share of the CUs
+        (before the first run; HTM_RANKS_PER_GPU, if set, stands instead)"""
+        check(self._lib.htm_chains_share_gpu(self.handle, int(ranks_on_this_gpu)))
+
     def sync(self):
         check(self._lib.htm_chains_sync(self.handle))
 

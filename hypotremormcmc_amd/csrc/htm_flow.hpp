@@ -925,7 +925,7 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
     __syncthreads();
 #ifdef HTM_STAMPS
     if (cs.stamps)
-        for (int k = tid; k < 96; k += blockDim.x) if (sh.stamp_acc[k]) atomicAdd(&cs.stamps[k], sh.stamp_acc[k]);
+        for (int k = tid; k < 96; k += blockDim.x) if (sh.stamp_acc[k]) atomicAdd(&cs.stamps[32 + k], sh.stamp_acc[k]);      // (the workers' own stamps sit at 20..28)
 #endif
     // ---- every step up to last_iter is committed: the swap of the last iteration, counters, the launch's end state
     if (tid == 0 && sh.c.err == 0) {

@@ -169,6 +169,7 @@ struct htm_chains {
     bool persist = true;                       // k_mcmc (master + resident full-evaluation workers) vs k_step + k_full
     bool flow = false;                         // single-rank loop on the free-running master (htm_flow.hpp) instead of step_body
     bool split = false;                        // worker blocks as a k_workers launch of their own (12 waves per block) beside the master's
+    long blocks_fit = 0, wide_blocks_fit = 0;  // resident blocks of a k_mcmc / k_mcmc_wide launch on this device (htm_chains_share_gpu)
     bool flow_lock = false;                    // lock-step ranks (MODE_LOCKRUN) on the free-running master too
     bool ctrl_fresh = false;                   // h_ctrl is the device's control block as of an idle stream (no launch since it was read)
     bool wide = false;                         // the single-rank loop in blocks of 12 waves (k_mcmc_wide: large event counts)
@@ -935,6 +936,7 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
                 }
             }
         }
+        hc->blocks_fit = (long)per_cu * n_cu;
         long room = (long)per_cu * n_cu - 1;
         // Several ranks on one GPU (more masters instead of more rounds per master: 4 ranks x 8 chains run 2.7 M steps/s where one
         // rank x 32 chains runs 1.7 M): every rank's blocks must be resident at once, so each takes its share of the CUs
@@ -968,6 +970,7 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
             HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&wpc, wfn, 768, hc->step_smem));
             HIPCHK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
             long wroom = (long)wpc * n_cu - 1;
+            hc->wide_blocks_fit = (long)wpc * n_cu;
             if (const char *e2 = getenv("HTM_RANKS_PER_GPU")) { const int k = atoi(e2); if (k > 1) wroom = (long)wpc * n_cu / k - 1; }
             if (wroom >= 1) {
                 hc->wide = true;
@@ -1833,6 +1836,20 @@ int htm_chains_get_state(htm_chains *hc, int chain, double *hypo, double *t_corr
     if (log_likelihood) HIPCHK(hipMemcpy(log_likelihood, d.L + c, sizeof(double), hipMemcpyDeviceToHost));
     if (n_propose) HIPCHK(hipMemcpy(n_propose, d.n_propose + 7 * c, 7 * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (n_accept) HIPCHK(hipMemcpy(n_accept, d.n_accept + 7 * c, 7 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return HTM_OK;
+}
+
+int htm_chains_share_gpu(htm_chains *hc, int ranks_on_this_gpu)
+{
+    if (!hc || ranks_on_this_gpu < 1) return fail(HTM_EINVAL, "bad argument");
+    if (hc->launch_seq > 0) return fail(HTM_ESTATE, "htm_chains_share_gpu must be called before the chain set's first launch");
+    if (getenv("HTM_RANKS_PER_GPU") || !hc->persist || hc->split || ranks_on_this_gpu == 1) return HTM_OK;      // (an explicit setting stands)
+    const long fit = hc->wide ? hc->wide_blocks_fit : hc->blocks_fit;
+    const long room = fit / ranks_on_this_gpu - 1;
+    if (room < 1) return fail(HTM_ESTATE, "%d ranks on one GPU: not even one worker block per rank fits next to the masters", ranks_on_this_gpu);
+    hc->dev.n_workers = (int)std::min<long>(hc->dev.n_workers, room);
+    if (hc->wide) hc->n_workers8 = (int)std::min<long>(hc->n_workers8, hc->blocks_fit / ranks_on_this_gpu - 1);
+    hc->dev.n_wg = hc->dev.n_workers;
     return HTM_OK;
 }
 

@@ -8,7 +8,7 @@ module htm_c_api
   public :: htm_last_error_c, htm_error_message
   public :: htm_forward_create, htm_forward_destroy, htm_forward_loglik_full, htm_forward_loglik_partial
   public :: htm_forward_travel_time, htm_forward_amp, htm_forward_travel_time_single, htm_forward_amp_single
-  public :: htm_chains_create, htm_chains_destroy, htm_chains_run, htm_chains_get_state, htm_chains_get_rng, htm_chains_get_loglik
+  public :: htm_chains_create, htm_chains_destroy, htm_chains_run, htm_chains_get_state, htm_chains_get_rng, htm_chains_get_loglik, htm_chains_share_gpu
   public :: htm_chains_lik_count, htm_chains_lik_read, htm_chains_sample_count, htm_chains_sample_read
   public :: htm_chains_iterations_done
   public :: htm_chains_step_begin, htm_chains_swap_record_host, htm_chains_step_end_host, htm_chains_drain
@@ -280,6 +280,13 @@ module htm_c_api
        integer(c_int32_t), intent(out) :: n_propose(7), n_accept(7)
        integer(c_int) :: rc
      end function htm_chains_get_state
+
+     function htm_chains_share_gpu(handle, ranks_on_this_gpu) bind(C, name="htm_chains_share_gpu") result(rc)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: handle
+       integer(c_int), value :: ranks_on_this_gpu
+       integer(c_int) :: rc
+     end function htm_chains_share_gpu
 
      function htm_chains_get_loglik(handle, chain, log_likelihood) bind(C, name="htm_chains_get_loglik") result(rc)
        import :: c_int, c_double, c_ptr

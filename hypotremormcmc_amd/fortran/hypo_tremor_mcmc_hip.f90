@@ -183,6 +183,22 @@ program hypo_tremor_mcmc_hip
 #ifdef HTM_MPI
   ! main loop of src/hypo_tremor_mcmc.f90:236-284 with swap_temperature (src/cls_parallel.f90:100-216) as ONE
   ! all-gather of every rank's record {pair chosen by rank 0, pending judge_swap draw, (T, L) of its chains}
+  ! Ranks that share a GPU (fewer GPUs than ranks on a node): every rank's persistent launch must be resident at once, so each
+  ! takes its share of the CUs.  The ranks of this node tell each other which device they use.
+  block
+    integer :: node_comm, n_node, k, same
+    integer, allocatable :: devs(:)
+    call mpi_comm_split_type(MPI_COMM_WORLD, MPI_COMM_TYPE_SHARED, 0, MPI_INFO_NULL, node_comm, ierr)
+    call mpi_comm_size(node_comm, n_node, ierr)
+    allocate(devs(n_node))
+    call mpi_allgather(int(htm_default_device), 1, MPI_INTEGER, devs, 1, MPI_INTEGER, node_comm, ierr)
+    same = 0
+    do k = 1, n_node
+       if (devs(k) == int(htm_default_device)) same = same + 1
+    end do
+    if (same > 1) call check(htm_chains_share_gpu(chains, int(same, c_int)), "htm_chains_share_gpu")
+    call mpi_comm_free(node_comm, ierr)
+  end block
   ! Fastest transport first: persistent lock-step -- every rank's kernel writes its record straight into the other
   ! ranks' inboxes (peer-mapped device memory, xGMI between the GPUs of a node) and never leaves the GPU.  Set-up =
   ! one MPI_Allgather of the inboxes' IPC handles; taken only if EVERY rank could map every peer (HTM_XCHG=0: never).

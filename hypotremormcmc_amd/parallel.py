@@ -84,6 +84,7 @@ class TorchWorld:
         self.gathered = torch.zeros(self.world * self.rec.numel(), dtype=torch.float64, device=self.rec.device)
         # records a rank may hold between drains: n_chains per iteration at most
         self.drain_every = 4096
+        self._share_gpus()
         self.direct = self._try_direct_exchange()
         self.fast = None if self.direct else self._try_direct_rccl()
         # The set-up probe proves one token per peer, not the loop.  The FIRST direct run is therefore guarded: the rank's
@@ -93,6 +94,20 @@ class TorchWorld:
         self._direct_proven = False
         self._probe_token = 1
         self.fell_back = None
+
+    def _share_gpus(self):
+        """Ranks whose chains sit on the same GPU of the same host (a test arrangement, or deliberately more masters per GPU,
+        DESIGN.md 6) must all be resident at once: count them and let every rank take its share of the CUs."""
+        if not isinstance(self.r, DeviceRank) or self.world == 1:
+            return
+        import socket
+
+        mine = (socket.gethostname(), int(self.r.cs.fwd.device))
+        where = [None] * self.world
+        self.dist.all_gather_object(where, mine, group=self.group)
+        k = sum(1 for w in where if tuple(w) == mine)
+        if k > 1:
+            self.r.cs.share_gpu(k)
 
     def transport_name(self):
         if self.direct:

@@ -238,6 +238,11 @@ int htm_chains_get_state(htm_chains *hc, int chain, double *hypo, double *t_corr
                          double *a_corr, double *qs, double *temp, double *log_likelihood,
                          int32_t n_propose[7], int32_t n_accept[7]);
 int htm_chains_get_rng(htm_chains *hc, uint32_t state[4]);
+/* Several ranks share this rank's GPU (`ranks_on_this_gpu` of them, this one included): every rank's persistent launch must be
+ * resident at once (master and workers of a launch wait for each other), so each takes its share of the CUs.  Call before the
+ * chain set's first launch; the environment variable HTM_RANKS_PER_GPU, if set, stands instead.  (The reference has no
+ * counterpart: `mpirun -np N` ranks are CPU processes, src/cls_parallel.f90.) */
+int htm_chains_share_gpu(htm_chains *hc, int ranks_on_this_gpu);
 /* the chain's current log-likelihood alone (one 8-byte copy): what the reference's progress report prints every 1 000
  * iterations for chain 1 (`mc%one_step_summary`, src/cls_mcmc.f90:230-237) */
 int htm_chains_get_loglik(htm_chains *hc, int chain, double *log_likelihood);

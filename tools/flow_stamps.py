@@ -37,7 +37,7 @@ names = ["front: loads issued", "proposal, check published", "evaluation (2 posi
 print("ticks per step, by wave (partial-update steps); full-evaluation steps: total ticks per step (of which waiting for the workers)")
 print("%-4s %8s " % ("wave", "steps") + " ".join("%9s" % s[:9] for s in names) + " %9s | %7s %9s %9s | %9s %9s" % ("sum", "jobs", "ticks", "wait", "loop/iter", "between"))
 for w in range(min(8, nc)):
-    b = d[12 * w:12 * w + 12]
+    b = d[32 + 12 * w:32 + 12 * w + 12]
     ns, nj = max(1, b[7]), max(1, b[8])
     ph = [b[k] / ns for k in range(6)]
     steps = b[7] + b[8]
