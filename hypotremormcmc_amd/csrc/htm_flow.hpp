@@ -25,6 +25,10 @@
 #pragma once
 #include "htm_step.hpp"
 
+#ifndef HTM_FAIR
+#define HTM_FAIR 1        // diagnostics: 0 = no priority hand-over between the two waves of a SIMD
+#endif
+
 namespace htm {
 
 struct FlowShared : StepShared {
@@ -897,6 +901,14 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
                 __builtin_amdgcn_s_sleep(4);
             }
             if (dead) { if (lane == 0 && sh.c.err == 0) sh.c.err = -13; break; }
+        }
+        // Two chain waves share a SIMD, and the hardware issues the older one first: left alone, waves 0-3 finish a step in
+        // ~10 k cycles and wait ~2.7 k in their turns for waves 4-7, which need ~12 k.  The wave that is BEHIND its SIMD's
+        // other wave (a step or more, by the checks published) asks for priority; the one ahead gives it up.
+        if (HTM_FAIR && (c ^ 4) < nc) {      // (chain c ^ 4 is the corresponding chain of the SIMD's other wave, whatever the number of chains per wave)
+            const int pk = (int)(unsigned)sh.prog[c ^ 4];
+            if (pk >= (iter - i0) * nc + (c ^ 4)) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
         }
         const int r = flow_step<NCH, F32, LOCK>(f, cs, sh, rg, W, nx, s_gath, wmax, s_sx, s_sy, s_sz, c, p, iter, lane, wave, NW, launch, wave == 0,
                                           look, back, rec_phase == 1);

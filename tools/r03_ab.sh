@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-ROUNDS=2 BENCH_ARGS="--steps 6 --warmup 2 --iters-per-step 16384" bash tools/ab.sh hypotremormcmc_amd/lib/libhtm_base.so hypotremormcmc_amd/lib/libhtm_baselog.so hypotremormcmc_amd/lib/libhtm_hip.so 2>&1 | tee gpurun_out/r03_ab.txt
+ROUNDS=2 BENCH_ARGS="--steps 6 --warmup 2 --iters-per-step 16384" bash tools/ab.sh hypotremormcmc_amd/lib/libhtm_prev.so hypotremormcmc_amd/lib/libhtm_hip.so 2>&1 | tee gpurun_out/r03_ab2.txt
