@@ -905,7 +905,8 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
         // Two chain waves share a SIMD, and the hardware issues the older one first: left alone, waves 0-3 finish a step in
         // ~10 k cycles and wait ~2.7 k in their turns for waves 4-7, which need ~12 k.  The wave that is BEHIND its SIMD's
         // other wave (a step or more, by the checks published) asks for priority; the one ahead gives it up.
-        if (HTM_FAIR && (c ^ 4) < nc) {      // (chain c ^ 4 is the corresponding chain of the SIMD's other wave, whatever the number of chains per wave)
+        // (Not between lock-step ranks: there the hand-over costs 2-3 %, profiles/r03_n_fair.txt.)
+        if (HTM_FAIR && !LOCK && (c ^ 4) < nc) {      // (chain c ^ 4 is the corresponding chain of the SIMD's other wave, whatever the number of chains per wave)
             const int pk = (int)(unsigned)sh.prog[c ^ 4];
             if (pk >= (iter - i0) * nc + (c ^ 4)) __builtin_amdgcn_s_setprio(1);
             else __builtin_amdgcn_s_setprio(0);
