@@ -41,11 +41,45 @@ __device__ __forceinline__ double readlane63_f64(double v)
     return __hiloint2double(hi, lo);
 }
 
+#ifndef HTM_MFMA_SUM
+#define HTM_MFMA_SUM 0
+#endif
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// The same sum on the matrix pipe: two v_mfma_f64_16x16x4_f64 against a matrix of ones.  Lane l holds A[l & 15][l >> 4], so
+// the first product gives S_i = x_i + x_{i+16} + x_{i+32} + x_{i+48} for every row i; a lane of group g = l >> 4 receives the
+// rows g, g + 4, g + 8, g + 12 in its four result registers; their sum G_g is that lane's element of the second product's A,
+// whose every result element is G_0 + G_1 + G_2 + G_3.  Two matrix instructions and three additions per value in place of
+// twelve DPP moves, six additions and two v_readlane: 7 issue slots for 20.  Fixed order, every lane gets the sum.
+__device__ __forceinline__ double wave_sum_mfma(double x)
+{
+    const f64x4 z = {0.0, 0.0, 0.0, 0.0};
+    const f64x4 d = __builtin_amdgcn_mfma_f64_16x16x4f64(x, 1.0, z, 0, 0, 0);
+    const double g = (d[0] + d[1]) + (d[2] + d[3]);
+    const f64x4 e = __builtin_amdgcn_mfma_f64_16x16x4f64(g, 1.0, z, 0, 0, 0);
+    return e[0];
+}
+
 // N independent sums, interleaved step by step so that the DPP latencies overlap.
 // Must be called with all 64 lanes active; inactive stations contribute 0.
 template <int N>
 __device__ __forceinline__ void wave_sum(double (&v)[N])
 {
+    if constexpr (HTM_MFMA_SUM != 0) {
+        const f64x4 z = {0.0, 0.0, 0.0, 0.0};
+        double g[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const f64x4 d = __builtin_amdgcn_mfma_f64_16x16x4f64(v[k], 1.0, z, 0, 0, 0);
+            g[k] = (d[0] + d[1]) + (d[2] + d[3]);
+        }
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const f64x4 e = __builtin_amdgcn_mfma_f64_16x16x4f64(g[k], 1.0, z, 0, 0, 0);
+            v[k] = e[0];
+        }
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < N; ++k) v[k] += dpp_mov_f64<0xB1, 0xF>(v[k]);   // quad_perm [1,0,3,2]
 #pragma unroll
@@ -328,7 +362,8 @@ __device__ __forceinline__ void event_misfit(const FW &f, const ObsRegs<NCH> &ob
 // the models differ in position, corrections, vs and qs; their evaluations are independent instruction streams, written
 // side by side so that one model's dependent chains (square root, logarithm, the DPP reductions) run under the other's --
 // one station per lane has no such parallelism of its own.  Same arithmetic per model as event_misfit<NCH, 1>.
-template <int NCH, int NM, bool F32 = false, class FW>
+// PRE: `beta` and `q` hold 1 / vs and pi f / (qs vs) already (the caller formed them once for all events).
+template <int NCH, int NM, bool F32 = false, bool PRE = false, class FW>
 __device__ __forceinline__ void event_misfit_models(const FW &f, const ObsRegs<NCH> &ob, int lane, const StaRegs<NCH> &geo,
                                                     const double (&tcm)[NM][NCH], const double (&acm)[NM][NCH],
                                                     const double (&px)[NM], const double (&py)[NM], const double (&pz)[NM],
@@ -336,7 +371,10 @@ __device__ __forceinline__ void event_misfit_models(const FW &f, const ObsRegs<N
 {
     double rbeta[NM], katt[NM];
 #pragma unroll
-    for (int p = 0; p < NM; ++p) { const double qbeta = q[p] * beta[p]; rbeta[p] = 1.0 / beta[p]; katt[p] = (kPi * kFreq) / qbeta; }
+    for (int p = 0; p < NM; ++p) {
+        if constexpr (PRE) { rbeta[p] = beta[p]; katt[p] = q[p]; }
+        else { const double qbeta = q[p] * beta[p]; rbeta[p] = 1.0 / beta[p]; katt[p] = (kPi * kFreq) / qbeta; }
+    }
     const double (&tob)[NCH] = ob.tob, (&tpr)[NCH] = ob.tpr, (&aob)[NCH] = ob.aob, (&apr)[NCH] = ob.apr;
     double ts[NM][NCH], as[NM][NCH];
     double red[2 * NM];

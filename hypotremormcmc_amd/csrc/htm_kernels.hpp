@@ -57,41 +57,67 @@ __global__ __launch_bounds__(256) void k_full(FwdDev f, FullJob jb)
     if constexpr (NCH > 0) {
         if (keep_obs) load_obs_regs<NCH, F32>(ob_keep, f, blockIdx.x * 4 + wave, lane);
     }
-    // Stacked models, one event per wave, its rows resident (the shape of the batched call): TWO models per trip, evaluated
-    // side by side (event_misfit_models) -- with one station per lane a single model's evaluation is one dependent chain
-    // after the other, and the pair shares the trip's two barriers.
-    __shared__ double s_red2[2][4];
+    // Stacked models, one event per wave, its rows resident (the shape of the batched call): rounds of up to four PAIRS of
+    // models.  A pair is evaluated side by side (event_misfit_models: with one station per lane a single model's evaluation is
+    // one dependent chain after the other).  What does not depend on the event is done once per round, not once per wave and
+    // model: the two divisions of a model (1 / vs, pi f / (qs vs): cls_forward.f90:118, :204) by one lane each, and the sums
+    // over lanes and waves of the round's eight models by the whole block in one pass over LDS -- in the association of
+    // wave_sum and of the single-model trip below (a balanced tree over the lanes, then (w0 + w1) + (w2 + w3)), so a stacked
+    // model's value is bit for bit what the one-by-one call gives (tests/test_gpu_forward.py).
+    __shared__ double s_rb[8], s_ka[8];
+    __shared__ __attribute__((aligned(16))) double s_out[8][4][64];
     if constexpr (NCH > 0) {
-        if (!jb.desc && keep_obs) {
+        if (!jb.desc && jb.epw == 1) {           // (block-uniform: a wave of the last tile without an event adds zeros and keeps the barriers)
             StaRegs<NCH> geo;
             load_sta_regs<NCH>(geo, f.S, lane, f.sx, f.sy, f.sz, jb.tc, jb.ac, 0, -1, 0.0);      // (coordinates; the corrections come per model)
             const int ev = blockIdx.x * 4 + wave;
+            const int evc = keep_obs ? ev : 0;
             int k = k0;
-            for (; k + kstep < nm; k += 2 * kstep) {
-                const int ms[2] = {k, k + kstep};
-                double tcm[2][NCH], acm[2][NCH], px[2], py[2], pz[2], beta[2], q[2], out[2];
-#pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    const double *hyp = jb.hypo + (size_t)ms[p] * jb.hypo_stride;
-                    const double *tc = jb.tc + (size_t)ms[p] * jb.tc_stride, *ac = jb.ac + (size_t)ms[p] * jb.ac_stride;
-                    beta[p] = jb.vs[ms[p]]; q[p] = jb.qs[ms[p]];
-                    px[p] = hyp[3 * ev]; py[p] = hyp[3 * ev + 1]; pz[p] = hyp[3 * ev + 2];
-#pragma unroll
-                    for (int c = 0; c < NCH; ++c) {
-                        const int j = lane + 64 * c;
-                        tcm[p][c] = j < f.S ? tc[j] : 0.0; acm[p][c] = j < f.S ? ac[j] : 0.0;
-                    }
+            while (k + kstep < nm) {
+                const int left = (nm - k + kstep - 1) / kstep;          // models of this block from k on
+                const int np = left / 2 < 4 ? left / 2 : 4;             // pairs of this round
+                if ((int)threadIdx.x < 2 * np) {
+                    const int m = k + (int)threadIdx.x * kstep;
+                    const double beta = jb.vs[m], q = jb.qs[m];
+                    s_rb[threadIdx.x] = 1.0 / beta; s_ka[threadIdx.x] = (kPi * kFreq) / (q * beta);
                 }
-                event_misfit_models<NCH, 2, F32>(f, ob_keep, lane, geo, tcm, acm, px, py, pz, beta, q, out);
-                double tot[2] = {out[0], out[1]};
-                wave_sum<2>(tot);
-                if (lane == 0) { s_red2[0][wave] = tot[0]; s_red2[1][wave] = tot[1]; }
+                __syncthreads();      // (also: the round before has been summed before its s_out is overwritten)
+                for (int j = 0; j < np; ++j) {
+                    double tcm[2][NCH], acm[2][NCH], px[2], py[2], pz[2], rbeta[2], katt[2], out[2] = {0.0, 0.0};
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        const int m = k + (2 * j + p) * kstep;
+                        const double *hyp = jb.hypo + (size_t)m * jb.hypo_stride;
+                        const double *tc = jb.tc + (size_t)m * jb.tc_stride, *ac = jb.ac + (size_t)m * jb.ac_stride;
+                        rbeta[p] = s_rb[2 * j + p]; katt[p] = s_ka[2 * j + p];
+                        px[p] = hyp[3 * evc]; py[p] = hyp[3 * evc + 1]; pz[p] = hyp[3 * evc + 2];
+#pragma unroll
+                        for (int c = 0; c < NCH; ++c) {
+                            const int jj = lane + 64 * c;
+                            tcm[p][c] = jj < f.S ? tc[jj] : 0.0; acm[p][c] = jj < f.S ? ac[jj] : 0.0;
+                        }
+                    }
+                    if (keep_obs) event_misfit_models<NCH, 2, F32, true>(f, ob_keep, lane, geo, tcm, acm, px, py, pz, rbeta, katt, out);
+                    s_out[2 * j][wave][lane] = out[0]; s_out[2 * j + 1][wave][lane] = out[1];
+                }
                 __syncthreads();
-                if (threadIdx.x < 2)
-                    jb.partial[(size_t)ms[threadIdx.x] * jb.n_wg + blockIdx.x] =
-                        (s_red2[threadIdx.x][0] + s_red2[threadIdx.x][1]) + (s_red2[threadIdx.x][2] + s_red2[threadIdx.x][3]);
-                __syncthreads();
+                {   // thread t: model t >> 5 of the round, wave (t >> 3) & 3, lanes 8 (t & 7) .. + 7
+                    const int t = threadIdx.x, i = t >> 5;
+                    const double *src = &s_out[0][0][0] + 8 * t;
+                    double v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = src[u];
+                    double x = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+                    x += dpp_mov_f64<0xB1, 0xF>(x);      // the eight octets of a wave's 64 lanes: quad_perm [1,0,3,2],
+                    x += dpp_mov_f64<0x4E, 0xF>(x);      // [2,3,0,1],
+                    x += dpp_mov_f64<0x141, 0xF>(x);     // row_half_mirror
+                    x += dpp_mov_f64<0x128, 0xF>(x);     // row_ror:8 -- the other wave of the pair (w0 + w1, w2 + w3)
+                    x += dpp_mov_f64<0x142, 0xA>(x);     // row_bcast:15 -> rows 1, 3: (w2 + w3) + (w0 + w1)
+                    if ((t & 31) == 31 && i < 2 * np) jb.partial[(size_t)(k + i * kstep) * jb.n_wg + blockIdx.x] = x;
+                }
+                k += 2 * np * kstep;
             }
+            __syncthreads();   // (the single-model trips below use s_red behind their own barriers; keeps the block together)
             k0 = k;            // (an odd model out takes the single-model trip below)
         }
     }
@@ -238,6 +264,10 @@ namespace htm {
 __global__ void k_mathtest(int which, const double *x, double *y, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (which == 4) {            // the matrix-pipe wave sum: every lane's result for its wave's 64 values (n a multiple of 64)
+        if (i < n) y[i] = wave_sum_mfma(x[i]);
+        return;
+    }
     if (i < n) y[i] = which == 0 ? htm_log(x[i]) : which == 1 ? htm_sqrt(x[i]) : which == 2 ? sqrt(x[i]) : log(x[i]);   // 3: the device library's log (Rayleigh prior ratio, htm_step.hpp)
 }
 
@@ -257,9 +287,16 @@ __global__ void k_selftest(const double *in, double *out_dpp, double *out_ref, u
     wave_sum<2>(v);
     if (lane == 0) {
         out_dpp[0] = v[0]; out_dpp[1] = v[1];
-        for (int s = 0; s < 2; ++s) {   // same association as the DPP tree
+        for (int s = 0; s < 2; ++s) {   // same association as wave_sum's
             double t[64];
             for (int i = 0; i < 64; ++i) t[i] = in[64 * s + i];
+            if (HTM_MFMA_SUM != 0) {     // the matrix instruction adds its four products in order of k, from zero
+                double S[16], G[4];
+                for (int i = 0; i < 16; ++i) S[i] = ((t[i] + t[i + 16]) + t[i + 32]) + t[i + 48];
+                for (int g = 0; g < 4; ++g) G[g] = (S[g] + S[g + 4]) + (S[g + 8] + S[g + 12]);
+                out_ref[s] = ((G[0] + G[1]) + G[2]) + G[3];
+                continue;
+            }
             double q[16];
             for (int i = 0; i < 16; ++i) q[i] = (t[4 * i] + t[4 * i + 1]) + (t[4 * i + 2] + t[4 * i + 3]);
             double r[4];

@@ -160,6 +160,26 @@ def test_full_and_partial_vs_oracle_ragged_shapes(shape):
         assert abs(Pg - Po) <= RTOL_L * abs(Po)
 
 
+@pytest.mark.parametrize("shape", [(37, 64), (50, 65), (9, 16), (1, 1), (1001, 64)])
+@pytest.mark.parametrize("n", [2, 5])
+def test_stacked_models_equal_one_by_one_when_the_last_tile_is_ragged(shape, n):
+    """the stacked-model call on event counts that leave waves of the last tile without an event (cls_forward.f90:268-303)"""
+    from hypotremormcmc_amd import synth
+
+    E, S = shape
+    data = synth.make_synthetic(E, S, seed=7 + E + S, n_missing=2 if E * S > 20 else 0)
+    f, o = _mk(data, {}), _orc(data, {})
+    rng = np.random.default_rng(E * 31 + S + n)
+    H = np.stack([(data.ev_xyz + rng.normal(0, 1.0, data.ev_xyz.shape)).reshape(-1) for _ in range(n)])
+    TC = rng.normal(0, 0.2, (n, S)); AC = rng.normal(0, 0.02, (n, S))
+    VS = 3 + rng.normal(0, 0.2, n); QS = 250 + rng.normal(0, 30, n)
+    Lb = f.calc_log_likelihood_batch(H, TC, VS, AC, QS)
+    Ls = np.array([f.calc_log_likelihood(H[k], TC[k], VS[k], AC[k], QS[k]) for k in range(n)])
+    assert np.array_equal(Lb, Ls)
+    Lo = np.array([o.calc_log_likelihood(H[k], TC[k], VS[k], AC[k], QS[k]) for k in range(n)])
+    np.testing.assert_allclose(Lb, Lo, rtol=RTOL_L_FULLSIZE if E > 500 else RTOL_L)
+
+
 def test_headline_size_properties_1000x64():
     """BASELINE size (1 000 events x 64 stations): oracle agreement on one model + size-independent
     properties: batch == single bit for bit, permutation equivariance, idempotence, partial == full(moved)."""
