@@ -60,11 +60,69 @@ __device__ __forceinline__ double wave_sum_mfma(double x)
     return e[0];
 }
 
+#ifndef HTM_TSUM
+#define HTM_TSUM 1
+#endif
+// x + x of the lane 16 (32) places away, in every lane: v_permlane16_swap (v_permlane32_swap) on two copies of x leaves the
+// even (lower) rows in one and the odd (upper) rows in the other.
+__device__ __forceinline__ double swap16_sum(double x)
+{
+    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+__device__ __forceinline__ double swap32_sum(double x)
+{
+    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+
+// Two or four sums at once, TRANSPOSED: the first stage (lane <-> lane ^ 1) leaves each lane with the pair sum of ONE value of
+// every two, the second (lane ^ 2, four values) with the quad sum of one of four; from there a single register per lane runs
+// through the remaining stages instead of N.  Which value a lane keeps (its "class") is chosen so that the mirror stages pair
+// lanes of the same class: class = lane & 3 in the even quads of a row, 3 - (lane & 3) in the odd ones (row_half_mirror and
+// row_mirror reverse the lane order within 8 and 16); the stages across rows use the lane-preserving swaps above.  Every
+// value's additions are the balanced tree over the lanes in natural order -- the same operands at every node as in the plain
+// form below, so the same bits -- in 30 instructions for two values (44) and 45 for four (88).  Lanes 0..N-1 hold classes
+// 0..N-1 at the end.
+template <int N>
+__device__ __forceinline__ void wave_sum_transposed(double (&v)[N])
+{
+    static_assert(N == 2 || N == 4, "two or four values");
+    const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const bool b0 = ((lane ^ (lane >> 2)) & 1u) != 0u;
+    double x;
+    {
+        const double keep = b0 ? v[1] : v[0], send = b0 ? v[0] : v[1];
+        x = keep + dpp_mov_f64<0xB1, 0xF>(send);                       // quad_perm [1,0,3,2]
+    }
+    if constexpr (N == 4) {
+        const bool b1 = (((lane >> 1) ^ (lane >> 2)) & 1u) != 0u;
+        const double keep2 = b0 ? v[3] : v[2], send2 = b0 ? v[2] : v[3];
+        const double y = keep2 + dpp_mov_f64<0xB1, 0xF>(send2);
+        const double keep = b1 ? y : x, send = b1 ? x : y;
+        x = keep + dpp_mov_f64<0x4E, 0xF>(send);                       // quad_perm [2,3,0,1]
+    } else {
+        x += dpp_mov_f64<0x4E, 0xF>(x);
+    }
+    x += dpp_mov_f64<0x141, 0xF>(x);                                   // row_half_mirror
+    x += dpp_mov_f64<0x140, 0xF>(x);                                   // row_mirror
+    x = swap16_sum(x);
+    x = swap32_sum(x);
+    const int lo = __double2loint(x), hi = __double2hiint(x);
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = __hiloint2double(__builtin_amdgcn_readlane(hi, k), __builtin_amdgcn_readlane(lo, k));
+}
+
 // N independent sums, interleaved step by step so that the DPP latencies overlap.
 // Must be called with all 64 lanes active; inactive stations contribute 0.
 template <int N>
 __device__ __forceinline__ void wave_sum(double (&v)[N])
 {
+    if constexpr (HTM_TSUM != 0 && HTM_MFMA_SUM == 0 && (N == 2 || N == 4)) { wave_sum_transposed<N>(v); return; }
     if constexpr (HTM_MFMA_SUM != 0) {
         const f64x4 z = {0.0, 0.0, 0.0, 0.0};
         double g[N];

@@ -2154,7 +2154,7 @@ int htm_selftest_math(int device, int which, const double *x, double *y, int n)
 {
     int rc = use_device(device);
     if (rc) return rc;
-    if (!x || !y || n < 0 || which < 0 || which > 4 || (which == 4 && n % 64 != 0))
+    if (!x || !y || n < 0 || which < 0 || which > 6 || (which == 4 && n % 64 != 0) || (which >= 5 && n % 256 != 0))
         return fail(HTM_EINVAL, "htm_selftest_math: null pointer, negative count or unknown function");
     if (n == 0) return HTM_OK;
     double *d = nullptr;

@@ -268,6 +268,16 @@ __global__ void k_mathtest(int which, const double *x, double *y, int n)
         if (i < n) y[i] = wave_sum_mfma(x[i]);
         return;
     }
+    if (which == 5 || which == 6) {     // four sums per wave at once (5, wave_sum<4>) and one by one (6): x = four blocks of n / 4 values
+        const int q = n / 4;
+        if (i < q) {
+            double v[4] = {x[i], x[q + i], x[2 * q + i], x[3 * q + i]};
+            if (which == 5) wave_sum<4>(v);
+            else { for (int k = 0; k < 4; ++k) v[k] = wave_sum1(v[k]); }
+            for (int k = 0; k < 4; ++k) y[k * q + i] = v[k];
+        }
+        return;
+    }
     if (i < n) y[i] = which == 0 ? htm_log(x[i]) : which == 1 ? htm_sqrt(x[i]) : which == 2 ? sqrt(x[i]) : log(x[i]);   // 3: the device library's log (Rayleigh prior ratio, htm_step.hpp)
 }
 

@@ -313,7 +313,10 @@ int htm_selftest(int device);
  * library's sqrt (what 1 must equal), 3 the device library's log -- the one used by the Rayleigh prior ratio
  * (reference src/cls_model.f90:184-185, `log(x_new - mu) - log(x_old - mu)`: a term of the Metropolis decision, so the test
  * compares it with the host libm the reference links).  Lets a test measure them against a wider-precision result (stated
- * bound of the logarithm: < 1 ulp).  Synchronous. */
+ * bound of the logarithm: < 1 ulp).  The wave-level sums of the likelihood (cls_forward.f90:125-132, :210-217, :281-299) have
+ * their own modes: 4 = every lane's sum of its wave's 64 values on the matrix pipe (n a multiple of 64), 5 / 6 = x is four blocks
+ * of n / 4 values, a wave's four sums taken at once (5) or one by one (6) -- a test compares the associations bit for bit
+ * (n a multiple of 256).  Synchronous. */
 int htm_selftest_math(int device, int which, const double *x, double *y, int n);
 
 /* mod_random's generator (reference src/mod_random.f90:60-74) is linear over GF(2): the state after n draws is

@@ -1,9 +1,12 @@
 """GPU parity: `type forward` on the HIP path (through the C ABI) vs the oracle and the reference's own
 known answers.  Tolerance: 1e-12 relative on log-likelihoods (north_star asks for 1e-9; summation order and
 ocml-vs-glibc log() are the only differences), 1e-13 absolute-relative on synthetics."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
+from hypotremormcmc_amd import _lib
 from tests.helpers import load_case, tf
 
 pytestmark = pytest.mark.gpu
@@ -37,6 +40,29 @@ def test_selftest_dpp_reduction_and_device_rng():
     from hypotremormcmc_amd import _lib
 
     _lib.check(_lib.load().htm_selftest(0))
+
+
+def test_wave_sums_of_two_and_four_values_equal_the_single_sum_bit_for_bit():
+    """the transposed form (htm_device.hpp wave_sum_transposed) adds the same operands at every node of the tree as the plain one"""
+    lib = _lib.load()
+    rng = np.random.default_rng(11)
+    n = 256 * 64
+    x = rng.standard_normal(n) * np.exp(rng.uniform(-30, 30, n))
+    y4 = np.empty_like(x); y1 = np.empty_like(x); ym = np.empty_like(x)
+    _lib.check(lib.htm_selftest_math(0, 5, x.ctypes.data_as(_lib.dp), y4.ctypes.data_as(_lib.dp), C.c_int(n)))
+    _lib.check(lib.htm_selftest_math(0, 6, x.ctypes.data_as(_lib.dp), y1.ctypes.data_as(_lib.dp), C.c_int(n)))
+    assert np.array_equal(y4, y1)
+    X = x.reshape(-1, 64)
+    t = X
+    while t.shape[1] > 1:                      # the balanced tree over the lanes in natural order
+        t = t[:, 0::2] + t[:, 1::2]
+    assert np.array_equal(y1.reshape(-1, 64), np.repeat(t, 64, axis=1))
+    # the matrix-pipe form (measured, not used): the association of two v_mfma_f64_16x16x4_f64 against ones
+    _lib.check(lib.htm_selftest_math(0, 4, x.ctypes.data_as(_lib.dp), ym.ctypes.data_as(_lib.dp), C.c_int(n)))
+    S = ((X[:, 0:16] + X[:, 16:32]) + X[:, 32:48]) + X[:, 48:64]
+    G = (S[:, 0:4] + S[:, 4:8]) + (S[:, 8:12] + S[:, 12:16])
+    T = ((G[:, 0] + G[:, 1]) + G[:, 2]) + G[:, 3]
+    assert np.array_equal(ym.reshape(-1, 64), np.repeat(T[:, None], 64, axis=1))
 
 
 def test_device_logarithm_is_within_one_ulp():
