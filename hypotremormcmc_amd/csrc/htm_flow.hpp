@@ -25,6 +25,9 @@
 #pragma once
 #include "htm_step.hpp"
 
+#ifndef HTM_TURN_SLEEP
+#define HTM_TURN_SLEEP 1  // s_sleep argument in the turn's wait (64 clocks each)
+#endif
 #ifndef HTM_FAIR
 #define HTM_FAIR 1        // diagnostics: 0 = no priority hand-over between the two waves of a SIMD
 #endif
@@ -559,7 +562,7 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
                 if (sh.c.err != 0) return kFlowAbort;
                 if (__builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) { if (lane == 0) sh.c.err = -12; return kFlowAbort; }
             }
-            __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(HTM_TURN_SLEEP);
         }
     }
     FSTAMP(3);
