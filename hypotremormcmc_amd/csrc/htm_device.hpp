@@ -640,6 +640,27 @@ struct StreamDev {
     long long *hop_end;        // every array is complete for positions < *hop_end
 };
 
+// What a proposal reads of the element it perturbs, packed: ONE 32-byte scalar load per step where the four per-field arrays
+// cost four (four cache lines).  `rs2` = 1 / (2 sigma^2).  When every chain of the rank has the same priors and step sizes --
+// the reference's set-up (hypo_tremor_mcmc.f90: one parameter file for all chains) -- only chain 0's records are kept in use
+// (ChainsDev::prior_same): 1 / n_chains of the footprint, which decides whether the table stays in L2 (10 000 events x 16 chains:
+// 15 MB in four arrays against 1 MB here; the step's front fell from 6 k to 3 k cycles).
+struct __attribute__((aligned(32))) PriorRec {
+    double mu, rs2, step;
+    int32_t ptype, pad;
+};
+
+// (through the constant address space: a scalar load, as ld_const; the four doubles travel as one vector)
+__device__ __forceinline__ PriorRec ld_prior(const PriorRec *p)
+{
+    typedef const f64x4 __attribute__((address_space(4))) *CP;
+    const f64x4 v = *(CP)(unsigned long long)p;
+    PriorRec r;
+    r.mu = v[0]; r.rs2 = v[1]; r.step = v[2];
+    r.ptype = __double2loint(v[3]); r.pad = 0;
+    return r;
+}
+
 struct ChainsDev {
     int n_chains, n_procs, rank;
     int S, E;
@@ -683,6 +704,8 @@ struct ChainsDev {
     unsigned long long *stamps;      // diagnostic builds (-DHTM_STAMPS) only, else nullptr
     int dbg;                         // test switches (bit 0: HTM_DEBUG_NO_DROP, chain waves do not take disproved orders back)
     unsigned long long *diag;        // [32] what a wait that gave up was waiting for (written once, on the failure path; the host reports it)
+    const PriorRec *prior;           // [element of the rank's parameter vector] (layout of xall)
+    int prior_same;                  // all chains share chain 0's records: element (group, chain c, idx) reads (group, 0, idx)
 };
 
 }  // namespace htm

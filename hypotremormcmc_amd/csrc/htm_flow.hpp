@@ -298,10 +298,10 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
         if (fill_to > fl + 64) fill_to = fl + 64;
         if (fill_to > fl) pf_load(pf, cs, sh, fl + lane, fill_to);
     }
-    const double *xall_ = cs.xall, *muall_ = cs.muall, *rs2all_ = cs.rs2all, *stall_ = cs.stall;
-    const int *ptall_ = cs.ptall;
-    const int nc_ = cs.n_chains, S_ = cs.S, nh = 3 * cs.E;
-    asm volatile("" : "+s"(xall_), "+s"(muall_), "+s"(rs2all_), "+s"(stall_), "+s"(ptall_));
+    const double *xall_ = cs.xall;
+    const PriorRec *prior_ = cs.prior;
+    const int nc_ = cs.n_chains, S_ = cs.S, nh = 3 * cs.E, psame_ = cs.prior_same;
+    asm volatile("" : "+s"(xall_), "+s"(prior_));
     // the decoded proposal (htm_stream.hpp), its Gaussian and its judge draw: looked up during the step before (FlowNext), or here
     int type, idx, evt, dec_w;
     double g, r_ring, logr_ring;
@@ -326,8 +326,9 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
     goffs = lane == 1 ? o_h : goffs; goffs = lane == 2 ? o_h + 1 : goffs; goffs = lane == 3 ? o_h + 2 : goffs;
     goffs = lane == 4 ? c : goffs; goffs = lane == 5 ? off_qs + c : goffs;
     const double gathered_v = xall_[goffs];
-    const double mu = ld_const(muall_ + o), rs2 = ld_const(rs2all_ + o), step = ld_const(stall_ + o);
-    const int ptype = ld_const(ptall_ + o);
+    const PriorRec prr = ld_prior(prior_ + (psame_ ? o - c * gnx : o));      // (one 32-byte scalar load: PriorRec)
+    const double mu = prr.mu, rs2 = prr.rs2, step = prr.step;
+    const int ptype = prr.ptype;
     const double *tc = xall_ + off_tc + c * S_, *ac = xall_ + off_ac + c * S_;
     StaRegs<(NCH > 0 ? NCH : 1)> st;
     ObsRegs<(NCH > 0 ? NCH : 1)> ob;
@@ -726,10 +727,11 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
             const int jgoff = jt == 1 ? 0 : jt == 2 ? nc_ : jt == 3 ? nc_ + nc_ * S_ : 2 * nc_ + nc_ * S_;
             const int jo = jgoff + c * ((jt == 1 || jt == 3) ? 1 : S_) + ji;
             const double jx_old = rg.mx[jo];                                  // LDS mirror, kept current by this wave's commits
-            const double jstep = rg.mir_steps ? rg.mstep[jo] : ld_const(cs.stall + jo);
+            const int jop = cs.prior_same ? jo - c * ((jt == 1 || jt == 3) ? 1 : S_) : jo;
+            const double jstep = rg.mir_steps ? rg.mstep[jo] : ld_const(&cs.prior[jop].step);
             const double jx_new = jx_old + rg.pg[pj & M] * jstep;             // cls_model.f90:172, as the step will compute it
             if (cs.rayleigh14) {                                              // a Rayleigh prior among vs/qs/corrections (:178-187)
-                if (ld_const(cs.ptall + jo) == 1 && jx_new <= ld_const(cs.muall + jo)) mode = 0;      // prior rejects: no evaluation
+                if (ld_const(&cs.prior[jop].ptype) == 1 && jx_new <= ld_const(&cs.prior[jop].mu)) mode = 0;      // prior rejects: no evaluation
             }
             // two ahead: the workers wait for this step's commit by reading its value back; the step in between must not
             // be able to overwrite that very element before they look

@@ -732,6 +732,23 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
             HIPCHK(hipMemcpy(sg.data(), d.sgall, total * sizeof(double), hipMemcpyDeviceToHost));
             for (size_t k = 0; k < total; ++k) r2[k] = 1.0 / (2.0 * sg[k] * sg[k]);
             if ((rc = dev_upload(hc->pool, &d.rs2all, r2.data(), total))) return cleanup(rc);
+            // the packed records the chain steps read (PriorRec), and whether every chain has chain 0's
+            std::vector<double> mu(total), stp(total);
+            std::vector<int32_t> pt(total);
+            HIPCHK(hipMemcpy(mu.data(), d.muall, total * sizeof(double), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(stp.data(), d.stall, total * sizeof(double), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(pt.data(), d.ptall, total * sizeof(int32_t), hipMemcpyDeviceToHost));
+            std::vector<PriorRec> pr(total);
+            for (size_t k = 0; k < total; ++k) { pr[k].mu = mu[k]; pr[k].rs2 = r2[k]; pr[k].step = stp[k]; pr[k].ptype = pt[k]; pr[k].pad = 0; }
+            bool same = true;
+            const size_t goffs[5] = {0, n, n + n * S, 2 * n + n * S, 2 * n + 2 * n * S}, gnx[5] = {1, S, 1, S, 3 * E};
+            for (int gi = 0; gi < 5 && same; ++gi)
+                for (size_t c = 1; c < n && same; ++c)
+                    same = memcmp(&pr[goffs[gi] + c * gnx[gi]], &pr[goffs[gi]], gnx[gi] * sizeof(PriorRec)) == 0;
+            if (const char *e = getenv("HTM_PRIOR_SAME")) { if (e[0] == '0') same = false; }      // (diagnostics: every chain reads its own records)
+            PriorRec *dp = nullptr;
+            if ((rc = dev_upload(hc->pool, &dp, pr.data(), total))) return cleanup(rc);
+            d.prior = dp; d.prior_same = same ? 1 : 0;
         }
         d.rayleigh14 = 0;
         auto any_rayleigh = [](const htm_model_init &m, size_t cnt) {

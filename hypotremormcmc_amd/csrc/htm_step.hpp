@@ -311,11 +311,11 @@ __device__ __forceinline__ int chain_pass(FwRef f_, CsRef cs_, StepShared &sh, c
     p = __builtin_amdgcn_readfirstlane(p);
     // the kernel arguments of the step's front, requested in ONE batch before the stream window is read (left to the
     // compiler they are loaded one dependent round trip after the other, next to their uses, behind the window's data)
-    const double *xall_ = cs.xall, *muall_ = cs.muall, *rs2all_ = cs.rs2all, *stall_ = cs.stall;
-    const int *ptall_ = cs.ptall;
-    const int nc_ = cs.n_chains, S_ = cs.S, nh = 3 * cs.E;
+    const double *xall_ = cs.xall;
+    const PriorRec *prior_ = cs.prior;
+    const int nc_ = cs.n_chains, S_ = cs.S, nh = 3 * cs.E, psame_ = cs.prior_same;
     const int4 dec = rg.dec[p & M];                 // decoded ahead of time (htm_stream.hpp)
-    asm volatile("" : "+s"(xall_), "+s"(muall_), "+s"(rs2all_), "+s"(stall_), "+s"(ptall_));
+    asm volatile("" : "+s"(xall_), "+s"(prior_));
     // wave-uniform by construction: keep them in scalar registers (addresses and selects become SALU work)
     const int type = __builtin_amdgcn_readfirstlane(dec.x), idx = __builtin_amdgcn_readfirstlane(dec.y);
     const int evt = __builtin_amdgcn_readfirstlane(dec.z), dec_w = __builtin_amdgcn_readfirstlane(dec.w);
@@ -334,8 +334,9 @@ __device__ __forceinline__ int chain_pass(FwRef f_, CsRef cs_, StepShared &sh, c
     goffs = lane == 1 ? o_h : goffs; goffs = lane == 2 ? o_h + 1 : goffs; goffs = lane == 3 ? o_h + 2 : goffs;
     goffs = lane == 4 ? c : goffs; goffs = lane == 5 ? off_qs + c : goffs;
     const double gathered_v = xall_[goffs];
-    const double mu = ld_const(muall_ + o), rs2 = ld_const(rs2all_ + o), step = ld_const(stall_ + o);
-    const int ptype = ld_const(ptall_ + o);
+    const PriorRec prr = ld_prior(prior_ + (psame_ ? o - c * gnx : o));      // (one 32-byte scalar load: PriorRec, htm_device.hpp)
+    const double mu = prr.mu, rs2 = prr.rs2, step = prr.step;
+    const int ptype = prr.ptype;
     const double *tc = xall_ + off_tc + c * S_, *ac = xall_ + off_ac + c * S_;
     StaRegs<(NCH > 0 ? NCH : 1)> st;
     ObsRegs<(NCH > 0 ? NCH : 1)> ob;

@@ -372,6 +372,44 @@ def test_rejection_heavy_runs_against_oracle(E, S, nc, seed, sz, n_iter):
     assert np.array_equal(a, oa) and np.array_equal(b, ob)
 
 
+@pytest.mark.parametrize("lockstep", [False, True])
+def test_shared_prior_records_equal_per_chain_records(lockstep, monkeypatch):
+    """Every chain of a rank has the same priors and step sizes (the reference's set-up, cls_model.f90 via one parameter file):
+    the chain steps then read chain 0's packed records (PriorRec, htm_device.hpp).  HTM_PRIOR_SAME=0 makes every chain read its
+    own: same decisions, same draws, same parameter values -- on a rejection-heavy job (Rayleigh rejections read the records on both paths of the orders too)."""
+    from hypotremormcmc_amd import synth
+    from oracle import oracle
+
+    data = synth.make_synthetic(64, 64, 103)
+    n_iter = 1500
+    params = dict(synth.DEFAULT_PARAMS, n_procs=1, n_chains=11, n_cool=2, n_iter=n_iter, n_burn=n_iter // 2,
+                  n_interval=3, step_size_z=12.0, step_size_vs=0.4)
+    from hypotremormcmc_amd.parallel import LocalWorld
+
+    out = []
+    for same in ("1", "0"):
+        monkeypatch.setenv("HTM_PRIOR_SAME", same)
+        _, sets = _build_world(data, params)
+        if lockstep:
+            LocalWorld(sets).run(n_iter)        # (the lock-step ranks' loop, one rank)
+        else:
+            sets[0].run(n_iter)
+        gi, gc, gl = sets[0].likelihood_trace()
+        out.append((gi.copy(), gl.copy(), sets[0].rng_state(), sets[0].counts(), [sets[0].state(c).hypo.copy() for c in range(11)]))
+    assert np.array_equal(out[0][0], out[1][0])
+    # (a full evaluation's sum is grouped by how its order went out -- one or two steps ahead, or late after an epoch change,
+    # which is a matter of timing: log-likelihoods agree to rounding, everything discrete and every parameter value exactly)
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-12, atol=0)
+    assert out[0][2] == out[1][2]
+    assert all(np.array_equal(a, b) for a, b in zip(out[0][3], out[1][3]))
+    assert all(np.array_equal(a, b) for a, b in zip(out[0][4], out[1][4]))
+    job = oracle.Job(params, data); job.run(n_iter)
+    it, lk = job.likelihood_trace(0)
+    assert np.array_equal(out[0][0], it)
+    np.testing.assert_allclose(out[0][1], lk, rtol=RTOL_TRACE)
+    assert out[0][2] == job.rng_state(0)
+
+
 @pytest.mark.parametrize("seed,n_iter", [(3, 4000), (4, 9000)])
 def test_workers_put_an_unsatisfiable_wait_aside(seed, n_iter, monkeypatch):
     """Second line of defence of the hand-off: with the chain waves' take-back of disproved orders switched off
