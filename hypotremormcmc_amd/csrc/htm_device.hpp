@@ -8,6 +8,7 @@
 // observation streams t_obs/t_prec/a_obs/a_prec are read with coalesced 512-B wave loads in the
 // reference's own (n_sta, n_events) column-major layout.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -276,40 +277,73 @@ struct StaRegs {
 // :201-204,:210-217,:294-296 (amplitude).  The per-event weighted means need one wave reduction per data
 // type and position; those are issued together.  All 64 lanes must call.
 // one event's observations for this lane's stations (the four coalesced HBM streams of the path)
-template <int NCH>
+// (fp32 forward: the float streams stay floats here -- half the registers of a worker's look-ahead buffers -- and are promoted,
+// exactly, where the evaluation reads them.  Promoting at the load made every pair of loads wait for itself (the conversion
+// needs the value): four waits of a memory round trip each in front of a chain step, 3.7 k cycles at 10 000 x 128.)
+template <int NCH, bool F32 = false>
 struct ObsRegs {
-    double tob[NCH], tpr[NCH], aob[NCH], apr[NCH];
+    typedef typename std::conditional<F32, float, double>::type T;
+    T tob[NCH], tpr[NCH], aob[NCH], apr[NCH];
     double rpst, rpsa;   // 1 / sum_j precision(j, event), time and amplitude
 };
 
-template <int NCH, bool F32 = false, class FW>
-__device__ __forceinline__ void load_obs_regs(ObsRegs<NCH> &ob, const FW &f, int ev, int lane)
+#ifndef HTM_VRPS_WORKERS
+#define HTM_VRPS_WORKERS 0   // measured: -6 % at 10 000 x 128 (vector loads of a uniform address cost more than the scalar-cache traffic they avoid)
+#endif
+#ifndef HTM_NT_WORKERS
+#define HTM_NT_WORKERS 0   // 1: the workers read the observation rows with the non-temporal hint -- measured: -3 % (fp64) ... -15 % at 10 000 events (profiles/r03_p_nt_loads.txt): the rows are re-read from the Infinity Cache by every evaluation, the hint keeps them out of it
+#endif
+// NT: the rows are read once per full evaluation by a worker that streams many events (worker_body): loaded with the
+// non-temporal hint they do not push the chain master's working set (chain state, priors, station table) out of its XCD's L2.
+template <class T, bool NT>
+__device__ __forceinline__ T ld_stream(const T *p)
+{
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+// VRPS: the event's two precision-sum reciprocals come with VECTOR loads (same address in every lane) instead of scalar ones:
+// a worker that streams many events would otherwise run 2 x E scalar loads per full evaluation through the scalar cache it
+// shares with neighbouring CUs -- the chain master's among them, whose kernel arguments and prior records live there.
+__device__ __forceinline__ int lane_zero()
+{
+    int z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    return z;
+}
+template <int NCH, bool F32 = false, bool NT = false, bool VRPS = false, class FW>
+__device__ __forceinline__ void load_obs_regs(ObsRegs<NCH, F32> &ob, const FW &f, int ev, int lane)
 {
     const size_t base = (size_t)ev * (size_t)f.S;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int j = lane + 64 * c;
         const bool valid = j < f.S;
-        ob.tob[c] = ob.tpr[c] = ob.aob[c] = ob.apr[c] = 0.0;
+        ob.tob[c] = ob.tpr[c] = ob.aob[c] = ob.apr[c] = 0;
         if (valid) {
-            if constexpr (F32) {   // the float streams, promoted (exactly) to the registers' fp64
-                if (f.use_time) { ob.tob[c] = (double)f.t_obs32[base + j]; ob.tpr[c] = (double)f.t_prec32[base + j]; }
-                if (f.use_amp)  { ob.aob[c] = (double)f.a_obs32[base + j]; ob.apr[c] = (double)f.a_prec32[base + j]; }
+            if constexpr (F32) {   // the float streams
+                if (f.use_time) { ob.tob[c] = ld_stream<float, NT>(f.t_obs32 + base + j); ob.tpr[c] = ld_stream<float, NT>(f.t_prec32 + base + j); }
+                if (f.use_amp)  { ob.aob[c] = ld_stream<float, NT>(f.a_obs32 + base + j); ob.apr[c] = ld_stream<float, NT>(f.a_prec32 + base + j); }
             } else {
-                if (f.use_time) { ob.tob[c] = f.t_obs[base + j]; ob.tpr[c] = f.t_prec[base + j]; }
-                if (f.use_amp)  { ob.aob[c] = f.a_obs[base + j]; ob.apr[c] = f.a_prec[base + j]; }
+                if (f.use_time) { ob.tob[c] = ld_stream<double, NT>(f.t_obs + base + j); ob.tpr[c] = ld_stream<double, NT>(f.t_prec + base + j); }
+                if (f.use_amp)  { ob.aob[c] = ld_stream<double, NT>(f.a_obs + base + j); ob.apr[c] = ld_stream<double, NT>(f.a_prec + base + j); }
             }
         }
     }
-    ob.rpst = f.use_time ? ld_const(f.rpsum_t + ev) : 1.0;    // wave-uniform: scalar loads
-    ob.rpsa = f.use_amp ? ld_const(f.rpsum_a + ev) : 1.0;
+    if constexpr (VRPS) {
+        const int vz = lane_zero();
+        ob.rpst = f.use_time ? f.rpsum_t[ev + vz] : 1.0;
+        ob.rpsa = f.use_amp ? f.rpsum_a[ev + vz] : 1.0;
+    } else {
+        ob.rpst = f.use_time ? ld_const(f.rpsum_t + ev) : 1.0;    // wave-uniform: scalar loads
+        ob.rpsa = f.use_amp ? ld_const(f.rpsum_a + ev) : 1.0;
+    }
 }
 
 // The same rows, requested without a branch: every lane issues all four loads (a lane without a station reads the row's last
 // entry and discards it; the arrays exist whatever use_time / use_amp say), so the number of loads per call is fixed and the
 // compiler can leave several calls' worth in flight (s_waitcnt vmcnt(N > 0)) -- the worker blocks' event pipeline.
-template <int NCH, bool F32 = false, class FW>
-__device__ __forceinline__ void load_obs_regs_nobranch(ObsRegs<NCH> &ob, const FW &f, int ev, int lane)
+template <int NCH, bool F32 = false, bool NT = false, bool VRPS = false, class FW>
+__device__ __forceinline__ void load_obs_regs_nobranch(ObsRegs<NCH, F32> &ob, const FW &f, int ev, int lane)
 {
     const size_t base = (size_t)ev * (size_t)f.S;
     const bool ut = f.use_time != 0, ua = f.use_amp != 0;
@@ -318,18 +352,29 @@ __device__ __forceinline__ void load_obs_regs_nobranch(ObsRegs<NCH> &ob, const F
         const int j = lane + 64 * c;
         const bool valid = j < f.S;
         const size_t k = base + (size_t)(valid ? j : f.S - 1);
-        double t, tp, a, ap;
-        if constexpr (F32) { t = (double)f.t_obs32[k]; tp = (double)f.t_prec32[k]; a = (double)f.a_obs32[k]; ap = (double)f.a_prec32[k]; }
-        else { t = f.t_obs[k]; tp = f.t_prec[k]; a = f.a_obs[k]; ap = f.a_prec[k]; }
-        ob.tob[c] = (valid && ut) ? t : 0.0; ob.tpr[c] = (valid && ut) ? tp : 0.0;
-        ob.aob[c] = (valid && ua) ? a : 0.0; ob.apr[c] = (valid && ua) ? ap : 0.0;
+        typename ObsRegs<NCH, F32>::T t, tp, a, ap;
+        if constexpr (F32) {
+            t = ld_stream<float, NT>(f.t_obs32 + k); tp = ld_stream<float, NT>(f.t_prec32 + k);
+            a = ld_stream<float, NT>(f.a_obs32 + k); ap = ld_stream<float, NT>(f.a_prec32 + k);
+        } else {
+            t = ld_stream<double, NT>(f.t_obs + k); tp = ld_stream<double, NT>(f.t_prec + k);
+            a = ld_stream<double, NT>(f.a_obs + k); ap = ld_stream<double, NT>(f.a_prec + k);
+        }
+        ob.tob[c] = (valid && ut) ? t : 0; ob.tpr[c] = (valid && ut) ? tp : 0;
+        ob.aob[c] = (valid && ua) ? a : 0; ob.apr[c] = (valid && ua) ? ap : 0;
     }
-    ob.rpst = ut ? ld_const(f.rpsum_t + ev) : 1.0;
-    ob.rpsa = ua ? ld_const(f.rpsum_a + ev) : 1.0;
+    if constexpr (VRPS) {
+        const int vz = lane_zero();
+        const double t = f.rpsum_t[ev + vz], a = f.rpsum_a[ev + vz];
+        ob.rpst = ut ? t : 1.0; ob.rpsa = ua ? a : 1.0;
+    } else {
+        ob.rpst = ut ? ld_const(f.rpsum_t + ev) : 1.0;
+        ob.rpsa = ua ? ld_const(f.rpsum_a + ev) : 1.0;
+    }
 }
 
 template <int NCH, int NPOS, bool F32 = false, class FW>
-__device__ __forceinline__ void event_misfit(const FW &f, const ObsRegs<NCH> &ob, int lane,
+__device__ __forceinline__ void event_misfit(const FW &f, const ObsRegs<NCH, F32> &ob, int lane,
                                              const StaRegs<NCH> &st, const double (&px)[NPOS],
                                              const double (&py)[NPOS], const double (&pz)[NPOS], double beta,
                                              double q, double (&out)[NPOS])
@@ -341,7 +386,9 @@ __device__ __forceinline__ void event_misfit(const FW &f, const ObsRegs<NCH> &ob
     // libm `log` difference and the summation order), a third of the step's fp64 instructions go away.
     const double qbeta = q * beta;
     const double rbeta = 1.0 / beta, katt = (kPi * kFreq) / qbeta;
-    const double (&tob)[NCH] = ob.tob, (&tpr)[NCH] = ob.tpr, (&aob)[NCH] = ob.aob, (&apr)[NCH] = ob.apr;
+    double tob[NCH], tpr[NCH], aob[NCH], apr[NCH];      // (promoted here in the fp32 mode: exact)
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) { tob[c] = (double)ob.tob[c]; tpr[c] = (double)ob.tpr[c]; aob[c] = (double)ob.aob[c]; apr[c] = (double)ob.apr[c]; }
     double ts[NPOS][NCH], as[NPOS][NCH];
     double red[2 * NPOS];
 #pragma unroll
@@ -422,7 +469,7 @@ __device__ __forceinline__ void event_misfit(const FW &f, const ObsRegs<NCH> &ob
 // one station per lane has no such parallelism of its own.  Same arithmetic per model as event_misfit<NCH, 1>.
 // PRE: `beta` and `q` hold 1 / vs and pi f / (qs vs) already (the caller formed them once for all events).
 template <int NCH, int NM, bool F32 = false, bool PRE = false, class FW>
-__device__ __forceinline__ void event_misfit_models(const FW &f, const ObsRegs<NCH> &ob, int lane, const StaRegs<NCH> &geo,
+__device__ __forceinline__ void event_misfit_models(const FW &f, const ObsRegs<NCH, F32> &ob, int lane, const StaRegs<NCH> &geo,
                                                     const double (&tcm)[NM][NCH], const double (&acm)[NM][NCH],
                                                     const double (&px)[NM], const double (&py)[NM], const double (&pz)[NM],
                                                     const double (&beta)[NM], const double (&q)[NM], double (&out)[NM])
@@ -433,7 +480,9 @@ __device__ __forceinline__ void event_misfit_models(const FW &f, const ObsRegs<N
         if constexpr (PRE) { rbeta[p] = beta[p]; katt[p] = q[p]; }
         else { const double qbeta = q[p] * beta[p]; rbeta[p] = 1.0 / beta[p]; katt[p] = (kPi * kFreq) / qbeta; }
     }
-    const double (&tob)[NCH] = ob.tob, (&tpr)[NCH] = ob.tpr, (&aob)[NCH] = ob.aob, (&apr)[NCH] = ob.apr;
+    double tob[NCH], tpr[NCH], aob[NCH], apr[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) { tob[c] = (double)ob.tob[c]; tpr[c] = (double)ob.tpr[c]; aob[c] = (double)ob.aob[c]; apr[c] = (double)ob.apr[c]; }
     double ts[NM][NCH], as[NM][NCH];
     double red[2 * NM];
 #pragma unroll

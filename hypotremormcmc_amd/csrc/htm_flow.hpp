@@ -331,7 +331,7 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
     const int ptype = prr.ptype;
     const double *tc = xall_ + off_tc + c * S_, *ac = xall_ + off_ac + c * S_;
     StaRegs<(NCH > 0 ? NCH : 1)> st;
-    ObsRegs<(NCH > 0 ? NCH : 1)> ob;
+    ObsRegs<(NCH > 0 ? NCH : 1), F32> ob;
     if (partial) {
         if constexpr (NCH > 0) {
             load_sta_regs<NCH>(st, f.S, lane, s_sx, s_sy, s_sz, tc, ac, 0, -1, 0.0);

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void k_full(FwdDev f, FullJob jb)
     // one event per wave (E <= 4 * event tiles): the wave's observation rows do not depend on the model -- load
     // them once and keep them in registers over all models of this block
     constexpr int NR = NCH > 0 ? NCH : 1;
-    ObsRegs<NR> ob_keep;
+    ObsRegs<NR, F32> ob_keep;
     const bool keep_obs = NCH > 0 && jb.epw == 1 && (int)(blockIdx.x * 4 + wave) < f.E;
     if constexpr (NCH > 0) {
         if (keep_obs) load_obs_regs<NCH, F32>(ob_keep, f, blockIdx.x * 4 + wave, lane);
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void k_full(FwdDev f, FullJob jb)
                     if (keep_obs) {
                         event_misfit<NCH, 1, F32>(f, ob_keep, lane, st, px, py, pz, beta, q, out);
                     } else {
-                        ObsRegs<NCH> ob;
+                        ObsRegs<NCH, F32> ob;
                         load_obs_regs<NCH, F32>(ob, f, ev, lane);
                         event_misfit<NCH, 1, F32>(f, ob, lane, st, px, py, pz, beta, q, out);
                     }
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(64) void k_partial_one(FwdDev f, int ev, const doub
     double out[2];
     if constexpr (NCH > 0) {        // the register path of the chain kernels (honours the fp32-forward mode)
         StaRegs<NCH> st;
-        ObsRegs<NCH> ob;
+        ObsRegs<NCH, F32> ob;
         load_sta_regs<NCH>(st, f.S, lane, f.sx, f.sy, f.sz, tc, ac, 0, -1, 0.0);
         load_obs_regs<NCH, F32>(ob, f, ev, lane);
         event_misfit<NCH, 2, F32>(f, ob, lane, st, px, py, pz, beta, q, out);

@@ -339,7 +339,7 @@ __device__ __forceinline__ int chain_pass(FwRef f_, CsRef cs_, StepShared &sh, c
     const int ptype = prr.ptype;
     const double *tc = xall_ + off_tc + c * S_, *ac = xall_ + off_ac + c * S_;
     StaRegs<(NCH > 0 ? NCH : 1)> st;
-    ObsRegs<(NCH > 0 ? NCH : 1)> ob;
+    ObsRegs<(NCH > 0 ? NCH : 1), F32> ob;
     if (partial) {
         if constexpr (NCH > 0) {
             load_sta_regs<NCH>(st, f.S, lane, s_sx, s_sy, s_sz, tc, ac, 0, -1, 0.0);
@@ -1452,7 +1452,7 @@ __device__ __forceinline__ void worker_body(FwRef f_, CsRef cs_, unsigned long l
 
     constexpr int N = NCH > 0 ? NCH : 1;
     StaRegs<N> st;
-    ObsRegs<N> ob0;
+    ObsRegs<N, F32> ob0;
     if constexpr (NCH > 0) {
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
@@ -1642,13 +1642,13 @@ __device__ __forceinline__ void worker_body(FwRef f_, CsRef cs_, unsigned long l
                     // event of look-ahead).  fp64: an event's arithmetic covers the next one's loads, the deeper form below
                     // measured -1 % at 1 000 and 10 000 events x 64 stations, and two stations per lane do not fit the 256
                     // registers of a wave with three buffers.
-                    ObsRegs<NCH> ob_cur = ob0, ob_nxt = ob0;
+                    ObsRegs<NCH, F32> ob_cur = ob0, ob_nxt = ob0;
                     double cx = 0.0, cy = 0.0, cz = 0.0, nx = 0.0, ny = 0.0, nz = 0.0;
                     if (ev0 < f.E) { cx = ld_agent(hyp + 3 * ev0); cy = ld_agent(hyp + 3 * ev0 + 1); cz = ld_agent(hyp + 3 * ev0 + 2); }
                     for (int ev = ev0; ev < f.E; ev += NWV * W) {
                         const int evn = ev + NWV * W;
                         if (evn < f.E) {
-                            load_obs_regs<NCH, F32>(ob_nxt, f, evn, lane);
+                            load_obs_regs<NCH, F32, HTM_NT_WORKERS != 0, HTM_VRPS_WORKERS != 0>(ob_nxt, f, evn, lane);
                             nx = ld_agent(hyp + 3 * evn); ny = ld_agent(hyp + 3 * evn + 1); nz = ld_agent(hyp + 3 * evn + 2);
                         }
                         const bool ov = ev == ov_evt;
@@ -1668,13 +1668,13 @@ __device__ __forceinline__ void worker_body(FwRef f_, CsRef cs_, unsigned long l
                     // events' loads fly under the arithmetic of a third: the fp32 forward's arithmetic is too short to cover an
                     // event's loads (configs[4] shape: 837 -> 902 k steps/s).  The last <= 4 events of a wave take the plain path.
                     const int s8 = NWV * W;
-                    ObsRegs<NCH> b0 = ob0, b1 = ob0, b2 = ob0;
+                    ObsRegs<NCH, F32> b0 = ob0, b1 = ob0, b2 = ob0;
                     double x0 = 0.0, y0 = 0.0, z0 = 0.0, x1 = 0.0, y1 = 0.0, z1 = 0.0, x2 = 0.0, y2 = 0.0, z2 = 0.0;
-                    auto fetch = [&](ObsRegs<NCH> &b, double &x, double &y, double &z, int e) __attribute__((always_inline)) {
-                        load_obs_regs_nobranch<NCH, F32>(b, f, e, lane);
+                    auto fetch = [&](ObsRegs<NCH, F32> &b, double &x, double &y, double &z, int e) __attribute__((always_inline)) {
+                        load_obs_regs_nobranch<NCH, F32, HTM_NT_WORKERS != 0, HTM_VRPS_WORKERS != 0>(b, f, e, lane);
                         x = ld_agent(hyp + 3 * e); y = ld_agent(hyp + 3 * e + 1); z = ld_agent(hyp + 3 * e + 2);
                     };
-                    auto eval = [&](const ObsRegs<NCH> &b, double x, double y, double z, int e) __attribute__((always_inline)) {
+                    auto eval = [&](const ObsRegs<NCH, F32> &b, double x, double y, double z, int e) __attribute__((always_inline)) {
                         const bool ov = e == ov_evt;
                         const double px[1] = {(ov && ov_cmp == 0) ? ov_val : x};
                         const double py[1] = {(ov && ov_cmp == 1) ? ov_val : y};
