@@ -98,6 +98,16 @@ struct FlowNext {
     int b3;                       // base of iteration it + 2 (what the wave's B2 becomes when it moves on); -1: not known
 };
 
+// What a step reads from LDS before its loads go out, requested in ONE batch at the top of the loop (they used to be five
+// dependent round trips -- epoch, end of launch, the other wave's progress, the chain's order book, its log-likelihood -- each
+// behind a branch on the one before; LDS operations return in order, the first use waits for all of them once).
+struct FlowTop {
+    int epoch, last_iter, err, pk;
+    int book_pos, book_mode, book_mid;
+    unsigned book_tag;
+    double L;
+};
+
 constexpr int kFlowRestart = -1;  // flow_step: the step's position was disproved before its turn came: run it again
 constexpr int kFlowAbort = -2;    // flow_step: a wait gave up (sh.c.err is set)
 constexpr int kFlowStop = -3;     // flow_step (lock-step rank): the job stops after the iteration before: this step is not taken
@@ -274,7 +284,7 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
                                          double *s_gath, int wmax,
                                          const double *s_sx, const double *s_sy, const double *s_sz, int c, int p, int iter,
                                          int lane, int wave, int NW, unsigned long long launch, bool ext, int look, int back,
-                                         bool rec_now)
+                                         bool rec_now, const FlowTop &tp)
 {
     CsRef cs = rebase(cs_);
     FwRef f = rebase(f_);
@@ -339,8 +349,8 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
         }
     }
     // the book of this chain: is this step's order out already, and how
-    const int book_pos = sh.ob_pos[c], book_mode = sh.ob_mode[c], book_mid = sh.ob_mid[c];
-    const unsigned book_tag = sh.ob_tag[c];
+    const int book_pos = tp.book_pos, book_mode = tp.book_mode, book_mid = tp.book_mid;
+    const unsigned book_tag = tp.book_tag;
     const bool pre = !partial && book_pos == p;
     const int pre_mode = pre ? book_mode : 0;
     // a full-evaluation step whose order went out two steps ahead adds the event of the step in between itself (below):
@@ -362,7 +372,7 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
     const double x_old = rl_f64(gathered_v, 0);
     const double hx = rl_f64(gathered_v, 1), hy = rl_f64(gathered_v, 2), hz = rl_f64(gathered_v, 3);
     const double beta = rl_f64(gathered_v, 4), q = rl_f64(gathered_v, 5);
-    const double L_cur = sh.L[c];
+    const double L_cur = tp.L;
     const double x_new = x_old + g * step;                      // cls_model.f90:172
     const double da = x_new - mu, db = x_old - mu;
     double lpr = -(da * da - db * db) * rs2;                    // :175-177 (rs2 = 1 / (2 sigma^2), formed once on the host)
@@ -867,15 +877,25 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
 #endif
     while (alive) {
         // ---- top of a step: the epoch its position is predicted in
+        FlowTop tp;
         {
-            const int e = lds_ld(&sh.epoch);
+            const int co = (HTM_FAIR && !LOCK && (c ^ 4) < nc) ? (c ^ 4) : c;
+            tp.epoch = lds_ld(&sh.epoch); tp.last_iter = lds_ld(&sh.last_iter); tp.err = lds_ld(&sh.c.err);
+            tp.pk = (int)(unsigned)lds_ld(&sh.prog[co]);
+            tp.book_pos = sh.ob_pos[c]; tp.book_mode = sh.ob_mode[c]; tp.book_mid = sh.ob_mid[c]; tp.book_tag = sh.ob_tag[c];
+            tp.L = sh.L[c];
+            asm volatile("" ::: "memory");
+        }
+        {
+            const int e = tp.epoch;
             if (__builtin_expect(e != W.epoch, 0)) {
                 bool stands = false;
                 if (!flow_adopt(cs, sh, rg, W, e, iter, c, false, stands)) continue;
                 flow_void_books(cs, sh, wave, NW, nc, lane);
+                continue;      // (the book read above is void with it: from the top)
             }
         }
-        if (iter > lds_ld(&sh.last_iter) || sh.c.err != 0) {
+        if (iter > tp.last_iter || tp.err != 0) {
             // (a lock-step rank leaves only when the swap of its last iteration has been applied)
             if constexpr (LOCK) { if (sh.c.err == 0) flow_settle(cs, sh, rg, s_gath, iter - 1, lane); }
             break;
@@ -912,12 +932,12 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
         // other wave (a step or more, by the checks published) asks for priority; the one ahead gives it up.
         // (Not between lock-step ranks: there the hand-over costs 2-3 %, profiles/r03_n_fair.txt.)
         if (HTM_FAIR && !LOCK && (c ^ 4) < nc) {      // (chain c ^ 4 is the corresponding chain of the SIMD's other wave, whatever the number of chains per wave)
-            const int pk = (int)(unsigned)sh.prog[c ^ 4];
+            const int pk = tp.pk;
             if (pk >= (iter - i0) * nc + (c ^ 4)) __builtin_amdgcn_s_setprio(1);
             else __builtin_amdgcn_s_setprio(0);
         }
         const int r = flow_step<NCH, F32, LOCK>(f, cs, sh, rg, W, nx, s_gath, wmax, s_sx, s_sy, s_sz, c, p, iter, lane, wave, NW, launch, wave == 0,
-                                          look, back, rec_phase == 1);
+                                          look, back, rec_phase == 1, tp);
         if (r == kFlowRestart) continue;
         if (r == kFlowAbort || r == kFlowStop) break;
         // ---- this wave's next step
