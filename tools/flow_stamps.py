@@ -21,7 +21,13 @@ data = synth.make_synthetic(E_, S_, 1)
 params = dict(synth.DEFAULT_PARAMS, n_procs=1, n_chains=nc, n_cool=1, n_iter=10**7, n_burn=10**9, n_interval=1000)
 obs = ObsData.from_arrays(data.sta_x, data.sta_y, data.t_obs, data.t_stdv, data.a_obs, data.a_stdv)
 fwd, cs = driver.build_rank(params, data.sta_x, data.sta_y, data.sta_z, obs, 0, n_procs=1)
-cs.run(2000 if E_ <= 1000 else 300)
+if os.environ.get("HTM_STAMPS_LOCK") == "1":        # the lock-step ranks' loop (k_mcmc<.., 4>), one rank
+    from hypotremormcmc_amd.parallel import LocalWorld
+    _w = LocalWorld([cs])
+    _run = _w.run
+else:
+    _run = cs.run
+_run(2000 if E_ <= 1000 else 300)
 lib = _lib.load()
 lib.htm_chains_read_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
 a = (C.c_uint64 * 128)()
@@ -29,7 +35,7 @@ lib.htm_chains_read_stamps(cs.handle, a)
 base = list(a)
 n = 20000 if E_ <= 1000 else 2000
 t0 = time.perf_counter()
-cs.run(n)
+_run(n)
 print("wall us/iteration %.3f (stamps build)" % (1e6 * (time.perf_counter() - t0) / n))
 lib.htm_chains_read_stamps(cs.handle, a)
 d = [a[k] - base[k] for k in range(128)]
