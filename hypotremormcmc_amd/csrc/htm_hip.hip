@@ -181,6 +181,7 @@ struct htm_chains {
     unsigned long long *d_inbox = nullptr;
     size_t inbox_bytes = 0;
     std::vector<void *> peer_maps;             // hipIpcOpenMemHandle mappings to close
+    unsigned probe_calls = 0;                  // htm_chains_xchg_probe calls so far (part of the probe's tokens)
     unsigned long long **d_outbox = nullptr;
     bool xchg_ready = false;
     u32x4 *d_jump = nullptr;                   // [kJumpLevels][128] columns of T^(64 * 2^b) (k_rawgen)
@@ -1492,7 +1493,10 @@ int htm_chains_xchg_probe(htm_chains *hc, unsigned token, double seconds)
     if (rc) return rc;
     HIPCHK(hipMemset(d_res, 0, sizeof(int)));
     const unsigned long long ticks = (unsigned long long)(std::max(0.01, std::min(seconds, 60.0)) * 1e8);
-    hipLaunchKernelGGL(k_xchg_probe, dim3(1), dim3(64), 0, hc->fwd->stream, hc->dev, token & 0x7fffffffu, ticks, d_res);
+    // (the probe is collective: every rank has made the same number of calls, so the count makes a repeated probe's tokens
+    // new ones whatever token the callers pass -- a second probe must not pass on what the first one left in the inboxes)
+    const unsigned eff = (token + 0x10000u * ++hc->probe_calls) & 0x7fffffffu;
+    hipLaunchKernelGGL(k_xchg_probe, dim3(1), dim3(64), 0, hc->fwd->stream, hc->dev, eff, ticks, d_res);
     HIPCHK(hipGetLastError());
     int res = 0;
     HIPCHK(hipMemcpyAsync(&res, d_res, sizeof(int), hipMemcpyDeviceToHost, hc->fwd->stream));

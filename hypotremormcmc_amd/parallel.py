@@ -156,7 +156,7 @@ class TorchWorld:
         # every rank mapped every peer: prove that writes into the inboxes reach a polling kernel (all ranks probe together)
         dist.barrier(group=self.group)
         try:
-            cs.xchg_probe(token=1, seconds=10.0)       # (a later probe of the same set must use another token)
+            cs.xchg_probe(token=1, seconds=10.0)       # (the library adds the set's probe count to the token)
         except Exception:
             ok = 0
         flag = torch.tensor([ok], dtype=torch.int32, device=dev)

@@ -192,7 +192,8 @@ int htm_chains_step_end_host(htm_chains *hc, const double *gathered_records);
  *                 torch.distributed's all-gather over RCCL), `handle_bytes` apart, and maps the peers' inboxes
  *                 (n_procs == 1: handles may be NULL);
  *   xchg_probe    (optional, collective) a one-wave kernel writes a token into every rank's inbox and waits up to
- *                 `seconds` for all ranks' tokens in its own: proves at set-up that peer writes reach a polling kernel;
+ *                 `seconds` for all ranks' tokens in its own: proves at set-up that peer writes reach a polling kernel
+ *                 (the call count of the set is part of the token: a repeated probe never passes on an earlier one's tokens);
  *   run_lockstep_direct  n_iter lock-step iterations; synchronous; every rank must call it with the same n_iter.
  * The transport-agnostic step_begin / step_end protocol above stays available (and is what a rank falls back to
  * when peer mapping is refused). */
