@@ -1,0 +1,25 @@
+"""CPU: the synchronisation protocol of the free-running chain master (csrc/htm_flow.hpp) as a model -- tools/flow_protocol_sim.py
+runs its rules (prog / done / epoch / anchor, the turn rule, re-prediction from the anchor) as coroutines under a random
+scheduler and compares every step's start position, the final states, temperatures and stream position with the serial loop of
+the reference (src/hypo_tremor_mcmc.f90:236-284; draws per step as src/cls_mcmc.f90:193, the swap as src/cls_parallel.f90:121-136).
+A change of the protocol is tried here before it goes to the GPU."""
+import importlib.util
+import os
+
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _sim():
+    spec = importlib.util.spec_from_file_location("flow_protocol_sim", os.path.join(ROOT, "tools", "flow_protocol_sim.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("first", [1, 151, 301, 451])
+def test_free_running_protocol_equals_the_serial_loop(first):
+    sim = _sim()
+    for seed in range(first, first + 150):
+        assert sim.run_case(seed), "seed %d differs from the serial loop" % seed
