@@ -168,6 +168,7 @@ struct htm_chains {
     unsigned long long launch_seq = 0;         // k_mcmc launches of this chain set so far (the kernels' launch index)
     bool persist = true;                       // k_mcmc (master + resident full-evaluation workers) vs k_step + k_full
     bool flow = false;                         // single-rank loop on the free-running master (htm_flow.hpp) instead of step_body
+    int worker_cap = 250;                      // most worker blocks a launch takes (HTM_WORKER_CAP)
     bool split = false;                        // worker blocks as a k_workers launch of their own (12 waves per block) beside the master's
     long blocks_fit = 0, wide_blocks_fit = 0;  // resident blocks of a k_mcmc / k_mcmc_wide launch on this device (htm_chains_share_gpu)
     bool flow_lock = false;                    // lock-step ranks (MODE_LOCKRUN) on the free-running master too
@@ -677,6 +678,16 @@ int htm_forward_time_full_batch_dev(htm_forward *h, int n_models, const double *
 // ---------------------------------------------------------------------------------------------------
 // chains
 // ---------------------------------------------------------------------------------------------------
+// Worker blocks of a persistent launch: as many as fit (one per CU next to the master's), at most one per `waves_per_block` events.
+// A full evaluation takes as long as its busiest wave, which evaluates ceil(E / (waves per block x blocks)) events: at 10 000
+// events and 8 waves per block 250 blocks give five rounds where 240 gave six (+8 % at 10 000 x 128 x 16 fp32, +6 % at 10 000 x 64 x 8).
+// (Taking the SMALLEST block count that reaches the same number of rounds was measured too: -1 % -- the waves with a round less
+// leave the memory system to the others sooner.)
+static int worker_blocks(int E, int waves_per_block, long cap)
+{
+    return (int)std::max<long>(1, std::min<long>(std::max<long>(1, cap), (E + waves_per_block - 1) / waves_per_block));
+}
+
 // one group of the rank's parameter vector: a window [off, off + nx*nc) of the five per-field allocations
 static int upload_model(htm_chains *hc, ModelDev &m, const htm_model_init &in, int nx, int nc, size_t off, const char *name)
 {
@@ -775,7 +786,10 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
     if ((rc = dev_alloc(hc->pool, &d.prop, nc))) return cleanup(rc);
     if ((rc = dev_alloc(hc->pool, &d.desc, 1))) return cleanup(rc);
     HIPCHK(hipMemset(d.desc, 0, sizeof(FullDesc)));
-    d.n_workers = std::max(1, std::min(240, (h->E + 7) / 8));
+    int worker_cap = 250;          // of 256 CUs: the master's, and a few to spare
+    if (const char *e = getenv("HTM_WORKER_CAP")) worker_cap = std::max(1, std::min(255, atoi(e)));      // (tuning)
+    hc->worker_cap = worker_cap;
+    d.n_workers = worker_blocks(h->E, 8, worker_cap);
     if (const char *e = getenv("HTM_MAX_WORKERS")) d.n_workers = std::max(1, std::min(d.n_workers, atoi(e)));   // GPUs shared between ranks
     if ((rc = dev_alloc(hc->pool, &d.partial, (size_t)nc * std::max(h->n_wg, 256)))) return cleanup(rc);      // (<= 256 workers whatever the launch shape)
     if ((rc = dev_alloc(hc->pool, &d.ps, 1))) return cleanup(rc);
@@ -961,7 +975,7 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
         if (const char *e = getenv("HTM_RANKS_PER_GPU")) { const int k = atoi(e); if (k > 1) room = (long)per_cu * n_cu / k - 1; }
         if (hc->split) { }                      // (sized above)
         else if (room < 1) hc->persist = false;      // not even one worker fits next to the master: two-kernel path
-        else hc->dev.n_workers = (int)std::min<long>(hc->dev.n_workers, room);
+        else if (hc->dev.n_workers > room) hc->dev.n_workers = worker_blocks(h->E, 8, room);
     }
     hc->dev.n_wg = hc->dev.n_workers;           // persistent kernel: one partial per worker block
     {
@@ -993,7 +1007,7 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
             if (wroom >= 1) {
                 hc->wide = true;
                 hc->n_workers8 = hc->dev.n_workers;
-                int nw = (int)std::max<long>(1, std::min<long>(std::min<long>(255, wroom), (h->E + 11) / 12));
+                int nw = worker_blocks(h->E, 12, std::min<long>(hc->worker_cap, wroom));
                 if (const char *e3 = getenv("HTM_MAX_WORKERS")) nw = std::max(1, std::min(nw, atoi(e3)));
                 hc->dev.n_workers = nw; hc->dev.n_wg = nw;
             }
@@ -1868,8 +1882,8 @@ int htm_chains_share_gpu(htm_chains *hc, int ranks_on_this_gpu)
     const long fit = hc->wide ? hc->wide_blocks_fit : hc->blocks_fit;
     const long room = fit / ranks_on_this_gpu - 1;
     if (room < 1) return fail(HTM_ESTATE, "%d ranks on one GPU: not even one worker block per rank fits next to the masters", ranks_on_this_gpu);
-    hc->dev.n_workers = (int)std::min<long>(hc->dev.n_workers, room);
-    if (hc->wide) hc->n_workers8 = (int)std::min<long>(hc->n_workers8, hc->blocks_fit / ranks_on_this_gpu - 1);
+    if (hc->dev.n_workers > room) hc->dev.n_workers = worker_blocks(hc->fwd->E, hc->wide ? 12 : 8, room);
+    if (hc->wide && hc->n_workers8 > hc->blocks_fit / ranks_on_this_gpu - 1) hc->n_workers8 = worker_blocks(hc->fwd->E, 8, hc->blocks_fit / ranks_on_this_gpu - 1);
     hc->dev.n_wg = hc->dev.n_workers;
     return HTM_OK;
 }

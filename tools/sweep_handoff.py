@@ -1,4 +1,5 @@
-"""Sweep the hand-off geometry knobs of k_mcmc (run on the GPU box): prints steps/s per configuration."""
+"""Sweep the hand-off geometry knobs of k_mcmc (run on the GPU box): prints steps/s per configuration.
+    python tools/sweep_handoff.py [replicas,slot_stride,pgran_stride,npoll ...]      (SWEEP_BENCH_ARGS: the shape)"""
 import itertools
 import json
 import os
@@ -18,8 +19,11 @@ if len(sys.argv) > 1:
                for a in sys.argv[1:]]
 for cfg in configs:
     env = dict(os.environ, **{k: str(v) for k, v in cfg.items()})
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--steps", "12000",
-                          "--warmup", "2000"], env=env, capture_output=True, text=True)
+    # (a bench step is a block of iterations: a few short blocks per configuration; SWEEP_BENCH_ARGS picks the shape, e.g.
+    # "--events 10000 --stations 128 --chains 16 --forward-precision fp32 --iters-per-step 1024")
+    extra = os.environ.get("SWEEP_BENCH_ARGS", "--iters-per-step 16384").split()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--steps", "4",
+                          "--warmup", "1"] + extra, env=env, capture_output=True, text=True)
     try:
         v = json.loads(out.stdout.strip().splitlines()[-1])["value"]
     except Exception:
