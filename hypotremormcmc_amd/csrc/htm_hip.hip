@@ -989,12 +989,12 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
                                hc->ring_size >= 4 * wd + 32 + 2 * c_max + 16;
         hc->flow = window_ok && d.n_procs == 1;
         hc->flow_lock = window_ok && !(getenv("HTM_FLOW_LOCK") && getenv("HTM_FLOW_LOCK")[0] == '0');      // (MODE_LOCKRUN: any number of ranks)
-        // blocks of 12 waves where one worker wave evaluates several events per order (HTM_WIDE=0 / 1 overrides the choice by size)
+        // blocks of 12 waves (HTM_WIDE=1): opt-in.  Measured at 10 000 x 128 x 16 chains with 240 worker blocks: fp64 856 -> 902 k
+        // steps/s (four rounds of events per worker wave instead of six), the fp32 workers spill at 168 registers and lose a
+        // quarter, one station per lane gains nothing (profiles/r03_j_wide.txt).  With 250 blocks the 8-wave launch needs five
+        // rounds and is the faster one in fp64 too: 980 k against 949 k (profiles/r03_t_worker_blocks.txt).
         const char *ew = getenv("HTM_WIDE");
-        const bool by_size = (h->E + 7) / 8 > 240;
-        // (measured at 10 000 x 128 x 16 chains: fp64 856 -> 902 k steps/s; the fp32 workers with their three register
-        // buffers spill 56 registers at 168 and lose a quarter; one station per lane gains nothing: profiles/r03_j_wide.txt)
-        if (hc->flow && !hc->split && (h->nch == 1 || h->nch == 2) && (ew ? atoi(ew) != 0 : (by_size && h->nch == 2 && !h->dev.fp32))) {
+        if (hc->flow && !hc->split && (h->nch == 1 || h->nch == 2) && ew && atoi(ew) != 0) {
             const void *wfn = h->dev.fp32 ? (h->nch == 1 ? (const void *)k_mcmc_wide<1, true> : (const void *)k_mcmc_wide<2, true>)
                               : (h->nch == 1 ? (const void *)k_mcmc_wide<1, false> : (const void *)k_mcmc_wide<2, false>);
             int wpc = 0, n_cu = 0;
