@@ -52,3 +52,8 @@ for w in range(min(8, nc)):
     print("%-4d %8d " % (w, b[7]) + " ".join("%9.0f" % x for x in ph) + " %9.0f | %7d %9.0f %9.0f | %9.0f %9.0f" %
           (sum(ph), b[8], b[6] / nj, b[10] / nj, b[11] / max(1.0, iters), (b[11] - inside) / max(1, steps)))
 
+# worker block 0, thread 0 (100 MHz ticks summed over its jobs): order seen -> its events evaluated -> block sum stored
+jobs_all = sum(d[32 + 12 * w + 8] for w in range(min(8, nc)))
+if jobs_all:
+    print("worker block 0 per order: evaluation of its events %.2f us, block sum + store %.2f us  (%d orders)" %
+          ((d[22] - d[21]) / jobs_all / 100.0, (d[23] - d[22]) / jobs_all / 100.0, jobs_all))
