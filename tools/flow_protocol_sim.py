@@ -11,6 +11,11 @@ This script runs those rules as coroutines (one per wave) under a random schedul
 shared-memory accesses, with state-dependent rejections, swaps and a stop request, and compares everything -- the
 position every step started at, final chain states, temperatures, final stream position -- with the serial loop.
 
+The second half models the LOCK-STEP ranks (k_mcmc<.., 4>): several ranks with their own streams, the rank's last committer
+posting its swap record into every inbox, the first wave that needs the outcome collecting the records, the bet of ranks != 0
+that the judge draw is not theirs (lost: the next iteration is anchored one position later under a new epoch), a stop request
+travelling with the records -- against the serial ranks of cls_parallel.f90:121-213.
+
     python tools/flow_protocol_sim.py [n_cases]          # exits non-zero on the first difference
 """
 import random
@@ -305,6 +310,332 @@ def run_case(seed, verbose=False):
     return ok
 
 
+
+# ======================================================================================================================
+# Lock-step ranks (k_mcmc<.., 4>: flow_post_record / flow_settle / flow_collect_records of csrc/htm_flow.hpp).  R ranks, each
+# with its own stream and nc chains; the pair of an iteration's swap is drawn by rank 0 from ITS stream (select_pair), the
+# judge draw by the rank of the pair's first chain from its own (cls_parallel.f90:121-213).  Every rank's last committer of an
+# iteration posts the rank's record into all inboxes; the first wave that needs the outcome collects the R records, applies
+# the swap, re-anchors the next iteration if the judge draw turned out to be this rank's (ranks != 0 bet that it is not),
+# spreads a stop request, and publishes xdone.
+# ======================================================================================================================
+class LockStream(Stream):
+    def __init__(self, seed, nc, p_rej, rank, R):
+        super().__init__(seed * 131 + rank, nc, p_rej)
+        self.rank, self.R = rank, R
+
+    def pair(self, p):                   # select_pair at p on rank 0's stream: (i1, i2, draws of the pair)
+        n_all = self.R * self.nc
+        if n_all < 2:
+            return -1, -1, 0
+        i1 = h32(self.seed, 3, p) % n_all
+        i2 = (i1 + 1 + h32(self.seed, 4, p) % (n_all - 1)) % n_all
+        return i1, i2, 2 + h32(self.seed, 5, p) % 3
+
+    def u(self, p):                      # the uniform draw at position p (judge_swap's number when it is taken there)
+        return h32(self.seed, 9, p)
+
+    def nd_pred(self, p):                # what THIS rank predicts the swap at p to draw from its stream (flow_swap_at's lock rule)
+        if self.R * self.nc < 2 or self.rank != 0:
+            return 0
+        i1, i2, z = self.pair(p)
+        return z + (1 if i1 // self.nc == 0 else 0)
+
+    def next_from(self, p, n):
+        e = self.hop(p, n)
+        return e, e + self.nd_pred(e)
+
+
+def swap_outcome_lock(u, L1, L2, T1, T2):
+    return h32(u, L1, L2, T1, T2) % 100 < 30
+
+
+def serial_lock(sts, nc, R, n_iter, x0, L0, T0):
+    x = [list(v) for v in x0]; L = [list(v) for v in L0]; T = [list(v) for v in T0]
+    p = [0] * R
+    trace = {}
+    for i in range(1, n_iter + 1):
+        for r in range(R):
+            for c in range(nc):
+                trace[(r, i, c)] = p[r]
+                ok, cnt, acc, x[r][c], L[r][c] = step_outcome(sts[r], p[r], x[r][c], L[r][c], T[r][c])
+                p[r] += cnt
+        if R * nc > 1:
+            i1, i2, z = sts[0].pair(p[0])
+            p[0] += z
+            r1, c1, r2, c2 = i1 // nc, i1 % nc, i2 // nc, i2 % nc
+            u = sts[r1].u(p[r1]); p[r1] += 1
+            if swap_outcome_lock(u, L[r1][c1], L[r2][c2], T[r1][c1], T[r2][c2]):
+                T[r1][c1], T[r2][c2] = T[r2][c2], T[r1][c1]
+    return x, L, T, p, trace
+
+
+def wave_lock(sh, st, net, w, NW, nc, R, rank, i0, rnd, trace):
+    """one chain wave of a lock-step rank; `net` = the inboxes of all ranks"""
+    key = lambda i, c: (i - i0) * nc + c
+    nextB = lambda pos, n: st.next_from(pos, n)[1]
+    my_epoch, my_akey = 0, 0
+    i = i0 + 1
+    rc, rpos = 0, 0
+    rc1, rpos1 = 0, nextB(0, nc)
+    B2 = nextB(rpos1, nc)
+    chains = list(range(w, nc, NW))
+    if not chains:
+        return
+    ci = 0
+
+    def from_anchor(a_key, a_pos):
+        ia, ca = i0 + a_key // nc, a_key % nc
+        return (ia, 0, a_pos + st.nd_pred(a_pos)) if ca == 0 else (ia, ca, a_pos)
+
+    def adopt(e, a_key, a_pos, it, c, in_turn):
+        """flow_adopt: returns `stands`"""
+        nonlocal my_epoch, my_akey, rc, rpos, rc1, rpos1, B2
+        stands = in_turn and key(it, c) < a_key
+        my_epoch, my_akey = e, a_key
+        ia, ca, ap = from_anchor(a_key, a_pos)
+        if not stands:
+            if ia == it:
+                rc, rpos = ca, ap
+            else:
+                assert ia == it - 1 and ca > 0, (ia, ca, it)
+                rc, rpos = 0, nextB(ap, nc - ca)
+            rc1, rpos1 = 0, nextB(rpos, nc - rc)
+            B2 = nextB(rpos1, nc)
+        elif ia == it:
+            rc, rpos = ca, ap
+            rc1, rpos1 = 0, nextB(ap, nc - ca)
+            B2 = nextB(rpos1, nc)
+        else:
+            rc1, rpos1 = ca, ap
+            B2 = nextB(ap, nc - ca)
+        return stands
+
+    def read_anchor():
+        """generator: (e, a_key, a_pos) read consistently"""
+        e = sh.epoch; yield
+        while True:
+            a_key, a_pos = sh.anchor[e & 1]; yield
+            e2 = sh.epoch; yield
+            if e2 == e:
+                return e, a_key, a_pos
+            e = e2
+
+    def collect(j):
+        """flow_collect_records(j): this wave has claimed iteration j's records"""
+        E = sh.Eof[j & 3]; yield
+        nd = st.nd_pred(E)
+        while True:                                   # exchange_finish: all R records of iteration j
+            box = dict(net[rank][j & 1]); yield
+            if all(box.get(q, (None,))[0] == j for q in range(R)):
+                break
+        recs = [box[q][1] for q in range(R)]
+        stop_any = any(rc_["stop"] for rc_ in recs)
+        i1, i2 = recs[0]["i1"], recs[0]["i2"]
+        if R * nc > 1:
+            r1, c1, r2, c2 = i1 // nc, i1 % nc, i2 // nc, i2 % nc
+            u = recs[r1]["u"]
+            if swap_outcome_lock(u, recs[r1]["L"][c1], recs[r2]["L"][c2], recs[r1]["T"][c1], recs[r2]["T"][c2]):
+                if rank == r1: sh.temp[c1] = recs[r2]["T"][c2]
+                if rank == r2: sh.temp[c2] = recs[r1]["T"][c1]
+            if rank == r1:
+                sh.spos += 1                           # the judge draw was this rank's
+        yield
+        base = sh.spos
+        if base != E + nd:
+            e1 = sh.epoch + 1
+            sh.anchor[e1 & 1] = (key(j + 1, 0), base - nd); yield
+            sh.epoch = e1; yield
+        if stop_any:
+            sh.last_iter = min(sh.last_iter, j); yield
+        sh.iter_done = j
+        sh.xdone = j; yield
+
+    def settle(j):
+        """flow_settle(j)"""
+        if j <= i0:
+            return
+        xd = sh.xdone; yield
+        if xd >= j:
+            return
+        mine = False
+        if sh.xclaim == j - 1:                        # (atomic compare-and-swap)
+            sh.xclaim = j; mine = True
+        yield
+        if mine:
+            yield from collect(j)
+            return
+        while True:
+            xd = sh.xdone; yield
+            if xd >= j:
+                return
+
+    def post(j):
+        """flow_post_record(j): the rank's last committer of iteration j"""
+        E = sh.Eof[j & 3]; yield
+        i1, i2, z = st.pair(E) if rank == 0 else (-1, -1, 0)
+        nd = st.nd_pred(E)
+        own = 1 if (rank == 0 and i1 >= 0 and i1 // nc == 0) else 0
+        jp = E + nd - own
+        rec = {"i1": i1, "i2": i2, "u": st.u(jp), "T": list(sh.temp), "L": list(sh.L),
+               "stop": sh.stop_at == j}
+        sh.spos = jp
+        sh.xcount[(j + 1) & 3] = 0; yield
+        order = list(range(R)); rnd.shuffle(order)
+        for q in order:                               # peer writes land one rank after the other
+            net[q][j & 1][rank] = (j, rec); yield
+
+    while True:
+        c = chains[ci]
+        e = sh.epoch; yield
+        if e != my_epoch:
+            e, a_key, a_pos = yield from read_anchor()
+            assert key(i, c) >= a_key, (i, c, a_key)
+            adopt(e, a_key, a_pos, i, c, False)
+        last = sh.last_iter; yield
+        if i > last:
+            yield from settle(i - 1)                  # (a rank leaves only when the swap of its last iteration is applied)
+            break
+        assert c >= rc
+        P = st.hop(rpos, c - rc)
+        for _ in range(rnd.randint(0, 3)):
+            yield
+        x, L = sh.x[c], sh.L[c]
+        ok_pre = not (st.rayleigh(P) and h32(st.seed, 6, P, x) % 1000 < int(1000 * st.p_rej))
+        cnt_pre = st.w(P) - (0 if ok_pre else 1)
+        if c == nc - 1:
+            sh.Eof[i & 3] = P + cnt_pre; yield
+        sh.prog[c] = (my_epoch, key(i, c), 0 if ok_pre else 1); yield
+        for _ in range(rnd.randint(0, 6)):
+            yield
+        restart = stop = False
+        while True:
+            pr = list(sh.prog); yield
+            e = sh.epoch; yield
+            if e != my_epoch:
+                e, a_key, a_pos = yield from read_anchor()
+                if not adopt(e, a_key, a_pos, i, c, True):
+                    restart = True
+                    break
+                continue
+            good = True
+            for c2 in range(nc):
+                if c2 == c:
+                    continue
+                need = key(i, c2) if c2 < c else key(i - 1, c2)
+                pe, pk, pf = pr[c2]
+                if pk > need:
+                    continue
+                if pk == need and (pk < my_akey or (pe == my_epoch and pf == 0)):
+                    continue
+                good = False
+            if good:
+                break
+            last = sh.last_iter; yield
+            if i > last:
+                stop = True
+                break
+            yield
+        if restart:
+            continue
+        if stop:
+            break
+        # ---- the swap of the iteration before: from ALL ranks' records
+        yield from settle(i - 1)
+        last = sh.last_iter; yield
+        if i > last:
+            break
+        e = sh.epoch; yield
+        if e != my_epoch:
+            e, a_key, a_pos = yield from read_anchor()
+            if not adopt(e, a_key, a_pos, i, c, True):
+                continue                               # the step starts elsewhere: again
+        T_now = sh.temp[c]; yield
+        ok, cnt, acc, x2, L2_ = step_outcome(st, P, x, L, T_now)
+        assert ok == ok_pre
+        trace[(rank, i, c)] = P
+        sh.x[c], sh.L[c] = x2, L2_; yield
+        sh.done[c] = key(i, c); yield
+        sh.xcount[i & 3] += 1                          # (atomic)
+        is_last = sh.xcount[i & 3] == nc
+        yield
+        if is_last:
+            yield from post(i)
+        if not ok:
+            a = (key(i, c) + 1, P + cnt)
+            sh.anchor[(my_epoch + 1) & 1] = a; yield
+            sh.epoch = my_epoch + 1; yield
+            e, a_key, a_pos = yield from read_anchor()
+            adopt(e, a_key, a_pos, i, c, True)
+        ci += 1
+        if ci == len(chains):
+            ci = 0
+            i += 1
+            rc, rpos = rc1, rpos1
+            rc1, rpos1 = 0, B2
+            B2 = nextB(B2, nc)
+    return
+
+
+def run_case_lock(seed, verbose=False):
+    rnd = random.Random(seed * 7919 + 1)
+    R = rnd.choice([1, 2, 2, 3, 4])
+    nc = rnd.choice([1, 2, 3, 5, 8, 8, 11, 16])
+    NW = 8
+    n_iter = rnd.randint(3, 30)
+    p_rej = rnd.choice([0.0, 0.02, 0.2, 0.6, 1.0])
+    sts = [LockStream(seed, nc, p_rej, r, R) for r in range(R)]
+    x0 = [[h32(seed, 10, r, c) for c in range(nc)] for r in range(R)]
+    L0 = [[h32(seed, 11, r, c) % 100000 for c in range(nc)] for r in range(R)]
+    T0 = [[1 + r * nc + c for c in range(nc)] for r in range(R)]
+    stop = rnd.choice([None, None, (rnd.randrange(R), rnd.randint(1, n_iter))])      # (rank, iteration) that asks everybody to stop
+    n_run = stop[1] if stop else n_iter
+    xs, Ls, Ts, ps, tr_s = serial_lock(sts, nc, R, n_run, x0, L0, T0)
+    net = [[{}, {}] for _ in range(R)]
+    shs, gens, trace = [], [], {}
+    i0 = 0
+    for r in range(R):
+        sh = Shared()
+        sh.epoch, sh.anchor = 0, [(0, 0), (0, 0)]
+        sh.prog = [(0, c, 0) for c in range(nc)]
+        sh.done = [c for c in range(nc)]
+        sh.x, sh.L, sh.temp = list(x0[r]), list(L0[r]), list(T0[r])
+        sh.last_iter = n_iter
+        sh.stop_at = stop[1] if (stop and stop[0] == r) else None
+        sh.Eof = [0, 0, 0, 0]
+        sh.xcount, sh.xclaim, sh.xdone, sh.spos, sh.iter_done = [0, 0, 0, 0], i0, i0, 0, i0
+        shs.append(sh)
+        gens += [(r, wave_lock(sh, sts[r], net, w, NW, nc, R, r, i0, rnd, trace)) for w in range(NW)]
+    alive = list(range(len(gens)))
+    slow_rank = rnd.choice([None, None, rnd.randrange(R)])      # a rank that is scheduled rarely
+    steps = 0
+    while alive:
+        k = rnd.choice(alive)
+        if slow_rank is not None and gens[k][0] == slow_rank and rnd.random() < 0.8:
+            continue
+        try:
+            next(gens[k][1])
+        except StopIteration:
+            alive.remove(k)
+        steps += 1
+        if steps > 20_000_000:
+            raise RuntimeError("no progress (deadlock or livelock): lock-step seed %d" % seed)
+    ok = all(shs[r].x == xs[r] and shs[r].L == Ls[r] and shs[r].temp == Ts[r] and shs[r].spos == ps[r] and
+             shs[r].iter_done == n_run for r in range(R)) and trace == tr_s
+    if verbose or not ok:
+        print("lock-step seed %d: %d ranks x %d chains, %d iterations (stop %s), p_rej %.2f: %s" %
+              (seed, R, nc, n_iter, stop, p_rej, "equal" if ok else "MISMATCH"))
+        if not ok:
+            for k in sorted(tr_s):
+                if trace.get(k) != tr_s[k]:
+                    print("  first differing step (rank, iteration, chain)", k, "serial", tr_s[k], "flow", trace.get(k))
+                    break
+            for r in range(R):
+                print("  rank", r, "x", shs[r].x == xs[r], "L", shs[r].L == Ls[r], "T", shs[r].temp == Ts[r], "pos", shs[r].spos, ps[r],
+                      "done", shs[r].iter_done, n_run)
+    return ok
+
+
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     bad = 0
@@ -313,4 +644,10 @@ if __name__ == "__main__":
             bad += 1
             break
     print("%d cases: %s" % (n, "all equal to the serial loop" if not bad else "FAILED"))
+    if not bad:
+        for s in range(1, n + 1):
+            if not run_case_lock(s):
+                bad += 1
+                break
+        print("%d lock-step cases: %s" % (n, "all equal to the serial ranks" if not bad else "FAILED"))
     sys.exit(1 if bad else 0)
