@@ -373,7 +373,9 @@ __device__ __forceinline__ void load_obs_regs_nobranch(ObsRegs<NCH, F32> &ob, co
     }
 }
 
-template <int NCH, int NPOS, bool F32 = false, class FW>
+// PRE: `beta` and `q` hold 1 / vs and pi f / (qs vs) already -- the caller formed them once (a worker per order, the chain master
+// per commit of vs or qs): two fp64 divisions, ~28 instructions, that the compiler does not move out of a loop over events.
+template <int NCH, int NPOS, bool F32 = false, bool PRE = false, class FW>
 __device__ __forceinline__ void event_misfit(const FW &f, const ObsRegs<NCH, F32> &ob, int lane,
                                              const StaRegs<NCH> &st, const double (&px)[NPOS],
                                              const double (&py)[NPOS], const double (&pz)[NPOS], double beta,
@@ -384,8 +386,9 @@ __device__ __forceinline__ void event_misfit(const FW &f, const ObsRegs<NCH, F32
     // stations of a call, so the divisions are done ONCE (two here, the sums' reciprocals on the host) and the per-station
     // work is multiplications: the values differ from the reference's in the last bit at most (the same class as the
     // libm `log` difference and the summation order), a third of the step's fp64 instructions go away.
-    const double qbeta = q * beta;
-    const double rbeta = 1.0 / beta, katt = (kPi * kFreq) / qbeta;
+    double rbeta, katt;
+    if constexpr (PRE) { rbeta = beta; katt = q; }
+    else { const double qbeta = q * beta; rbeta = 1.0 / beta; katt = (kPi * kFreq) / qbeta; }
     double tob[NCH], tpr[NCH], aob[NCH], apr[NCH];      // (promoted here in the fp32 mode: exact)
 #pragma unroll
     for (int c = 0; c < NCH; ++c) { tob[c] = (double)ob.tob[c]; tpr[c] = (double)ob.tpr[c]; aob[c] = (double)ob.aob[c]; apr[c] = (double)ob.apr[c]; }

@@ -55,6 +55,9 @@ struct FlowShared : StepShared {
     int ob_pos[kMaxChains], ob_mode[kMaxChains], ob_mid[kMaxChains];     // ob_mid: type | event << 3 of the step in between (mode 2)
     unsigned ob_tag[kMaxChains];
     unsigned long long n_full_w, n_part_w;
+    // 1 / vs and pi f / (qs vs) of every chain (what event_misfit multiplies by: cls_forward.f90:118, :204), renewed by the chain's
+    // own wave when it commits a new vs or qs: a partial update reads them instead of dividing twice (28 instructions)
+    double rbeta[kMaxChains], katt[kMaxChains];
     // a lock-step rank (k_mcmc<.., 4>): chains of this rank that have committed iteration i (index i & 3: the last one posts the
     // rank's swap record); the iteration whose records a wave has taken on to collect
     int xcount[4], xclaim;
@@ -106,6 +109,7 @@ struct FlowTop {
     int book_pos, book_mode, book_mid;
     unsigned book_tag;
     double L;
+    double rbeta, katt;           // the chain's 1 / vs and pi f / (qs vs) (FlowShared)
 };
 
 constexpr int kFlowRestart = -1;  // flow_step: the step's position was disproved before its turn came: run it again
@@ -425,7 +429,7 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
                 if (c > 0) hB = rg.hop[(W.B2 & M) * kHops + c - 1];
                 hE = rg.hop[(W.B2 & M) * kHops + nc_ - 1];
             }
-            if constexpr (NCH > 0) event_misfit<NCH, 2, F32>(f, ob, lane, st, px, py, pz, beta, q, out);
+            if constexpr (NCH > 0) event_misfit<NCH, 2, F32, true>(f, ob, lane, st, px, py, pz, tp.rbeta, tp.katt, out);
             else event_misfit_generic<2>(f, ev, lane, s_sx, s_sy, s_sz, tc, ac, 0, -1, 0.0, px, py, pz, beta, q, out);
             L_new = L_cur + wave_sum1(out[0] - out[1]);
             // look-ahead, second round trip: what the stream holds at those positions -- used after the commit
@@ -631,6 +635,10 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
             if (o < rg.mir_n) rg.mx[o] = x_new;
             sh.L[c] = L_new;
             if (cool) sh.na[c * 7 + type - 1] += 1;
+            if (__builtin_expect(type == 1 || type == 3, 0)) {      // a new vs or qs: the chain's two reciprocals with it
+                const double b_ = type == 1 ? x_new : beta, q_ = type == 3 ? x_new : q;
+                sh.rbeta[c] = 1.0 / b_; sh.katt[c] = (kPi * kFreq) / (q_ * b_);
+            }
         }
         sh.L4[par][c] = L_post;
         lds_st(&sh.done[c], key);
@@ -848,6 +856,8 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
             sh.L[c] = L; sh.temp[c] = T; sh.rtemp[c] = 1.0 / T;
             sh.T4[(i0 + 1) & 3][c] = T; sh.T4[i0 & 3][c] = T; sh.L4[i0 & 3][c] = L;
             sh.rT4[(i0 + 1) & 3][c] = 1.0 / T; sh.rT4[i0 & 3][c] = 1.0 / T;
+            const double b_ = cs.xall[c], q_ = cs.xall[nc + nc * cs.S + c];      // vs, qs of the chain ([vs | t_corr | qs | ...])
+            sh.rbeta[c] = 1.0 / b_; sh.katt[c] = (kPi * kFreq) / (q_ * b_);
         }
     }
     if (sh.c.iter_done >= sh.c.iter_target || sh.c.stop || sh.c.err) return;      // (uniform)
@@ -884,6 +894,7 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
             tp.pk = (int)(unsigned)lds_ld(&sh.prog[co]);
             tp.book_pos = sh.ob_pos[c]; tp.book_mode = sh.ob_mode[c]; tp.book_mid = sh.ob_mid[c]; tp.book_tag = sh.ob_tag[c];
             tp.L = sh.L[c];
+            tp.rbeta = sh.rbeta[c]; tp.katt = sh.katt[c];
             asm volatile("" ::: "memory");
         }
         {

@@ -139,6 +139,7 @@ __global__ __launch_bounds__(256) void k_full(FwdDev f, FullJob jb)
 
         double lane_acc = 0.0;
         if constexpr (NCH > 0) {
+            const double rbeta_m = 1.0 / beta, katt_m = (kPi * kFreq) / (q * beta);      // (once per model, not once per event)
             StaRegs<NCH> st;
             load_sta_regs<NCH>(st, f.S, lane, f.sx, f.sy, f.sz, tc, ac, ov_kind, ov_idx, ov_val);
             for (int e = 0; e < jb.epw; ++e) {
@@ -152,11 +153,11 @@ __global__ __launch_bounds__(256) void k_full(FwdDev f, FullJob jb)
                     const double pz[1] = {(ov && ov_cmp == 2) ? ov_val : hyp[3 * ev + 2]};
                     double out[1];
                     if (keep_obs) {
-                        event_misfit<NCH, 1, F32>(f, ob_keep, lane, st, px, py, pz, beta, q, out);
+                        event_misfit<NCH, 1, F32, true>(f, ob_keep, lane, st, px, py, pz, rbeta_m, katt_m, out);
                     } else {
                         ObsRegs<NCH, F32> ob;
                         load_obs_regs<NCH, F32>(ob, f, ev, lane);
-                        event_misfit<NCH, 1, F32>(f, ob, lane, st, px, py, pz, beta, q, out);
+                        event_misfit<NCH, 1, F32, true>(f, ob, lane, st, px, py, pz, rbeta_m, katt_m, out);
                     }
                     lane_acc += out[0];
                 }

@@ -1619,6 +1619,8 @@ __device__ __forceinline__ void worker_body(FwRef f_, CsRef cs_, unsigned long l
             const GroupOff go = group_offsets(cs);
             const double beta_c = ld_agent(cs.xall + m), q_c = ld_agent(cs.xall + go.qs + m);
             const double beta = type == 1 ? ov_val : beta_c, q = type == 3 ? ov_val : q_c;
+            // (once per order, not once per event: cls_forward.f90:118, :204 divide per station; event_misfit multiplies)
+            const double rbeta_j = 1.0 / beta, katt_j = (kPi * kFreq) / (q * beta);
             int ov_kind = 0, ov_idx = -1, ov_evt = -1, ov_cmp = 0;
             const int r_off = (int)s_job[6] - 1 - (go.hy + m * go.nh);
             const int r_evt = s_job[6] ? r_off / 3 : -1;       // two-ahead orders: the event left to the chain's own wave
@@ -1656,7 +1658,7 @@ __device__ __forceinline__ void worker_body(FwRef f_, CsRef cs_, unsigned long l
                         const double py[1] = {(ov && ov_cmp == 1) ? ov_val : cy};
                         const double pz[1] = {(ov && ov_cmp == 2) ? ov_val : cz};
                         double out[1];
-                        event_misfit<NCH, 1, F32>(f, ob_cur, lane, st, px, py, pz, beta, q, out);
+                        event_misfit<NCH, 1, F32, true>(f, ob_cur, lane, st, px, py, pz, rbeta_j, katt_j, out);
                         // two-ahead order: the event of the step in between is left to the chain's own wave (it may be mid-commit)
                         lane_acc += (ev == r_evt) ? 0.0 : out[0];
                         ob_cur = ob_nxt; cx = nx; cy = ny; cz = nz;
@@ -1680,7 +1682,7 @@ __device__ __forceinline__ void worker_body(FwRef f_, CsRef cs_, unsigned long l
                         const double py[1] = {(ov && ov_cmp == 1) ? ov_val : y};
                         const double pz[1] = {(ov && ov_cmp == 2) ? ov_val : z};
                         double out[1];
-                        event_misfit<NCH, 1, F32>(f, b, lane, st, px, py, pz, beta, q, out);
+                        event_misfit<NCH, 1, F32, true>(f, b, lane, st, px, py, pz, rbeta_j, katt_j, out);
                         // two-ahead order: the event of the step in between is left to the chain's own wave (it may be mid-commit)
                         lane_acc += (e == r_evt) ? 0.0 : out[0];
                     };
