@@ -342,10 +342,28 @@ __device__ __forceinline__ void load_obs_regs(ObsRegs<NCH, F32> &ob, const FW &f
 // The same rows, requested without a branch: every lane issues all four loads (a lane without a station reads the row's last
 // entry and discards it; the arrays exist whatever use_time / use_amp say), so the number of loads per call is fixed and the
 // compiler can leave several calls' worth in flight (s_waitcnt vmcnt(N > 0)) -- the worker blocks' event pipeline.
-template <int NCH, bool F32 = false, bool NT = false, bool VRPS = false, class FW>
+// FULL: every lane has a station in every chunk and both data types are used (the caller has checked: n_sta a multiple of 64,
+// use_time and use_amp) -- no selects on the loaded values at all.
+template <int NCH, bool F32 = false, bool NT = false, bool VRPS = false, bool FULL = false, class FW>
 __device__ __forceinline__ void load_obs_regs_nobranch(ObsRegs<NCH, F32> &ob, const FW &f, int ev, int lane)
 {
     const size_t base = (size_t)ev * (size_t)f.S;
+    if constexpr (FULL) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const size_t k = base + (size_t)(lane + 64 * c);
+            if constexpr (F32) {
+                ob.tob[c] = ld_stream<float, NT>(f.t_obs32 + k); ob.tpr[c] = ld_stream<float, NT>(f.t_prec32 + k);
+                ob.aob[c] = ld_stream<float, NT>(f.a_obs32 + k); ob.apr[c] = ld_stream<float, NT>(f.a_prec32 + k);
+            } else {
+                ob.tob[c] = ld_stream<double, NT>(f.t_obs + k); ob.tpr[c] = ld_stream<double, NT>(f.t_prec + k);
+                ob.aob[c] = ld_stream<double, NT>(f.a_obs + k); ob.apr[c] = ld_stream<double, NT>(f.a_prec + k);
+            }
+        }
+        ob.rpst = ld_const(f.rpsum_t + ev);
+        ob.rpsa = ld_const(f.rpsum_a + ev);
+        return;
+    }
     const bool ut = f.use_time != 0, ua = f.use_amp != 0;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {

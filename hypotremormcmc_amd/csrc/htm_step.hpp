@@ -1644,19 +1644,22 @@ __device__ __forceinline__ void worker_body(FwRef f_, CsRef cs_, unsigned long l
                     // event of look-ahead).  fp64: an event's arithmetic covers the next one's loads, the deeper form below
                     // measured -1 % at 1 000 and 10 000 events x 64 stations, and two stations per lane do not fit the 256
                     // registers of a wave with three buffers.
+                    const bool full_rows64 = f.S == 64 * NCH && f.use_time != 0 && f.use_amp != 0;      // (loads without selects or branches)
                     ObsRegs<NCH, F32> ob_cur = ob0, ob_nxt = ob0;
                     double cx = 0.0, cy = 0.0, cz = 0.0, nx = 0.0, ny = 0.0, nz = 0.0;
                     if (ev0 < f.E) { cx = ld_agent(hyp + 3 * ev0); cy = ld_agent(hyp + 3 * ev0 + 1); cz = ld_agent(hyp + 3 * ev0 + 2); }
                     for (int ev = ev0; ev < f.E; ev += NWV * W) {
                         const int evn = ev + NWV * W;
                         if (evn < f.E) {
-                            load_obs_regs<NCH, F32, HTM_NT_WORKERS != 0, HTM_VRPS_WORKERS != 0>(ob_nxt, f, evn, lane);
+                            if (full_rows64) load_obs_regs_nobranch<NCH, F32, HTM_NT_WORKERS != 0, HTM_VRPS_WORKERS != 0, true>(ob_nxt, f, evn, lane);
+                            else load_obs_regs<NCH, F32, HTM_NT_WORKERS != 0, HTM_VRPS_WORKERS != 0>(ob_nxt, f, evn, lane);
                             nx = ld_agent(hyp + 3 * evn); ny = ld_agent(hyp + 3 * evn + 1); nz = ld_agent(hyp + 3 * evn + 2);
                         }
-                        const bool ov = ev == ov_evt;
-                        const double px[1] = {(ov && ov_cmp == 0) ? ov_val : cx};
-                        const double py[1] = {(ov && ov_cmp == 1) ? ov_val : cy};
-                        const double pz[1] = {(ov && ov_cmp == 2) ? ov_val : cz};
+                        double ex = cx, ey = cy, ez = cz;      // (the proposed component of a first-iteration order: a rare branch)
+                        if (__builtin_expect(ev == ov_evt, 0)) { ex = ov_cmp == 0 ? ov_val : cx; ey = ov_cmp == 1 ? ov_val : cy; ez = ov_cmp == 2 ? ov_val : cz; }
+                        const double px[1] = {ex};
+                        const double py[1] = {ey};
+                        const double pz[1] = {ez};
                         double out[1];
                         event_misfit<NCH, 1, F32, true>(f, ob_cur, lane, st, px, py, pz, rbeta_j, katt_j, out);
                         // two-ahead order: the event of the step in between is left to the chain's own wave (it may be mid-commit)
@@ -1672,15 +1675,20 @@ __device__ __forceinline__ void worker_body(FwRef f_, CsRef cs_, unsigned long l
                     const int s8 = NWV * W;
                     ObsRegs<NCH, F32> b0 = ob0, b1 = ob0, b2 = ob0;
                     double x0 = 0.0, y0 = 0.0, z0 = 0.0, x1 = 0.0, y1 = 0.0, z1 = 0.0, x2 = 0.0, y2 = 0.0, z2 = 0.0;
+                    // (every lane has a station in both chunks and both data types are used: the loads need no selects)
+                    const bool full_rows = (f.S & 63) == 0 && f.S == 64 * NCH && f.use_time != 0 && f.use_amp != 0;
                     auto fetch = [&](ObsRegs<NCH, F32> &b, double &x, double &y, double &z, int e) __attribute__((always_inline)) {
-                        load_obs_regs_nobranch<NCH, F32, HTM_NT_WORKERS != 0, HTM_VRPS_WORKERS != 0>(b, f, e, lane);
+                        if (full_rows) load_obs_regs_nobranch<NCH, F32, HTM_NT_WORKERS != 0, HTM_VRPS_WORKERS != 0, true>(b, f, e, lane);
+                        else load_obs_regs_nobranch<NCH, F32, HTM_NT_WORKERS != 0, HTM_VRPS_WORKERS != 0>(b, f, e, lane);
                         x = ld_agent(hyp + 3 * e); y = ld_agent(hyp + 3 * e + 1); z = ld_agent(hyp + 3 * e + 2);
                     };
                     auto eval = [&](const ObsRegs<NCH, F32> &b, double x, double y, double z, int e) __attribute__((always_inline)) {
-                        const bool ov = e == ov_evt;
-                        const double px[1] = {(ov && ov_cmp == 0) ? ov_val : x};
-                        const double py[1] = {(ov && ov_cmp == 1) ? ov_val : y};
-                        const double pz[1] = {(ov && ov_cmp == 2) ? ov_val : z};
+                        // (the proposed hypocentre component of an order of the first iteration: a rare branch, not three selects per event)
+                        double ex = x, ey = y, ez = z;
+                        if (__builtin_expect(e == ov_evt, 0)) { ex = ov_cmp == 0 ? ov_val : x; ey = ov_cmp == 1 ? ov_val : y; ez = ov_cmp == 2 ? ov_val : z; }
+                        const double px[1] = {ex};
+                        const double py[1] = {ey};
+                        const double pz[1] = {ez};
                         double out[1];
                         event_misfit<NCH, 1, F32, true>(f, b, lane, st, px, py, pz, rbeta_j, katt_j, out);
                         // two-ahead order: the event of the step in between is left to the chain's own wave (it may be mid-commit)
