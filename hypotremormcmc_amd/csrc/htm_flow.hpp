@@ -819,7 +819,7 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int NW = min((int)(blockDim.x >> 6), 8);      // chain waves (a 12-wave block -- k_mcmc_wide -- has four idle ones)
+    const int NW = min((int)(blockDim.x >> 6), 8);      // chain waves
     const int nc = cs.n_chains;
     {
         const int vz0 = opaque_zero();
@@ -1037,34 +1037,6 @@ __global__ __launch_bounds__(512) void k_mcmc(FwdDev f, ChainsDev cs, int mode, 
     } else {
         worker_body<NCH, F32, 8>(ka.f, ka.cs, launch, blockIdx.x - 1);
     }
-}
-
-// Large event counts (one wave evaluates several events per order: the iteration is bound by the workers, 41 MB per full
-// evaluation at 10 000 x 128): the same launch with blocks of TWELVE waves -- three per SIMD instead of two, the kernel held
-// to 168 registers; the master's block uses eight of its waves.  Single-rank loop on the free-running master only.
-template <int NCH, bool F32 = false>
-__global__ __launch_bounds__(768) void k_mcmc_wide(FwdDev f, ChainsDev cs, int mode, int target_arg,
-                                                    const double *gathered, int ring_size, int wmax,
-                                                    unsigned long long launch)
-{
-    const KArgLayout __attribute__((address_space(4))) &ka = *(const KArgLayout __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
-    if (blockIdx.x == 0) {
-        flow_body<NCH, F32, false>(ka.f, ka.cs, target_arg, ring_size, wmax, launch);
-        __syncthreads();
-        if (threadIdx.x == 0) st_agent(&ka.cs.ps->quit, launch + 1ull);
-    } else {
-        worker_body<NCH, F32, 12>(ka.f, ka.cs, launch, blockIdx.x - 1);
-    }
-}
-
-// The worker blocks as a launch of their own (htm_hip.hip: split_workers), next to a k_mcmc launch of the master block alone:
-// 12 waves per block and the workers' own register budget -- where one wave evaluates many events (10 000 events: 41 MB
-// per full evaluation) the iteration is bound by the workers, and the master's 150-200 registers held them at 8 waves per CU.
-template <int NCH, bool F32 = false>
-__global__ __launch_bounds__(768) void k_workers(FwdDev f, ChainsDev cs, unsigned long long launch)
-{
-    const KArgLayout __attribute__((address_space(4))) &ka = *(const KArgLayout __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
-    worker_body<NCH, F32, 12>(ka.f, ka.cs, launch, blockIdx.x);
 }
 
 }  // namespace htm

@@ -169,13 +169,9 @@ struct htm_chains {
     bool persist = true;                       // k_mcmc (master + resident full-evaluation workers) vs k_step + k_full
     bool flow = false;                         // single-rank loop on the free-running master (htm_flow.hpp) instead of step_body
     int worker_cap = 250;                      // most worker blocks a launch takes (HTM_WORKER_CAP)
-    bool split = false;                        // worker blocks as a k_workers launch of their own (12 waves per block) beside the master's
-    long blocks_fit = 0, wide_blocks_fit = 0;  // resident blocks of a k_mcmc / k_mcmc_wide launch on this device (htm_chains_share_gpu)
+    long blocks_fit = 0;                       // resident blocks of a k_mcmc launch on this device (htm_chains_share_gpu)
     bool flow_lock = false;                    // lock-step ranks (MODE_LOCKRUN) on the free-running master too
     bool ctrl_fresh = false;                   // h_ctrl is the device's control block as of an idle stream (no launch since it was read)
-    bool wide = false;                         // the single-rank loop in blocks of 12 waves (k_mcmc_wide: large event counts)
-    int n_workers8 = 0;                        // worker blocks of the 8-wave launches (lock-step modes) when `wide`
-    hipStream_t wstream = nullptr;             // ... on this stream
     ChainsDev dev_np{};                        // view for the non-persistent kernels (partial sums per k_full tile)
     uint32_t init_state[4] = {0, 0, 0, 0};     // mod_random state at stream position 0
     // in-kernel exchange of the swap records (persistent lock-step): this rank's inbox, the peers' inboxes as mapped here
@@ -232,19 +228,9 @@ int launch_full(htm_forward *h, const FullJob &jb, int gy)
 int launch_mcmc(htm_chains *hc, int mode, int target, const double *gathered)
 {
     htm_forward *h = hc->fwd;
-    dim3 grid(hc->split ? 1 : 1 + hc->dev.n_workers), block(512);
+    dim3 grid(1 + hc->dev.n_workers), block(512);
     hc->ctrl_fresh = false;
     const unsigned long long seq = ++hc->launch_seq;      // this chain set's k_mcmc launches, counted from 1
-    if (hc->split) {
-        // the worker blocks first, on their own stream: they wait for orders carrying this launch's number and leave when the
-        // master (launched next, one block) says so
-        dim3 wgrid(hc->dev.n_workers), wblock(768);
-        if (h->dev.fp32) { if (h->nch == 1) hipLaunchKernelGGL((k_workers<1, true>), wgrid, wblock, 1024, hc->wstream, h->dev, hc->dev, seq);
-                           else hipLaunchKernelGGL((k_workers<2, true>), wgrid, wblock, 1024, hc->wstream, h->dev, hc->dev, seq); }
-        else if (h->nch == 1) hipLaunchKernelGGL((k_workers<1, false>), wgrid, wblock, 1024, hc->wstream, h->dev, hc->dev, seq);
-        else hipLaunchKernelGGL((k_workers<2, false>), wgrid, wblock, 1024, hc->wstream, h->dev, hc->dev, seq);
-        HIPCHK(hipGetLastError());
-    }
 #define HTM_LAUNCH_MCMC(N, F, K) hipLaunchKernelGGL((k_mcmc<N, F, K>), grid, block, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax, seq)
 #define HTM_LAUNCH_MCMC_K(K)                                                                              \
     do {                                                                                                   \
@@ -254,14 +240,7 @@ int launch_mcmc(htm_chains *hc, int mode, int target, const double *gathered)
         else HTM_LAUNCH_MCMC(0, false, K);                                                                 \
     } while (0)
     // one instantiation per main loop: the single-rank loop, one lock-step iteration per launch, persistent lock-step
-    if (mode == MODE_RUN && hc->flow && hc->wide) {
-        dim3 wgrid(1 + hc->dev.n_workers), wblock(768);
-        if (h->dev.fp32) { if (h->nch == 1) hipLaunchKernelGGL((k_mcmc_wide<1, true>), wgrid, wblock, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax, seq);
-                           else hipLaunchKernelGGL((k_mcmc_wide<2, true>), wgrid, wblock, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax, seq); }
-        else if (h->nch == 1) hipLaunchKernelGGL((k_mcmc_wide<1, false>), wgrid, wblock, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax, seq);
-        else hipLaunchKernelGGL((k_mcmc_wide<2, false>), wgrid, wblock, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax, seq);
-    }
-    else if (mode == MODE_RUN && hc->flow) HTM_LAUNCH_MCMC_K(3);
+    if (mode == MODE_RUN && hc->flow) HTM_LAUNCH_MCMC_K(3);
     else if (mode == MODE_RUN) HTM_LAUNCH_MCMC_K(0);
     else if (mode == MODE_LOCKRUN && hc->flow_lock) HTM_LAUNCH_MCMC_K(4);
     else if (mode == MODE_LOCKRUN) HTM_LAUNCH_MCMC_K(2);
@@ -946,35 +925,12 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
             per_cu = std::min(per_cu, pc);
         }
         HIPCHK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
-        // Large event counts (one wave evaluates several events per order: the iteration is bound by the workers): the worker
-        // blocks run as a launch of their own with 12 waves per block and their own registers (k_workers), the master's block
-        // alone in the k_mcmc launch.  HTM_SPLIT_WORKERS=0 / 1 overrides the choice by size.
-        {
-            const char *e = getenv("HTM_SPLIT_WORKERS");
-            const bool by_size = (h->E + 7) / 8 > 240;
-            (void)by_size;
-            hc->split = (h->nch == 1 || h->nch == 2) && e && atoi(e) != 0;      // (opt-in: see DESIGN.md 9 -- a relaunch race is open)
-            if (hc->split) {
-                const void *wfn = h->dev.fp32 ? (h->nch == 1 ? (const void *)k_workers<1, true> : (const void *)k_workers<2, true>)
-                                  : (h->nch == 1 ? (const void *)k_workers<1, false> : (const void *)k_workers<2, false>);
-                int wpc = 0;
-                HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&wpc, wfn, 768, 1024));
-                long wroom = (long)wpc * n_cu - 2;        // (the master's block takes a CU's worth of LDS)
-                if (const char *e2 = getenv("HTM_RANKS_PER_GPU")) { const int k = atoi(e2); if (k > 1) wroom = (long)wpc * n_cu / k - 2; }
-                if (wroom < 1 || hipStreamCreateWithFlags(&hc->wstream, hipStreamNonBlocking) != hipSuccess) hc->split = false;
-                else {
-                    hc->dev.n_workers = (int)std::max<long>(1, std::min<long>(std::min<long>(255, wroom), (h->E + 11) / 12));
-                    if (const char *e3 = getenv("HTM_MAX_WORKERS")) hc->dev.n_workers = std::max(1, std::min(hc->dev.n_workers, atoi(e3)));
-                }
-            }
-        }
         hc->blocks_fit = (long)per_cu * n_cu;
         long room = (long)per_cu * n_cu - 1;
         // Several ranks on one GPU (more masters instead of more rounds per master: 4 ranks x 8 chains run 2.7 M steps/s where one
         // rank x 32 chains runs 1.7 M): every rank's blocks must be resident at once, so each takes its share of the CUs
         if (const char *e = getenv("HTM_RANKS_PER_GPU")) { const int k = atoi(e); if (k > 1) room = (long)per_cu * n_cu / k - 1; }
-        if (hc->split) { }                      // (sized above)
-        else if (room < 1) hc->persist = false;      // not even one worker fits next to the master: two-kernel path
+        if (room < 1) hc->persist = false;      // not even one worker fits next to the master: two-kernel path
         else if (hc->dev.n_workers > room) hc->dev.n_workers = worker_blocks(h->E, 8, room);
     }
     hc->dev.n_wg = hc->dev.n_workers;           // persistent kernel: one partial per worker block
@@ -989,29 +945,6 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
                                hc->ring_size >= 4 * wd + 32 + 2 * c_max + 16;
         hc->flow = window_ok && d.n_procs == 1;
         hc->flow_lock = window_ok && !(getenv("HTM_FLOW_LOCK") && getenv("HTM_FLOW_LOCK")[0] == '0');      // (MODE_LOCKRUN: any number of ranks)
-        // blocks of 12 waves (HTM_WIDE=1): opt-in.  Measured at 10 000 x 128 x 16 chains with 240 worker blocks: fp64 856 -> 902 k
-        // steps/s (four rounds of events per worker wave instead of six), the fp32 workers spill at 168 registers and lose a
-        // quarter, one station per lane gains nothing (profiles/r03_j_wide.txt).  With 250 blocks the 8-wave launch needs five
-        // rounds and is the faster one in fp64 too: 980 k against 949 k (profiles/r03_t_worker_blocks.txt).
-        const char *ew = getenv("HTM_WIDE");
-        if (hc->flow && !hc->split && (h->nch == 1 || h->nch == 2) && ew && atoi(ew) != 0) {
-            const void *wfn = h->dev.fp32 ? (h->nch == 1 ? (const void *)k_mcmc_wide<1, true> : (const void *)k_mcmc_wide<2, true>)
-                              : (h->nch == 1 ? (const void *)k_mcmc_wide<1, false> : (const void *)k_mcmc_wide<2, false>);
-            int wpc = 0, n_cu = 0;
-            if (hc->step_smem > 48 * 1024) HIPCHK(hipFuncSetAttribute(wfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hc->step_smem));
-            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&wpc, wfn, 768, hc->step_smem));
-            HIPCHK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
-            long wroom = (long)wpc * n_cu - 1;
-            hc->wide_blocks_fit = (long)wpc * n_cu;
-            if (const char *e2 = getenv("HTM_RANKS_PER_GPU")) { const int k = atoi(e2); if (k > 1) wroom = (long)wpc * n_cu / k - 1; }
-            if (wroom >= 1) {
-                hc->wide = true;
-                hc->n_workers8 = hc->dev.n_workers;
-                int nw = worker_blocks(h->E, 12, std::min<long>(hc->worker_cap, wroom));
-                if (const char *e3 = getenv("HTM_MAX_WORKERS")) nw = std::max(1, std::min(nw, atoi(e3)));
-                hc->dev.n_workers = nw; hc->dev.n_wg = nw;
-            }
-        }
     }
     // first stretch of the random stream (synchronous)
     if ((rc = stream_produce(hc, 1 << 16))) return cleanup(rc);
@@ -1026,7 +959,6 @@ int htm_chains_destroy(htm_chains *hc)
     (void)hipSetDevice(hc->fwd->device);
     if (hc->side) (void)hipStreamSynchronize(hc->side);
     (void)hipStreamSynchronize(hc->fwd->stream);
-    if (hc->wstream) { (void)hipStreamSynchronize(hc->wstream); (void)hipStreamDestroy(hc->wstream); }
     if (hc->ev_side) (void)hipEventDestroy(hc->ev_side);
     if (hc->side) (void)hipStreamDestroy(hc->side);
     if (hc->gexec) (void)hipGraphExecDestroy(hc->gexec);
@@ -1877,13 +1809,12 @@ int htm_chains_get_state(htm_chains *hc, int chain, double *hypo, double *t_corr
 int htm_chains_share_gpu(htm_chains *hc, int ranks_on_this_gpu)
 {
     if (!hc || ranks_on_this_gpu < 1) return fail(HTM_EINVAL, "bad argument");
-    if (hc->launch_seq > 0) return fail(HTM_ESTATE, "htm_chains_share_gpu must be called before the chain set's first launch");
-    if (getenv("HTM_RANKS_PER_GPU") || !hc->persist || hc->split || ranks_on_this_gpu == 1) return HTM_OK;      // (an explicit setting stands)
-    const long fit = hc->wide ? hc->wide_blocks_fit : hc->blocks_fit;
-    const long room = fit / ranks_on_this_gpu - 1;
+    if (getenv("HTM_RANKS_PER_GPU") || !hc->persist || ranks_on_this_gpu == 1) return HTM_OK;      // (an explicit setting stands)
+    // (a chain set that has already run keeps the launch shape it ran with: ADVICE r3 -- a world built around it must not fail)
+    if (hc->launch_seq > 0) return HTM_OK;
+    const long room = hc->blocks_fit / ranks_on_this_gpu - 1;
     if (room < 1) return fail(HTM_ESTATE, "%d ranks on one GPU: not even one worker block per rank fits next to the masters", ranks_on_this_gpu);
-    if (hc->dev.n_workers > room) hc->dev.n_workers = worker_blocks(hc->fwd->E, hc->wide ? 12 : 8, room);
-    if (hc->wide && hc->n_workers8 > hc->blocks_fit / ranks_on_this_gpu - 1) hc->n_workers8 = worker_blocks(hc->fwd->E, 8, hc->blocks_fit / ranks_on_this_gpu - 1);
+    if (hc->dev.n_workers > room) hc->dev.n_workers = worker_blocks(hc->fwd->E, 8, room);
     hc->dev.n_wg = hc->dev.n_workers;
     return HTM_OK;
 }

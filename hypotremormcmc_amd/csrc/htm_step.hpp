@@ -1434,8 +1434,7 @@ __global__ __launch_bounds__(512) void k_step(FwdDev f, ChainsDev cs, int mode, 
 // granules (data is the flag); chain state is read with agent-scope loads after the job word has been seen
 // (the master drained its stores before publishing it).  Leaves when the master has finished (PSync::quit)
 // or after a bounded wait.
-// NWV = waves per worker block: 8 inside a k_mcmc launch (the master's block shape), 12 in a k_workers launch of its own
-// (blocks of 768 threads: three waves per SIMD where the master's registers allow two -- large event counts, htm_hip.hip)
+// NWV = waves per worker block (8: the master's block shape)
 template <int NCH, bool F32, int NWV = 8>
 __device__ __forceinline__ void worker_body(FwRef f_, CsRef cs_, unsigned long long launch, int w)
 {
@@ -1736,7 +1735,6 @@ __device__ __forceinline__ void worker_body(FwRef f_, CsRef cs_, unsigned long l
 #endif
             if (tid == 0) {
                 double tot8 = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) + ((s_red[4] + s_red[5]) + (s_red[6] + s_red[7]));
-                if constexpr (NWV == 12) tot8 = tot8 + ((s_red[8] + s_red[9]) + (s_red[10] + s_red[11]));
                 st_gran_f64(cs.pgran + ((size_t)m * cs.n_wg + w) * cs.pgran_stride, tag, tot8);
             }
             __syncthreads();
