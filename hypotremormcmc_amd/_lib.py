@@ -95,6 +95,7 @@ SIGNATURES = {
     "htm_chains_enable_steplog": (C.c_int, [vp, C.c_int]),
     "htm_chains_steplog_read": (C.c_int, [vp, C.POINTER(C.c_int), ip, dp]),
     "htm_chains_handoff_stats": (C.c_int, [vp, C.POINTER(C.c_int64)]),
+    "htm_chains_master_stats": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "htm_chains_last_run_stats": (C.c_int, [vp, dp, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "htm_chains_profile": (C.c_int, [vp, C.c_int, dp, C.POINTER(C.c_int), dp, C.POINTER(C.c_int),
                                      C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

@@ -250,6 +250,13 @@ class ChainSet:
         check(self._lib.htm_chains_handoff_stats(self.handle, C.byref(n)))
         return dict(orders_put_aside=n.value)
 
+    def master_stats(self):
+        """which main loop the launches run on (5 / 6 pipelined master, 3 / 4 free-running, 0 / 2 barriers, -1 two kernels)
+        and how often the pipelined master flushed its speculative records"""
+        a = C.c_int(); b = C.c_int(); n = C.c_int64()
+        check(self._lib.htm_chains_master_stats(self.handle, C.byref(a), C.byref(b), C.byref(n)))
+        return dict(single_rank_loop=a.value, lockstep_loop=b.value, flushes=n.value)
+
     def last_run_stats(self):
         us = C.c_double(); g = C.c_int(); f = C.c_int64(); p = C.c_int64()
         check(self._lib.htm_chains_last_run_stats(self.handle, C.byref(us), C.byref(g), C.byref(f), C.byref(p)))

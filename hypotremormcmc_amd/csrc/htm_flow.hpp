@@ -1016,27 +1016,4 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
     if (tid == 0) *cs.ctrl = sh.c;
 }
 
-// One launch = the chain master (block 0) + W full-evaluation workers (blocks 1..W), all resident.
-// `launch` = the host's count of k_mcmc launches of this chain set (1, 2, ...): orders and the quit word carry it, so
-// nothing a previous launch left in memory can be mistaken for this launch's.
-template <int NCH, bool F32 = false, int MK = 0>
-__global__ __launch_bounds__(512) void k_mcmc(FwdDev f, ChainsDev cs, int mode, int target_arg,
-                                               const double *gathered, int ring_size, int wmax,
-                                               unsigned long long launch)
-{
-    const KArgLayout __attribute__((address_space(4))) &ka = *(const KArgLayout __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
-    if (blockIdx.x == 0) {
-        // MK 3: the single-rank loop on the free-running master (flow_body); 0: the same loop with barriers (step_body)
-        // 4: a lock-step rank (MODE_LOCKRUN, swap records exchanged inside the launch) on the free-running master; 2: with barriers
-        if constexpr (MK == 3) flow_body<NCH, F32, false>(ka.f, ka.cs, target_arg, ring_size, wmax, launch);
-        else if constexpr (MK == 4) flow_body<NCH, F32, true>(ka.f, ka.cs, target_arg, ring_size, wmax, launch);
-        else step_body<NCH, true, F32, MK>(ka.f, ka.cs, mode, target_arg, gathered, ring_size, wmax, launch);
-        // every exit of the master comes through here (its returns are uniform over the block): release the workers
-        __syncthreads();
-        if (threadIdx.x == 0) st_agent(&ka.cs.ps->quit, launch + 1ull);
-    } else {
-        worker_body<NCH, F32, 8>(ka.f, ka.cs, launch, blockIdx.x - 1);
-    }
-}
-
 }  // namespace htm

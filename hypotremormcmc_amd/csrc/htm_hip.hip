@@ -20,7 +20,7 @@
 #include <vector>
 
 #include "htm_kernels.hpp"
-#include "htm_flow.hpp"
+#include "htm_pipe.hpp"
 #include "htm_select.hpp"
 
 using namespace htm;
@@ -171,6 +171,8 @@ struct htm_chains {
     int worker_cap = 250;                      // most worker blocks a launch takes (HTM_WORKER_CAP)
     long blocks_fit = 0;                       // resident blocks of a k_mcmc launch on this device (htm_chains_share_gpu)
     bool flow_lock = false;                    // lock-step ranks (MODE_LOCKRUN) on the free-running master too
+    bool pipe = false;                         // single-rank loop on the pipelined master (htm_pipe.hpp)
+    size_t pipe_smem = 0; int pipe_ring = 512; // its LDS size and stream window
     bool ctrl_fresh = false;                   // h_ctrl is the device's control block as of an idle stream (no launch since it was read)
     ChainsDev dev_np{};                        // view for the non-persistent kernels (partial sums per k_full tile)
     uint32_t init_state[4] = {0, 0, 0, 0};     // mod_random state at stream position 0
@@ -240,7 +242,15 @@ int launch_mcmc(htm_chains *hc, int mode, int target, const double *gathered)
         else HTM_LAUNCH_MCMC(0, false, K);                                                                 \
     } while (0)
     // one instantiation per main loop: the single-rank loop, one lock-step iteration per launch, persistent lock-step
-    if (mode == MODE_RUN && hc->flow) HTM_LAUNCH_MCMC_K(3);
+    if (mode == MODE_RUN && hc->pipe) {
+        // the pipelined master (htm_pipe.hpp): one or two stations per lane only
+#define HTM_LAUNCH_PIPE(N, F) hipLaunchKernelGGL((k_mcmc<N, F, 5>), grid, block, hc->pipe_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->pipe_ring, hc->wmax, seq)
+        if (h->dev.fp32) { if (h->nch == 1) HTM_LAUNCH_PIPE(1, true); else HTM_LAUNCH_PIPE(2, true); }
+        else if (h->nch == 1) HTM_LAUNCH_PIPE(1, false);
+        else HTM_LAUNCH_PIPE(2, false);
+#undef HTM_LAUNCH_PIPE
+    }
+    else if (mode == MODE_RUN && hc->flow) HTM_LAUNCH_MCMC_K(3);
     else if (mode == MODE_RUN) HTM_LAUNCH_MCMC_K(0);
     else if (mode == MODE_LOCKRUN && hc->flow_lock) HTM_LAUNCH_MCMC_K(4);
     else if (mode == MODE_LOCKRUN) HTM_LAUNCH_MCMC_K(2);
@@ -787,6 +797,8 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
     }
     if ((rc = dev_alloc(hc->pool, &d.slots, (size_t)d.slot_rep * d.slot_stride))) return cleanup(rc);
     HIPCHK(hipMemset(d.slots, 0, (size_t)d.slot_rep * d.slot_stride * sizeof(unsigned long long)));
+    if ((rc = dev_alloc(hc->pool, &d.lo_gran, (size_t)nc * 16))) return cleanup(rc);
+    HIPCHK(hipMemset(d.lo_gran, 0, (size_t)nc * 16 * sizeof(unsigned long long)));
     if ((rc = dev_alloc(hc->pool, &d.pgran, (size_t)nc * 256 * d.pgran_stride))) return cleanup(rc);
     HIPCHK(hipMemset(d.pgran, 0, (size_t)nc * 256 * d.pgran_stride * sizeof(unsigned long long)));
     {
@@ -814,8 +826,8 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
     HIPCHK(hipMemset(d.diag, 0, 32 * sizeof(unsigned long long)));
     d.stamps = nullptr;
 #ifdef HTM_STAMPS
-    if ((rc = dev_alloc(hc->pool, &d.stamps, 128))) return cleanup(rc);
-    HIPCHK(hipMemset(d.stamps, 0, 128 * sizeof(unsigned long long)));
+    if ((rc = dev_alloc(hc->pool, &d.stamps, 128 + 2 * 8192))) return cleanup(rc);      // (+ the event trace of htm_pipe.hpp)
+    HIPCHK(hipMemset(d.stamps, 0, (128 + 2 * 8192) * sizeof(unsigned long long)));
 #endif
 
     // random-stream service
@@ -945,6 +957,30 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
                                hc->ring_size >= 4 * wd + 32 + 2 * c_max + 16;
         hc->flow = window_ok && d.n_procs == 1;
         hc->flow_lock = window_ok && !(getenv("HTM_FLOW_LOCK") && getenv("HTM_FLOW_LOCK")[0] == '0');      // (MODE_LOCKRUN: any number of ranks)
+        // The pipelined master (htm_pipe.hpp; HTM_PIPE=0 keeps the free-running one): front / evaluators / decider over an LDS ring
+        // of iteration slots.  Needs the LDS mirror of the non-hypocentre parameters (what its evaluators read) and one or two
+        // stations per lane.
+        {
+            const char *ep = getenv("HTM_PIPE");
+            const int wdp = 6 * nc + 16;
+            int ring = 512;
+            while (ring < 2 * wdp + 160) ring *= 2;
+            const size_t mirp = 2 * (size_t)nc + 2 * (size_t)nc * h->S;
+            const size_t smem = ((sizeof(PipeShared) + 15) & ~size_t(15)) + (size_t)ring * lds_pos + 3 * (size_t)h->S * sizeof(double) +
+                                mirp * sizeof(double) + pipe_ring_bytes(nc);
+            hc->pipe = hc->persist && d.n_procs == 1 && !(ep && ep[0] == '0') && d.dbg == 0 && (h->nch == 1 || h->nch == 2) && smem <= lds_cap &&
+                       hc->dev.mirror_n == (int)mirp;      // (the mirror is part of every loop's LDS layout: one size for all)
+            if (hc->pipe) {
+                hc->pipe_smem = smem; hc->pipe_ring = ring;
+                const void *pfn = h->dev.fp32 ? (h->nch == 1 ? (const void *)k_mcmc<1, true, 5> : (const void *)k_mcmc<2, true, 5>)
+                                  : (h->nch == 1 ? (const void *)k_mcmc<1, false, 5> : (const void *)k_mcmc<2, false, 5>);
+                int pc = 0, n_cu2 = 0;
+                if (smem > 48 * 1024) HIPCHK(hipFuncSetAttribute(pfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, pfn, 512, smem));
+                HIPCHK(hipDeviceGetAttribute(&n_cu2, hipDeviceAttributeMultiprocessorCount, h->device));
+                if ((long)pc * n_cu2 - 1 < hc->dev.n_workers) hc->pipe = false;      // (the launch shape was sized for the other loops: keep it)
+            }
+        }
     }
     // first stretch of the random stream (synchronous)
     if ((rc = stream_produce(hc, 1 << 16))) return cleanup(rc);
@@ -1935,6 +1971,20 @@ int htm_chains_last_run_stats(htm_chains *hc, double *device_us, int *graph_laun
     return HTM_OK;
 }
 
+int htm_chains_master_stats(htm_chains *hc, int *single_rank_loop, int *lockstep_loop, int64_t *flushes)
+{
+    if (!hc) return fail(HTM_EINVAL, "NULL argument");
+    if (single_rank_loop) *single_rank_loop = !hc->persist ? -1 : hc->pipe ? 5 : hc->flow ? 3 : 0;
+    if (lockstep_loop) *lockstep_loop = !hc->persist ? -1 : hc->flow_lock ? 4 : 2;
+    if (flushes) {
+        HIPCHK(hipStreamSynchronize(hc->fwd->stream));
+        unsigned long long v = 0;
+        HIPCHK(hipMemcpy(&v, hc->dev.diag + 25, sizeof(v), hipMemcpyDeviceToHost));
+        *flushes = (int64_t)v;
+    }
+    return HTM_OK;
+}
+
 int htm_chains_handoff_stats(htm_chains *hc, int64_t *orders_put_aside)
 {
     if (!hc || !orders_put_aside) return fail(HTM_EINVAL, "NULL argument");
@@ -1946,6 +1996,20 @@ int htm_chains_handoff_stats(htm_chains *hc, int64_t *orders_put_aside)
 }
 
 #ifdef HTM_STAMPS
+/* diagnostic builds only: the pipelined master's event trace ({time, code << 48 | iteration << 8 | chain} pairs) */
+int htm_chains_read_trace(htm_chains *hc, unsigned long long *out, int n_pairs)
+{
+#ifdef HTM_STAMPS
+    if (!hc || !out || n_pairs > 8192) return fail(HTM_EINVAL, "bad argument");
+    HIPCHK(hipStreamSynchronize(hc->fwd->stream));
+    HIPCHK(hipMemcpy(out, hc->dev.stamps + 128, (size_t)n_pairs * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return HTM_OK;
+#else
+    (void)hc; (void)out; (void)n_pairs;
+    return fail(HTM_ESTATE, "not a diagnostic build");
+#endif
+}
+
 int htm_chains_read_stamps(htm_chains *hc, unsigned long long out[128])
 {
     HIPCHK(hipStreamSynchronize(hc->fwd->stream));

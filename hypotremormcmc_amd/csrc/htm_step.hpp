@@ -1611,7 +1611,10 @@ __device__ __forceinline__ void worker_body(FwRef f_, CsRef cs_, unsigned long l
         if (wstamp) cs.stamps[21] += __builtin_amdgcn_s_memrealtime();
 #endif
         {
-            const int type = (int)(s_job[0] & 7u), idx = (int)(s_job[0] >> 3);
+            // (bit 31 of the order word: an order of the pipelined master, htm_pipe.hpp -- no commit is named, and the word after
+            // it names a SECOND event the workers leave out)
+            const bool pipe_order = (s_job[0] >> 31) != 0u;
+            const int type = (int)(s_job[0] & 7u), idx = (int)((s_job[0] & 0x7fffffffu) >> 3);
             const double ov_val = __longlong_as_double((long long)(((unsigned long long)s_job[1] << 32) | s_job[2]));
             // vs and qs of the evaluated model: chain state unless they are the proposal (same round of loads as
             // the corrections and the event coordinates below)
@@ -1623,6 +1626,39 @@ __device__ __forceinline__ void worker_body(FwRef f_, CsRef cs_, unsigned long l
             int ov_kind = 0, ov_idx = -1, ov_evt = -1, ov_cmp = 0;
             const int r_off = (int)s_job[6] - 1 - (go.hy + m * go.nh);
             const int r_evt = s_job[6] ? r_off / 3 : -1;       // two-ahead orders: the event left to the chain's own wave
+            const int r_off2 = (int)s_job[4] - 1 - (go.hy + m * go.nh);
+            const int r_evt2 = (pipe_order && s_job[4]) ? r_off2 / 3 : -1;
+            // An order of the pipelined master: the wave that holds a left-out event evaluates it at BOTH candidate positions --
+            // where the state has it, and with the component that the hypocentre step in between proposes (its value comes in
+            // tagged granules beside the order) -- under this order's parameters, and reports the two sums on their own: the
+            // master adds the one that step's decision selects (htm_pipe.hpp).
+            unsigned long long lgv0 = 0, lgv1 = 0, lgv2 = 0, lgv3 = 0;
+            if (pipe_order && (r_evt >= 0 || r_evt2 >= 0)) {
+                const unsigned long long *lgi = cs.lo_gran + (size_t)m * 16;
+                lgv0 = ld_agent(lgi); lgv1 = ld_agent(lgi + 1); lgv2 = ld_agent(lgi + 2); lgv3 = ld_agent(lgi + 3);
+            }
+            auto leftout = [&](const auto &ob_, double x, double y, double z, int e, const auto &st_, double rb_, double ka_) __attribute__((always_inline)) {
+                if constexpr (NCH > 0) {
+                    const int k = (e == r_evt) ? 0 : 1;
+                    const int cmpk = k == 0 ? r_off - 3 * r_evt : r_off2 - 3 * r_evt2;
+                    unsigned long long *lg = cs.lo_gran + (size_t)m * 16;
+                    unsigned long long a = k == 0 ? lgv0 : lgv2, b = k == 0 ? lgv1 : lgv3;      // (requested with the order's state loads)
+                    for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+                        if ((unsigned)(a >> 32) == tag && (unsigned)(b >> 32) == tag) break;
+                        __builtin_amdgcn_s_sleep(1);
+                        a = ld_agent(lg + 2 * k); b = ld_agent(lg + 2 * k + 1);
+                    }
+                    if ((unsigned)(a >> 32) != tag || (unsigned)(b >> 32) != tag) return;      // (never seen: the master's collector reports the unanswered order)
+                    const double xn = gran_f64(a, b);
+                    const double px[2] = {x, cmpk == 0 ? xn : x};
+                    const double py[2] = {y, cmpk == 1 ? xn : y};
+                    const double pz[2] = {z, cmpk == 2 ? xn : z};
+                    double o2[2];
+                    event_misfit<(NCH > 0 ? NCH : 1), 2, F32, true>(f, ob_, lane, st_, px, py, pz, rb_, ka_, o2);
+                    wave_sum<2>(o2);
+                    if (lane == 0) { st_gran_f64(lg + 8 + 4 * k, tag, o2[0]); st_gran_f64(lg + 8 + 4 * k + 2, tag, o2[1]); }
+                }
+            };
             if (type == 2 || type == 4) { ov_kind = type; ov_idx = idx; }
             else if (type >= 5) { ov_evt = idx / 3; ov_cmp = idx - 3 * ov_evt; }
             const double *hyp = cs.xall + go.hy + (size_t)m * go.nh;
@@ -1660,9 +1696,12 @@ __device__ __forceinline__ void worker_body(FwRef f_, CsRef cs_, unsigned long l
                         const double py[1] = {ey};
                         const double pz[1] = {ez};
                         double out[1];
-                        event_misfit<NCH, 1, F32, true>(f, ob_cur, lane, st, px, py, pz, rbeta_j, katt_j, out);
-                        // two-ahead order: the event of the step in between is left to the chain's own wave (it may be mid-commit)
-                        lane_acc += (ev == r_evt) ? 0.0 : out[0];
+                        if (__builtin_expect(pipe_order && (ev == r_evt || ev == r_evt2), 0)) leftout(ob_cur, cx, cy, cz, ev, st, rbeta_j, katt_j);
+                        else {
+                            event_misfit<NCH, 1, F32, true>(f, ob_cur, lane, st, px, py, pz, rbeta_j, katt_j, out);
+                            // two-ahead order: the event of the step in between is left to the chain's own wave (it may be mid-commit)
+                            lane_acc += (ev == r_evt) ? 0.0 : out[0];
+                        }
                         ob_cur = ob_nxt; cx = nx; cy = ny; cz = nz;
                     }
                 } else {
@@ -1689,9 +1728,12 @@ __device__ __forceinline__ void worker_body(FwRef f_, CsRef cs_, unsigned long l
                         const double py[1] = {ey};
                         const double pz[1] = {ez};
                         double out[1];
-                        event_misfit<NCH, 1, F32, true>(f, b, lane, st, px, py, pz, rbeta_j, katt_j, out);
-                        // two-ahead order: the event of the step in between is left to the chain's own wave (it may be mid-commit)
-                        lane_acc += (e == r_evt) ? 0.0 : out[0];
+                        if (__builtin_expect(pipe_order && (e == r_evt || e == r_evt2), 0)) leftout(b, x, y, z, e, st, rbeta_j, katt_j);
+                        else {
+                            event_misfit<NCH, 1, F32, true>(f, b, lane, st, px, py, pz, rbeta_j, katt_j, out);
+                            // two-ahead order: the event of the step in between is left to the chain's own wave (it may be mid-commit)
+                            lane_acc += (e == r_evt) ? 0.0 : out[0];
+                        }
                     };
                     int ev = ev0;
                     if (ev < f.E) {

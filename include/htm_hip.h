@@ -273,6 +273,13 @@ int htm_chains_last_run_stats(htm_chains *hc, double *device_us, int *graph_laun
  * back themselves; the other worker blocks behave alike).  Synchronises with the handle's stream. */
 int htm_chains_handoff_stats(htm_chains *hc, int64_t *orders_put_aside);
 
+/* Which main loop the single-rank / lock-step launches of this chain set run on, and the health of its speculation:
+ * *single_rank_loop / *lockstep_loop = 5 / 6 the pipelined master (csrc/htm_pipe.hpp), 3 / 4 the free-running chain master
+ * (csrc/htm_flow.hpp), 0 / 2 the loop with workgroup barriers, -1 the two-kernel path; *flushes = how often the pipelined
+ * master threw its speculative records away since the chain set was created (rare at production sizes).  No reference
+ * counterpart (diagnostics).  Synchronises with the handle's stream. */
+int htm_chains_master_stats(htm_chains *hc, int *single_rank_loop, int *lockstep_loop, int64_t *flushes);
+
 /* Same work as htm_chains_run, but every kernel is launched eagerly and bracketed by its own pair of HIP
  * events on the handle's stream, so that the average duration of each kernel comes from the run itself:
  * k_step (proposals + partial updates + judge + swap; may cover several iterations per launch) and k_full
