@@ -172,6 +172,7 @@ struct htm_chains {
     long blocks_fit = 0;                       // resident blocks of a k_mcmc launch on this device (htm_chains_share_gpu)
     bool flow_lock = false;                    // lock-step ranks (MODE_LOCKRUN) on the free-running master too
     bool pipe = false;                         // single-rank loop on the pipelined master (htm_pipe.hpp)
+    bool pipe_lock = false;                    // lock-step ranks (MODE_LOCKRUN) on it too
     size_t pipe_smem = 0; int pipe_ring = 512; // its LDS size and stream window
     bool ctrl_fresh = false;                   // h_ctrl is the device's control block as of an idle stream (no launch since it was read)
     ChainsDev dev_np{};                        // view for the non-persistent kernels (partial sums per k_full tile)
@@ -244,7 +245,14 @@ int launch_mcmc(htm_chains *hc, int mode, int target, const double *gathered)
     // one instantiation per main loop: the single-rank loop, one lock-step iteration per launch, persistent lock-step
     if (mode == MODE_RUN && hc->pipe) {
         // the pipelined master (htm_pipe.hpp): one or two stations per lane only
-#define HTM_LAUNCH_PIPE(N, F) hipLaunchKernelGGL((k_mcmc<N, F, 5>), grid, block, hc->pipe_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->pipe_ring, hc->wmax, seq)
+#define HTM_LAUNCH_PIPE(N, F) hipLaunchKernelGGL((k_mcmc<N, F, 5>), grid, dim3(mcmc_threads<N, 5>()), hc->pipe_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->pipe_ring, hc->wmax, seq)
+        if (h->dev.fp32) { if (h->nch == 1) HTM_LAUNCH_PIPE(1, true); else HTM_LAUNCH_PIPE(2, true); }
+        else if (h->nch == 1) HTM_LAUNCH_PIPE(1, false);
+        else HTM_LAUNCH_PIPE(2, false);
+#undef HTM_LAUNCH_PIPE
+    }
+    else if (mode == MODE_LOCKRUN && hc->pipe_lock) {
+#define HTM_LAUNCH_PIPE(N, F) hipLaunchKernelGGL((k_mcmc<N, F, 6>), grid, dim3(mcmc_threads<N, 6>()), hc->pipe_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->pipe_ring, hc->wmax, seq)
         if (h->dev.fp32) { if (h->nch == 1) HTM_LAUNCH_PIPE(1, true); else HTM_LAUNCH_PIPE(2, true); }
         else if (h->nch == 1) HTM_LAUNCH_PIPE(1, false);
         else HTM_LAUNCH_PIPE(2, false);
@@ -966,19 +974,39 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
             int ring = 512;
             while (ring < 2 * wdp + 160) ring *= 2;
             const size_t mirp = 2 * (size_t)nc + 2 * (size_t)nc * h->S;
-            const size_t smem = ((sizeof(PipeShared) + 15) & ~size_t(15)) + (size_t)ring * lds_pos + 3 * (size_t)h->S * sizeof(double) +
+            const size_t smem = ((sizeof(PipeShared) + 15) & ~size_t(15)) + (size_t)ring * lds_pos + (3 * (size_t)h->S + kGathStage) * sizeof(double) +
                                 mirp * sizeof(double) + pipe_ring_bytes(nc);
-            hc->pipe = hc->persist && d.n_procs == 1 && !(ep && ep[0] == '0') && d.dbg == 0 && (h->nch == 1 || h->nch == 2) && smem <= lds_cap &&
-                       hc->dev.mirror_n == (int)mirp;      // (the mirror is part of every loop's LDS layout: one size for all)
-            if (hc->pipe) {
+            // (opt-in, HTM_PIPE=1 / HTM_PIPE_LOCK=1: on one CU it matches the free-running master -- 4.8 us per iteration at 1000 x 64 x 8,
+            // +8 % at 16 chains, profiles/r04_pipe_*.txt -- and does not beat it; DESIGN.md 3.6 says what it is for)
+            const char *epl = getenv("HTM_PIPE_LOCK");
+            const bool usable = hc->persist && d.dbg == 0 && (h->nch == 1 || h->nch == 2) && smem <= lds_cap &&
+                                hc->dev.mirror_n == (int)mirp;      // (the mirror is part of every loop's LDS layout: one size for all)
+            hc->pipe = usable && d.n_procs == 1 && ep && ep[0] == '1';
+            hc->pipe_lock = usable && epl && epl[0] == '1' &&
+                            (size_t)d.n_procs * (4 + 2 * (size_t)nc) <= (size_t)kGathStage;      // (MODE_LOCKRUN: any number of ranks)
+            if (hc->pipe || hc->pipe_lock) {
                 hc->pipe_smem = smem; hc->pipe_ring = ring;
-                const void *pfn = h->dev.fp32 ? (h->nch == 1 ? (const void *)k_mcmc<1, true, 5> : (const void *)k_mcmc<2, true, 5>)
-                                  : (h->nch == 1 ? (const void *)k_mcmc<1, false, 5> : (const void *)k_mcmc<2, false, 5>);
-                int pc = 0, n_cu2 = 0;
-                if (smem > 48 * 1024) HIPCHK(hipFuncSetAttribute(pfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-                HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, pfn, 512, smem));
+                int n_cu2 = 0;
                 HIPCHK(hipDeviceGetAttribute(&n_cu2, hipDeviceAttributeMultiprocessorCount, h->device));
-                if ((long)pc * n_cu2 - 1 < hc->dev.n_workers) hc->pipe = false;      // (the launch shape was sized for the other loops: keep it)
+                const int pthreads = h->nch == 1 ? mcmc_threads<1, 5>() : 512;
+                if (pthreads == 768) {
+                    // (12-wave blocks: a worker block takes 12 events; every loop of this chain set then runs with this many blocks)
+                    int nw = worker_blocks(h->E, 12, hc->worker_cap);
+                    if (const char *e3 = getenv("HTM_MAX_WORKERS")) nw = std::max(1, std::min(nw, atoi(e3)));
+                    if (const char *e4 = getenv("HTM_RANKS_PER_GPU")) { const int k = atoi(e4); if (k > 1) nw = std::min<long>(nw, std::max<long>(1, hc->blocks_fit / k - 1)); }
+                    hc->dev.n_workers = std::min(hc->dev.n_workers, nw); hc->dev.n_wg = hc->dev.n_workers;
+                }
+                for (int lk = 5; lk <= 6; ++lk) {
+                    const void *pfn = lk == 5 ? (h->dev.fp32 ? (h->nch == 1 ? (const void *)k_mcmc<1, true, 5> : (const void *)k_mcmc<2, true, 5>)
+                                                            : (h->nch == 1 ? (const void *)k_mcmc<1, false, 5> : (const void *)k_mcmc<2, false, 5>))
+                                              : (h->dev.fp32 ? (h->nch == 1 ? (const void *)k_mcmc<1, true, 6> : (const void *)k_mcmc<2, true, 6>)
+                                                            : (h->nch == 1 ? (const void *)k_mcmc<1, false, 6> : (const void *)k_mcmc<2, false, 6>));
+                    int pc = 0;
+                    if (smem > 48 * 1024) HIPCHK(hipFuncSetAttribute(pfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, pfn, pthreads, smem));
+                    hc->blocks_fit = std::min<long>(hc->blocks_fit, (long)pc * n_cu2);
+                    if ((long)pc * n_cu2 - 1 < hc->dev.n_workers) { if (lk == 5) hc->pipe = false; else hc->pipe_lock = false; }      // (the launch shape was sized for the other loops: keep it)
+                }
             }
         }
     }
@@ -1975,7 +2003,7 @@ int htm_chains_master_stats(htm_chains *hc, int *single_rank_loop, int *lockstep
 {
     if (!hc) return fail(HTM_EINVAL, "NULL argument");
     if (single_rank_loop) *single_rank_loop = !hc->persist ? -1 : hc->pipe ? 5 : hc->flow ? 3 : 0;
-    if (lockstep_loop) *lockstep_loop = !hc->persist ? -1 : hc->flow_lock ? 4 : 2;
+    if (lockstep_loop) *lockstep_loop = !hc->persist ? -1 : hc->pipe_lock ? 6 : hc->flow_lock ? 4 : 2;
     if (flushes) {
         HIPCHK(hipStreamSynchronize(hc->fwd->stream));
         unsigned long long v = 0;

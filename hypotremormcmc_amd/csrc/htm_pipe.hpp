@@ -39,7 +39,7 @@
 namespace htm {
 
 constexpr int kPipeSlots = 8;     // iterations in the slot ring
-constexpr int kPipeAhead = 3;     // F produces iteration it only when it <= decided + kPipeAhead   (kPipeSlots >= kPipeAhead + 2 + 2)
+constexpr int kPipeAhead = 6;     // F produces iteration it only when it <= decided + kPipeAhead   (kPipeSlots >= kPipeAhead + 2)
 constexpr int kPipeLog = 8;       // commits per chain D remembers
 
 enum { PI_POS, PI_TYPE, PI_IDX, PI_EVT, PI_O, PI_CNT, PI_SEQ, PI_KIND, PI_LO1, PI_LO2, PI_N };
@@ -64,6 +64,8 @@ struct PipeShared : StepShared {
     int landed_it;                // the commits of iterations <= landed_it have landed in memory
     int f_it;                     // F has produced iterations <= f_it (in the current epoch)
     int f_stop_it;                // F cannot produce this iteration (end of the produced stream); 0 = none
+    int win_fill, win_want, win_lo;   // the LDS window of the stream rings holds [.., win_fill); F asks for [.., win_want); positions < win_lo are dead (C extends it)
+    int win_seq, win_ack;             // F went BACK (a flush): it reads the window again only when C has seen the new win_lo
     int quit;
     int i0;
     int pver[kMaxChains];         // parameter version of the chain (odd: a commit is being written)
@@ -214,7 +216,14 @@ __device__ __forceinline__ void pipe_front_adopt(CsRef cs_, PipeShared &sh, cons
     const int nc = cs.n_chains;
     F.epoch = e;
     F.it = lds_ld(&sh.fl_it); F.B = lds_ld(&sh.fl_base);
-    if (F.B < F.lo) { F.fill = F.B; F.lo = F.B; }        // (the ring has moved past it: fetched again)
+    // The restart position lies BEHIND where F was: the collector, which extends the window, may be overwriting exactly those
+    // ring positions (it took them for dead).  It is told, and F reads the window again only when it has answered -- nothing
+    // checks a decoded proposal against the stream, so F must never read a position that is being replaced.
+    if (lane == 0) { lds_st(&sh.win_lo, F.B); lds_st(&sh.win_seq, lds_ld(&sh.win_seq) + 1); }
+    while (lds_ld(&sh.win_ack) != lds_ld(&sh.win_seq)) {
+        if (lds_ld(&sh.quit) != 0 || sh.c.err != 0) break;
+        __builtin_amdgcn_s_sleep(2);
+    }
     const bool in = lane < nc;
     const int c = in ? lane : 0;
     // kinds and events of the two steps before: decided iterations, their slots are intact
@@ -261,12 +270,28 @@ __device__ __forceinline__ void pipe_issue(CsRef cs_, PipeShared &sh, const Ring
     }
 }
 
+// judge_swap's draw of the swap found at E (cls_parallel.f90:163, :292-299) as this rank's stream has it: a single rank draws it
+// right after the pair; a lock-step rank PEEKS at the draw it would take if the pair's first chain were its own (rank 0
+// knows: then it is the last of the nd draws) -- what goes into the rank's swap record (htm_step.hpp, exchange_post)
+template <bool LOCK>
+__device__ __forceinline__ void pipe_judge_draw(CsRef cs, const Ring &rg, int E, int i1, int nd, double &sr, double &slr)
+{
+    sr = 0.0; slr = 0.0;
+    if constexpr (LOCK) {
+        const int own = (cs.rank == 0 && i1 >= 0 && i1 / cs.n_chains == 0) ? 1 : 0;
+        const int jp = E + nd - own;
+        sr = rg.U[jp & rg.mask]; slr = rg.LOGU[jp & rg.mask];
+    } else if (nd > 0) {
+        sr = rg.U[(E + nd - 1) & rg.mask]; slr = rg.LOGU[(E + nd - 1) & rg.mask];
+    }
+}
+
 // one iteration's proposal records from the inputs requested for it (lanes <-> chains); returns where the next iteration starts
 template <bool LOCK>
 __device__ __forceinline__ int pipe_finish(CsRef cs_, PipeShared &sh, const Ring &rg, const PipeRings &pr, PipeFront &F, PipeLoads &L, int lane)
 {
     CsRef cs = rebase(cs_);
-    const int nc = cs.n_chains, M = rg.mask;
+    const int nc = cs.n_chains;
     const bool in = lane < nc;
     const int c = in ? lane : 0;
     const int it = F.it, B = F.B;
@@ -306,7 +331,7 @@ __device__ __forceinline__ int pipe_finish(CsRef cs_, PipeShared &sh, const Ring
     double sr = F.ssr, slr = F.sslr;
     if (__builtin_expect(E_end != F.sE, 0)) {
         flow_swap_at(cs, sh, rg, E_end, 1 << 30, i1, i2, nd);
-        sr = nd > 0 ? rg.U[(E_end + nd - 1) & M] : 0.0; slr = nd > 0 ? rg.LOGU[(E_end + nd - 1) & M] : 0.0;
+        pipe_judge_draw<LOCK>(cs, rg, E_end, i1, nd, sr, slr);
     }
     const int s = it & (kPipeSlots - 1);
     const int kind = !ok ? 0 : (L.evt > 0 && it > 1) ? 1 : 2;           // hypo_tremor_mcmc.f90:246
@@ -363,45 +388,43 @@ __device__ __forceinline__ void pipe_front(CsRef cs_, PipeShared &sh, const Ring
     L0.P = 0; L0.type = 5; L0.idx = 0; L0.evt = 1; L0.o = 0; L0.gnx = 1; L0.snap = 0; L0.decw = 6;
     L0.g = 0.0; L0.r = 0.0; L0.logr = 0.0; L0.x_old = 0.0; L0.hx = 0.0; L0.hy = 0.0; L0.hz = 0.0; L0.pv = f64x4{0.0, 1.0, 0.0, 0.0};
     L1 = L0;
-    bool have0 = false;
+    bool have = false;               // the current buffer holds the inputs of iteration F.it, requested at F.B
 #ifdef HTM_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_last = __builtin_amdgcn_s_memtime();
 #endif
     __builtin_amdgcn_s_setprio(1);
-    for (;;) {
-        if (lds_ld(&sh.quit) != 0) break;
+    // one pass of the loop with La = the current iteration's inputs, Lb = the buffer the next iteration's are requested into.
+    // The two buffers swap roles after every published iteration (the loop below is unrolled by two): copying loaded values from
+    // one to the other would wait for the loads just issued.  Returns 0: leave, 1: nothing published, 2: published.
+    auto pass = [&](PipeLoads &La, PipeLoads &Lb) __attribute__((always_inline)) -> int {
+        if (lds_ld(&sh.quit) != 0) return 0;
         const int e = lds_ld(&sh.epoch);
-        if (e != F.epoch) { pipe_front_adopt(cs, sh, pr, F, e, lane); have0 = false; }
+        if (e != F.epoch) { pipe_front_adopt(cs, sh, pr, F, e, lane); have = false; }
+        // the stream window: kept three iterations ahead of F.B by the collector wave (positions before F.B are dead)
+        F.fill = lds_ld(&sh.win_fill);
+        if (lane == 0) { lds_st(&sh.win_lo, F.B); lds_st(&sh.win_want, min(F.B + 3 * wd + 96, sh.avail)); }
         const int dd = lds_ld(&sh.d_done);
         const int target = sh.c.iter_target;
-        if (!(F.it <= dd + kPipeAhead && F.it <= target && lds_ld(&sh.f_stop_it) == 0)) {
+        if (!(F.it <= dd + kPipeAhead && F.it <= target && lds_ld(&sh.f_stop_it) == 0 && __ballot(in && F.p2 != 0) == 0ull)) {
             pipe_orders(cs, sh, pr, F, lane, launch);
             // (not allowed to publish yet: the iteration's inputs are requested meanwhile)
-            if (!have0 && F.it <= target && F.B + wd + 16 <= min(F.fill, sh.avail)) {
-                L0.P = pipe_hops(rg, F.B, c, rounds);
-                pipe_issue(cs, sh, rg, L0, c, in);
-                have0 = true; F.sE = -1;
+            if (!have && F.it <= target && F.B + wd + 16 <= min(F.fill, sh.avail) && F.B >= F.fill - (rg.mask + 1)) {
+                La.P = pipe_hops(rg, F.B, c, rounds);
+                pipe_issue(cs, sh, rg, La, c, in);
+                have = true; F.sE = -1;
             }
             __builtin_amdgcn_s_sleep(2);
             PSTAMP(1);
-            continue;
+            return 1;
         }
-        if (!have0) {
-            if (F.B + wd + 16 > sh.avail) { if (lane == 0) lds_st(&sh.f_stop_it, F.it); continue; }      // the produced stream ends here: D stops the launch before it
-            pipe_window(cs, sh, rg, F, F.B + wd + 16, lane);
-            L0.P = pipe_hops(rg, F.B, c, rounds);
-            pipe_issue(cs, sh, rg, L0, c, in);
-            have0 = true; F.sE = -1;
+        if (!have) {
+            if (F.B + wd + 16 > sh.avail) { if (lane == 0) lds_st(&sh.f_stop_it, F.it); return 1; }      // the produced stream ends here: D stops the launch before it
+            if (F.B + wd + 16 > F.fill || F.B < F.fill - (rg.mask + 1)) { __builtin_amdgcn_s_sleep(2); return 1; }      // (the window is on its way)
+            La.P = pipe_hops(rg, F.B, c, rounds);
+            pipe_issue(cs, sh, rg, La, c, in);
+            have = true; F.sE = -1;
             PCOUNT(4);
-        }
-        // one round of the stream window, in flight under this iteration's work (positions before F.B are dead)
-        PfRegs pf;
-        pf.p = -1;
-        int pf_to = F.fill;
-        if (F.fill < F.B + 3 * wd + 32 && F.fill < sh.avail) {
-            pf_to = min(min(F.fill + 64, sh.avail), F.B + rg.mask + 1 - 8);
-            if (pf_to > F.fill) pf_load(pf, cs, sh, F.fill + lane, pf_to);
         }
         // the next iteration, where the stream predicts it
         bool have1 = false;
@@ -411,27 +434,35 @@ __device__ __forceinline__ void pipe_front(CsRef cs_, PipeShared &sh, const Ring
             if (F.sE < 0) {
                 F.sE = pipe_hops(rg, F.B, nc, rounds);
                 flow_swap_at(cs, sh, rg, F.sE, 1 << 30, F.si1, F.si2, F.snd);
-                F.ssr = F.snd > 0 ? rg.U[(F.sE + F.snd - 1) & rg.mask] : 0.0; F.sslr = F.snd > 0 ? rg.LOGU[(F.sE + F.snd - 1) & rg.mask] : 0.0;
+                pipe_judge_draw<LOCK>(cs, rg, F.sE, F.si1, F.snd, F.ssr, F.sslr);
             }
             Bp = F.sE + F.snd;
-            if (F.it + 1 <= target && Bp + wd + 16 <= min(F.fill, sh.avail)) {
-                L1.P = pipe_hops(rg, Bp, c, rounds);
-                pipe_issue(cs, sh, rg, L1, c, in);
+            if (F.it + 1 <= target && Bp + wd + 16 <= min(F.fill, sh.avail) && F.B >= F.fill - (rg.mask + 1)) {
+                Lb.P = pipe_hops(rg, Bp, c, rounds);
+                pipe_issue(cs, sh, rg, Lb, c, in);
                 have1 = true;
                 // (and the same for the iteration after: where ITS steps end if every prior is ok)
                 nE = pipe_hops(rg, Bp, nc, rounds);
                 flow_swap_at(cs, sh, rg, nE, 1 << 30, ni1, ni2, nnd);
-                nsr = nnd > 0 ? rg.U[(nE + nnd - 1) & rg.mask] : 0.0; nslr = nnd > 0 ? rg.LOGU[(nE + nnd - 1) & rg.mask] : 0.0;
+                pipe_judge_draw<LOCK>(cs, rg, nE, ni1, nnd, nsr, nslr);
             }
         }
-        pipe_orders(cs, sh, pr, F, lane, launch);
-        const int Bn = pipe_finish<LOCK>(cs, sh, rg, pr, F, L0, lane);
-        if (pf_to > F.fill) { pf_store(pf, rg); F.fill = pf_to; F.lo = max(F.lo, F.fill - (rg.mask + 1)); }
-        if (have1 && Bn == Bp) { L0 = L1; have0 = true; F.sE = nE; F.si1 = ni1; F.si2 = ni2; F.snd = nnd; F.ssr = nsr; F.sslr = nslr; }
-        else { have0 = false; F.sE = -1; }
-        PSTAMP(0); PCOUNT(2);
+        PSTAMP(5);
         pipe_orders(cs, sh, pr, F, lane, launch);
         PSTAMP(3);
+        const int Bn = pipe_finish<LOCK>(cs, sh, rg, pr, F, La, lane);
+        PSTAMP(6);
+        if (have1 && Bn == Bp) { have = true; F.sE = nE; F.si1 = ni1; F.si2 = ni2; F.snd = nnd; F.ssr = nsr; F.sslr = nslr; }
+        else { have = false; F.sE = -1; }
+        PSTAMP(7); PCOUNT(2);
+        pipe_orders(cs, sh, pr, F, lane, launch);
+        PSTAMP(3);
+        return 2;
+    };
+    for (int cur = 0;;) {
+        const int r = cur == 0 ? pass(L0, L1) : pass(L1, L0);
+        if (r == 0) break;
+        if (r == 2) cur ^= 1;
     }
     if (lane == 0) sh.c.jobs_total = F.jobs;
 #ifdef HTM_STAMPS
@@ -514,12 +545,15 @@ __device__ __forceinline__ void pipe_evaluator(FwRef f_, CsRef cs_, PipeShared &
     // look at a taken task if its iteration's records are there: a single-event update has its rows requested
     auto look = [&](PipeTask<N, F32> &T) __attribute__((always_inline)) {
         const int s = T.it & (kPipeSlots - 1);
-        if (lds_ld(&sh.hdr[s].tag) != pipe_tag(T.te, T.it)) return;
+        // (the tag and, in the same batch, what it covers: used only if the tag is the iteration's)
+        const int tg = lds_ld(&sh.hdr[s].tag);
+        const int kdv = pr.I(s, PI_KIND, T.c), idv = pr.I(s, PI_IDX, T.c), evv = pr.I(s, PI_EVT, T.c);
+        const double xn = pr.D(s, PD_XNEW, T.c), hx = pr.D(s, PD_HX, T.c), hy = pr.D(s, PD_HY, T.c), hz = pr.D(s, PD_HZ, T.c);
+        if (tg != pipe_tag(T.te, T.it)) return;
         T.seen = true;
-        const int kind = uni(pr.I(s, PI_KIND, T.c)) & 15;
-        if (kind != 1) return;                  // (prior rejected: nothing to evaluate; full evaluation: the collector's)
-        T.idx = uni(pr.I(s, PI_IDX, T.c)); T.evt = uni(pr.I(s, PI_EVT, T.c));
-        T.x_new = pr.D(s, PD_XNEW, T.c); T.hx = pr.D(s, PD_HX, T.c); T.hy = pr.D(s, PD_HY, T.c); T.hz = pr.D(s, PD_HZ, T.c);
+        if ((uni(kdv) & 15) != 1) return;        // (prior rejected: nothing to evaluate; full evaluation: the collector's)
+        T.idx = uni(idv); T.evt = uni(evv);
+        T.x_new = xn; T.hx = hx; T.hy = hy; T.hz = hz;
         load_obs_regs<N, F32>(T.ob, f, T.evt - 1, lane);
         T.live = true;
     };
@@ -565,22 +599,46 @@ __device__ __forceinline__ void pipe_evaluator(FwRef f_, CsRef cs_, PipeShared &
         PTRACE(3, it, c);
         const int s = it & (kPipeSlots - 1), want = pipe_tag(te, it), bank = te & 1;
         const int ev = cur.evt - 1, cmp = cur.idx - 3 * ev;
-        double rb, ka, beta, q;
-        int dep = 0, pv = 0;
+        double rb = 0.0, ka = 0.0, beta = 0.0, q = 0.0;
+        int dep = 0, pv = 0, d_type = 0, d_idx = 0;
+        double d_xn = 0.0;
         bool live = true;
-        // (the chain's steps of the three iterations before: F is never further ahead of the decisions)
-        const int kb1 = pr.I((it - 1) & (kPipeSlots - 1), PI_KIND, c), kb2 = pr.I((it - 2) & (kPipeSlots - 1), PI_KIND, c), kb3 = pr.I((it - 3) & (kPipeSlots - 1), PI_KIND, c);
-        const bool f1 = (uni(kb1) & 15) == 2, f2 = (uni(kb2) & 15) == 2, f3 = (uni(kb3) & 15) == 2;
+        const double *tcp = rg.mx + nc + c * S_, *acp = rg.mx + 2 * nc + nc * S_ + c * S_;
         for (;;) {
+            // Everything the evaluation needs besides the record, requested in ONE batch (LDS operations of a wave execute in
+            // order, so the sequence lock's two reads bracket the data between them): the decisions' progress, the kinds of the
+            // chain's steps of the iterations before (as far back as F can be ahead of the decisions), the parameter version, the
+            // chain's corrections and its two reciprocals, the version again.
+            const int dd = lds_ld(&sh.d_done);
+            int kb[kPipeAhead - 1];
+#pragma unroll
+            for (int j = 0; j < kPipeAhead - 1; ++j) kb[j] = pr.I((it - 1 - j) & (kPipeSlots - 1), PI_KIND, c);
+            const int p1 = lds_ld(&sh.pver[c]);
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                const int j = lane + 64 * k;
+                st.tc[k] = j < S_ ? tcp[j] : 0.0; st.ac[k] = j < S_ ? acp[j] : 0.0;
+            }
+            rb = sh.rbeta[c]; ka = sh.katt[c]; beta = rg.mx[c]; q = rg.mx[nc + nc * S_ + c];
+            asm volatile("" ::: "memory");
+            const int p2 = lds_ld(&sh.pver[c]);
             // undecided full-evaluation steps of this chain before this one: none -> one evaluation; one -> a second one
             // under its proposal; more -> wait
-            const int dd = lds_ld(&sh.d_done);
-            const bool u1 = f1 && it - 1 > dd, u2 = f2 && it - 2 > dd, u3 = f3 && it - 3 > dd;
-            const int ndep = (u1 ? 1 : 0) + (u2 ? 1 : 0) + (u3 ? 1 : 0);
-            dep = u1 ? it - 1 : u2 ? it - 2 : u3 ? it - 3 : 0;
-            if (ndep <= 1) {
-                pv = pipe_params<N>(sh, rg, S_, nc, c, lane, st, rb, ka, beta, q);
-                if (dep == 0 || lds_ld(&sh.d_done) == dd) break;
+            unsigned fullm = 0;
+#pragma unroll
+            for (int j = 0; j < kPipeAhead - 1; ++j) fullm |= ((uni(kb[j]) & 15) == 2) ? (1u << j) : 0u;
+            const int nund = it - 1 - dd;                                   // iterations it - 1 .. dd + 1 are undecided
+            const unsigned um = nund <= 0 ? 0u : (fullm & ((nund >= 32 ? ~0u : ((1u << nund) - 1u))));
+            const int ndep = __popc(um);
+            dep = um ? it - 1 - (__ffs((int)um) - 1) : 0;
+            pv = p1;
+            if (ndep <= 1 && !(p1 & 1) && p1 == p2) {
+                if (dep == 0) break;
+                // (that step's proposal, read while the step is still undecided -- its slot cannot have been taken over --: checked by
+                // reading the decisions' progress again)
+                const int sd = dep & (kPipeSlots - 1);
+                d_type = uni(pr.I(sd, PI_TYPE, c)); d_idx = uni(pr.I(sd, PI_IDX, c)); d_xn = pr.D(sd, PD_XNEW, c);
+                if (lds_ld(&sh.d_done) == dd) break;
             }
             if (lds_ld(&sh.epoch) != te || lds_ld(&sh.quit) != 0) { live = false; break; }
             __builtin_amdgcn_s_sleep(2);
@@ -594,8 +652,7 @@ __device__ __forceinline__ void pipe_evaluator(FwRef f_, CsRef cs_, PipeShared &
             const double dA = wave_sum1(out[0] - out[1]);
             double dB = 0.0;
             if (dep) {
-                const int sd = dep & (kPipeSlots - 1);
-                pipe_apply<N>(uni(pr.I(sd, PI_TYPE, c)), uni(pr.I(sd, PI_IDX, c)), pr.D(sd, PD_XNEW, c), lane, st, rb, ka, beta, q);
+                pipe_apply<N>(d_type, d_idx, d_xn, lane, st, rb, ka, beta, q);
                 event_misfit<N, 2, F32, true>(f, cur.ob, lane, st, px, py, pz, rb, ka, out);
                 dB = wave_sum1(out[0] - out[1]);
             }
@@ -626,6 +683,7 @@ __device__ __forceinline__ void pipe_collector(FwRef f_, CsRef cs_, PipeShared &
     const int nc = cs.n_chains;
     const bool in = lane < nc;
     const int c = in ? lane : 0;
+    int w_fill = sh.fill, w_ack = 0;     // the window holds the stream positions [w_fill - ring, w_fill)
     int seen_w = 0;                      // per lane: the order of the chain C has started to watch
     unsigned t_seen = 0;                 // per lane: since when (100 MHz clock, low word)
 #ifdef HTM_STAMPS
@@ -635,6 +693,23 @@ __device__ __forceinline__ void pipe_collector(FwRef f_, CsRef cs_, PipeShared &
     (void)f_; (void)s_sx; (void)s_sy; (void)s_sz;
     for (;;) {
         if (lds_ld(&sh.quit) != 0 || sh.c.err != 0) break;
+        // ---- the LDS window of the stream rings, on F's request: 64 positions per round, never over positions F still reads
+        {
+            const int sq = lds_ld(&sh.win_seq);
+            const int lo = lds_ld(&sh.win_lo), want = lds_ld(&sh.win_want);
+            // (F went back -- a flush -- behind what the ring still holds: from there again; F sees that it is not covered)
+            if (lo < w_fill - (rg.mask + 1)) { w_fill = lo; if (lane == 0) lds_st(&sh.win_fill, w_fill); }
+            const int to = min(min(w_fill + 64, want), lo + rg.mask + 1 - 8);
+            if (to > w_fill) {
+                PfRegs pf;
+                pf_load(pf, cs, sh, w_fill + lane, to);
+                pf_store(pf, rg);
+                w_fill = to;
+                if (lane == 0) lds_st(&sh.win_fill, w_fill);
+            } else if (lds_ld(&sh.win_fill) != w_fill && lane == 0) lds_st(&sh.win_fill, w_fill);
+            // (the window as published now respects the win_lo read above: F may go on)
+            if (sq != w_ack) { w_ack = sq; if (lane == 0) lds_st(&sh.win_ack, sq); }
+        }
         const int w = in ? lds_ld(&sh.col_w[c]) : 0;
         const int ep = lds_ld(&sh.epoch);
         if (w != seen_w) { seen_w = w; t_seen = (unsigned)__builtin_amdgcn_s_memrealtime(); }
@@ -643,7 +718,7 @@ __device__ __forceinline__ void pipe_collector(FwRef f_, CsRef cs_, PipeShared &
         unsigned long long m2 = __ballot(w != 0 && ((unsigned)w >> 24) == ((unsigned)ep & 0xffu));
         PSTAMP(0);
         if (m2 == 0ull) { __builtin_amdgcn_s_sleep(4); PSTAMP(3); continue; }
-        constexpr int kSweep = 4, kOrd = 4;       // <= 256 workers (host-checked)
+        constexpr int kSweep = 4, kOrd = 2;       // <= 256 workers (host-checked)
         unsigned long long hi[kOrd][kSweep], lo[kOrd][kSweep], lg[kOrd];
         int oc[kOrd];
         unsigned otag[kOrd];
@@ -730,7 +805,7 @@ __device__ __forceinline__ void pipe_collector(FwRef f_, CsRef cs_, PipeShared &
 // D: the decider
 // ------------------------------------------------------------------------------------------------------------------
 template <int NCH, bool F32, bool LOCK>
-__device__ __forceinline__ void pipe_decider(FwRef f_, CsRef cs_, PipeShared &sh, const Ring &rg, const PipeRings &pr, int lane, int wmax)
+__device__ __forceinline__ void pipe_decider(FwRef f_, CsRef cs_, PipeShared &sh, const Ring &rg, const PipeRings &pr, double *s_gath, int lane, int wmax)
 {
     CsRef cs = rebase(cs_);
     FwRef f = rebase(f_);
@@ -780,7 +855,10 @@ __device__ __forceinline__ void pipe_decider(FwRef f_, CsRef cs_, PipeShared &sh
                 __builtin_amdgcn_s_sleep(1);
             }
             if (dead) break;
-            if (stop) { last_iter = it - 1; stop_code = 2; break; }
+            if (stop) {
+                if constexpr (LOCK) { if (lane == 0) sh.c.err = -7; dead = true; break; }      // (lock-step ranks leave a launch only together: the stop request comes first)
+                last_iter = it - 1; stop_code = 2; break;
+            }
         }
         PSTAMP(0);
         PTRACE(7, it, 0);
@@ -824,6 +902,29 @@ __device__ __forceinline__ void pipe_decider(FwRef f_, CsRef cs_, PipeShared &sh
             continue;
         }
         // ---- the temperature of this iteration: the swap of the iteration before (cls_parallel.f90:121-136, :285-302)
+        if constexpr (LOCK) {
+            // a lock-step rank: decided from ALL ranks' records (htm_step.hpp, exchange_finish; posted at the end of the iteration
+            // before: their round trip ran under the wait and the checks above).  It may end the job (a rank asked everybody to
+            // stop, or failed) or move this rank's stream (the judge draw was this rank's after all: cls_parallel.f90:163)
+            if (it - 1 > i0) {
+                exchange_finish(cs, sh, s_gath, it - 1, lane, false);
+                if (sh.c.err != 0) { dead = true; break; }
+                if (in) { T = sh.temp[c]; rT = sh.rtemp[c]; }
+                if (sh.c.stop != 0) break;                                 // everybody leaves after iteration it - 1
+                const int base = (int)(sh.c.spos - sh.origin);             // where this iteration really starts
+                if (base != nextB) {
+                    nextB = base;
+                    epoch += 1;
+                    if (lane == 0) {
+                        sh.n_flush += 1;
+                        lds_st(&sh.fl_it, it); lds_st(&sh.fl_base, nextB);
+                        lds_st(&sh.epoch, epoch);
+                        __hip_atomic_exchange(&sh.q, ((unsigned long long)(unsigned)epoch << 32) | (unsigned)((it - i0 - 1) * nc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    continue;
+                }
+            }
+        } else
         if (it - 1 > i0 && n_all > 1) {
             const PipeHdr &hp = sh.hdr[(it - 1) & (kPipeSlots - 1)];
             const int i1 = uni(hp.i1), i2 = uni(hp.i2);
@@ -915,10 +1016,29 @@ __device__ __forceinline__ void pipe_decider(FwRef f_, CsRef cs_, PipeShared &sh
             n_lik += __popcll(ml); n_smp += __popcll(ms);
         }
         rec_phase = rec_phase + 1 == n_int ? 0 : rec_phase + 1;
+        if constexpr (LOCK) {
+            // this rank's swap record: pair (rank 0's select_pair), the pending judge_swap draw (peeked), (T, L) of all its chains,
+            // and whether it asks everybody to stop after this iteration (record buffers or produced stream nearly used up)
+            const PipeHdr &h = sh.hdr[s];
+            const int pi1 = uni(h.i1), pi2 = uni(h.i2), pnd = uni(h.nd), pE = uni(h.E);
+            const int own = (cs.rank == 0 && pi1 >= 0 && pi1 / nc == 0) ? 1 : 0;
+            const int jp = pE + pnd - own;
+            if (in) { sh.xrec[4 + 2 * c] = T; sh.xrec[5 + 2 * c] = L; }
+            const bool my_stop = n_lik + 3 * nc > cap_lik || n_smp + 3 * nc > cap_smp || sh.avail < jp + 4 * wmax;
+            if (lane == 0) {
+                sh.xrec[0] = (double)pi1; sh.xrec[1] = (double)pi2; sh.xrec[2] = h.sr; sh.xrec[3] = (double)it;
+                sh.c.swap_i1 = pi1; sh.c.swap_i2 = pi2; sh.c.swap_r = h.sr; sh.c.swap_logr = h.slr;
+                sh.c.spos = sh.origin + jp;                       // RNG commit: draws consumed so far (apply_swap adds the judge draw if it is ours)
+                sh.c.stage = ST_WAIT_SWAP;
+            }
+            exchange_post(cs, sh, it, lane, my_stop);
+        }
         if (lane == 0) lds_st(&sh.d_done, it);
         PTRACE(8, it, 0);
         // the launch ends here if the record buffers are nearly used up
-        if (__builtin_expect(n_lik + 3 * nc > cap_lik || n_smp + 3 * nc > cap_smp, 0)) { if (it < last_iter) { last_iter = it; stop_code = 1; } }
+        if constexpr (!LOCK) {      // (a lock-step rank asks the others through its record)
+            if (__builtin_expect(n_lik + 3 * nc > cap_lik || n_smp + 3 * nc > cap_smp, 0)) { if (it < last_iter) { last_iter = it; stop_code = 1; } }
+        }
         it += 1;
         PSTAMP(2); PCOUNT(4);
     }
@@ -928,6 +1048,19 @@ __device__ __forceinline__ void pipe_decider(FwRef f_, CsRef cs_, PipeShared &sh
     // ---- end of the launch: the swap of the last iteration, the chain set's state as the next launch (or the host) finds it
     const int last = it - 1;
     if (lane == 0) { sh.c.n_lik = n_lik; sh.c.n_smp = n_smp; }
+    if constexpr (LOCK) {
+        // (a lock-step rank leaves only when the swap of its last iteration has been applied: iteration counter, stream position,
+        // temperatures and the stop word are settled with it)
+        if (!dead && sh.c.err == 0 && last > i0 && sh.c.iter_done < last) exchange_finish(cs, sh, s_gath, last, lane, false);
+        if (sh.c.err == 0) {
+            if (in) cs.L[c] = L;
+            if (lane == 0) {
+                if (slog_cap > 0) sh.c.slog_n = min(slog_cap, slog_n0 + (sh.c.iter_done - i0) * nc);
+                sh.c.n_full_evals += (long long)n_full;
+                sh.c.n_partial_evals += (long long)n_part;
+            }
+        }
+    } else
     if (!dead && sh.c.err == 0 && last > i0) {
         const PipeHdr &hp = sh.hdr[last & (kPipeSlots - 1)];
         const int i1 = uni(hp.i1), i2 = uni(hp.i2);
@@ -979,8 +1112,9 @@ __device__ __forceinline__ void pipe_body(FwRef f_, CsRef cs_, int target_arg, i
     double *s_sx = reinterpret_cast<double *>(carve);
     double *s_sy = s_sx + f.S;
     double *s_sz = s_sy + f.S;
+    double *s_gath = s_sz + f.S;                       // the gathered swap records of a lock-step rank (exchange_finish)
     rg.mir_n = cs.mirror_n;
-    rg.mx = s_sz + f.S;
+    rg.mx = s_gath + kGathStage;
     rg.mstep = rg.mx + rg.mir_n;
     rg.mir_steps = false;
     rg.lock = LOCK ? 1 : 0;
@@ -1019,6 +1153,7 @@ __device__ __forceinline__ void pipe_body(FwRef f_, CsRef cs_, int target_arg, i
         sh.q = 0ull; sh.epoch = 0; sh.fl_it = 0; sh.fl_base = 0;
         sh.d_done = sh.c.iter_done; sh.landed_it = sh.c.iter_done; sh.f_it = sh.c.iter_done; sh.f_stop_it = 0; sh.quit = 0;
         sh.n_flush = 0ull; sh.trace_n = 0u;
+        sh.win_lo = 0; sh.win_want = 0; sh.win_seq = 0; sh.win_ack = 0;
     }
     __syncthreads();
     for (int c = tid; c < kMaxChains; c += blockDim.x) {
@@ -1037,10 +1172,15 @@ __device__ __forceinline__ void pipe_body(FwRef f_, CsRef cs_, int target_arg, i
         return;
     }
     prefetch_all(cs, sh, rg, min(2 * (6 * nc + 16) + 64, ring_size - 64));       // ends with a barrier
-    if (wave == 0) pipe_front<LOCK>(cs, sh, rg, pr, lane, launch);
-    else if (wave == 1) pipe_decider<NCH, F32, LOCK>(f, cs, sh, rg, pr, lane, wmax);
-    else if (wave == 7) pipe_collector<NCH, F32, LOCK>(f, cs, sh, rg, pr, s_sx, s_sy, s_sz, lane);
-    else pipe_evaluator<NCH, F32, LOCK>(f, cs, sh, rg, pr, s_sx, s_sy, s_sz, lane);
+    if (tid == 0) sh.win_fill = sh.fill;
+    __syncthreads();
+#ifndef HTM_PIPE_SKIP
+#define HTM_PIPE_SKIP 0
+#endif
+    if (wave == 0) { if constexpr (!(HTM_PIPE_SKIP & 1)) pipe_front<LOCK>(cs, sh, rg, pr, lane, launch); }
+    else if (wave == 1) { if constexpr (!(HTM_PIPE_SKIP & 2)) pipe_decider<NCH, F32, LOCK>(f, cs, sh, rg, pr, s_gath, lane, wmax); }
+    else if (wave == (int)(blockDim.x >> 6) - 1) { if constexpr (!(HTM_PIPE_SKIP & 4)) pipe_collector<NCH, F32, LOCK>(f, cs, sh, rg, pr, s_sx, s_sy, s_sz, lane); }
+    else { if constexpr (!(HTM_PIPE_SKIP & 8)) pipe_evaluator<NCH, F32, LOCK>(f, cs, sh, rg, pr, s_sx, s_sy, s_sz, lane); }
     __syncthreads();
 #ifdef HTM_STAMPS
     if (cs.stamps)
@@ -1056,8 +1196,14 @@ __device__ __forceinline__ void pipe_body(FwRef f_, CsRef cs_, int target_arg, i
 // One launch = the chain master (block 0) + W full-evaluation workers (blocks 1..W), all resident.
 // `launch` = the host's count of k_mcmc launches of this chain set (1, 2, ...): orders and the quit word carry it, so
 // nothing a previous launch left in memory can be mistaken for this launch's.
+// Blocks of 8 waves; the pipelined master with one station per lane takes 12 (three per SIMD, 168 registers a wave): nine
+// evaluators instead of five -- its throughput is the evaluators' (and the worker blocks take 12 events each).
+#ifndef HTM_PIPE_THREADS
+#define HTM_PIPE_THREADS 512
+#endif
+template <int NCH, int MK> constexpr int mcmc_threads() { return (MK >= 5 && NCH == 1) ? HTM_PIPE_THREADS : 512; }
 template <int NCH, bool F32 = false, int MK = 0>
-__global__ __launch_bounds__(512) void k_mcmc(FwdDev f, ChainsDev cs, int mode, int target_arg,
+__global__ __launch_bounds__((mcmc_threads<NCH, MK>())) void k_mcmc(FwdDev f, ChainsDev cs, int mode, int target_arg,
                                                const double *gathered, int ring_size, int wmax,
                                                unsigned long long launch)
 {
@@ -1067,13 +1213,14 @@ __global__ __launch_bounds__(512) void k_mcmc(FwdDev f, ChainsDev cs, int mode, 
         // 4: a lock-step rank (MODE_LOCKRUN, swap records exchanged inside the launch) on the free-running master; 2: with barriers
         if constexpr (MK == 3) flow_body<NCH, F32, false>(ka.f, ka.cs, target_arg, ring_size, wmax, launch);
         else if constexpr (MK == 4) flow_body<NCH, F32, true>(ka.f, ka.cs, target_arg, ring_size, wmax, launch);
-        else if constexpr (MK == 5) pipe_body<NCH, F32, false>(ka.f, ka.cs, target_arg, ring_size, wmax, launch);      // htm_pipe.hpp
+        else if constexpr (MK == 5) pipe_body<NCH, F32, false>(ka.f, ka.cs, target_arg, ring_size, wmax, launch);      // the pipelined master: single rank
+        else if constexpr (MK == 6) pipe_body<NCH, F32, true>(ka.f, ka.cs, target_arg, ring_size, wmax, launch);       // ... a lock-step rank (MODE_LOCKRUN)
         else step_body<NCH, true, F32, MK>(ka.f, ka.cs, mode, target_arg, gathered, ring_size, wmax, launch);
         // every exit of the master comes through here (its returns are uniform over the block): release the workers
         __syncthreads();
         if (threadIdx.x == 0) st_agent(&ka.cs.ps->quit, launch + 1ull);
     } else {
-        worker_body<NCH, F32, 8>(ka.f, ka.cs, launch, blockIdx.x - 1);
+        worker_body<NCH, F32, mcmc_threads<NCH, MK>() / 64>(ka.f, ka.cs, launch, blockIdx.x - 1);
     }
 }
 

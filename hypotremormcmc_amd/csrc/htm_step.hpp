@@ -1777,6 +1777,7 @@ __device__ __forceinline__ void worker_body(FwRef f_, CsRef cs_, unsigned long l
 #endif
             if (tid == 0) {
                 double tot8 = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) + ((s_red[4] + s_red[5]) + (s_red[6] + s_red[7]));
+                if constexpr (NWV == 12) tot8 = tot8 + ((s_red[8] + s_red[9]) + (s_red[10] + s_red[11]));
                 st_gran_f64(cs.pgran + ((size_t)m * cs.n_wg + w) * cs.pgran_stride, tag, tot8);
             }
             __syncthreads();

@@ -464,6 +464,9 @@ def _gloo_device_worker(rank, world, port, name, q, transport="staged"):
     import sys
 
     sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+    if transport.startswith("pipe-"):           # the lock-step ranks on the pipelined master (csrc/htm_pipe.hpp, opt-in)
+        os.environ["HTM_PIPE_LOCK"] = "1"
+        transport = transport[5:]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       HTM_XCHG="1" if transport.startswith("direct") else "0")
     caps = {}
@@ -519,7 +522,9 @@ def _gloo_device_worker(rank, world, port, name, q, transport="staged"):
 @pytest.mark.parametrize("name,world,transport", [("c1", 2, "staged"), ("timeonly", 3, "staged"), ("c1", 2, "direct"),
                                                   ("timeonly", 3, "direct"), ("rejects", 2, "direct"), ("fixedcorr", 2, "direct"),
                                                   ("rejects", 2, "direct-stops"), ("timeonly", 3, "direct-stops"),
-                                                  ("synth:64:32:12:4:6000", 2, "direct"), ("synth:64:32:19:2:4000", 2, "direct-stops")])
+                                                  ("synth:64:32:12:4:6000", 2, "direct"), ("synth:64:32:19:2:4000", 2, "direct-stops"),
+                                                  ("c1", 2, "pipe-direct"), ("timeonly", 3, "pipe-direct-stops"),
+                                                  ("synth:64:32:12:4:6000", 2, "pipe-direct")])
 def test_torchworld_across_processes_sharing_the_gpu(name, world, transport):
     """TorchWorld + device-resident chains in 2-3 separate processes sharing the one GPU: per-rank traces and the
     reduced counters against the reference's MPI run.  "staged": gloo with host-staged records per iteration;

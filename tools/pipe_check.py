@@ -18,15 +18,21 @@ S_ = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 n_iter = int(sys.argv[4]) if len(sys.argv) > 4 else 3000
 n_time = int(sys.argv[5]) if len(sys.argv) > 5 else 200000
 prec = os.environ.get("PIPE_CHECK_PREC", "fp64")
-data = synth.make_synthetic(E_, S_, 1)
-params = dict(synth.DEFAULT_PARAMS, n_procs=1, n_chains=nc, n_cool=1, n_iter=10**7, n_burn=100, n_interval=50, forward_precision=prec)
+seed = int(os.environ.get("PIPE_CHECK_SEED", "1"))
+data = synth.make_synthetic(E_, S_, seed)
+params = dict(synth.DEFAULT_PARAMS, n_procs=1, n_chains=nc, n_cool=int(os.environ.get("PIPE_CHECK_COOL", "1")), n_iter=10**7, n_burn=100, n_interval=50, forward_precision=prec)
+if os.environ.get("PIPE_CHECK_INT"):
+    params.update(n_interval=int(os.environ["PIPE_CHECK_INT"]), n_burn=int(os.environ.get("PIPE_CHECK_BURN", "100")))
+if os.environ.get("PIPE_CHECK_SZ"):
+    params.update(step_size_z=float(os.environ["PIPE_CHECK_SZ"]), step_size_vs=0.4)
 obs = ObsData.from_arrays(data.sta_x, data.sta_y, data.t_obs, data.t_stdv, data.a_obs, data.a_stdv)
 
 
 def run(pipe):
     os.environ["HTM_PIPE"] = "1" if pipe else "0"
     fwd, cs = driver.build_rank(params, data.sta_x, data.sta_y, data.sta_z, obs, 0, n_procs=1)
-    cs.enable_steplog(n_iter * nc)
+    if not os.environ.get("PIPE_CHECK_NOSLOG"):
+        cs.enable_steplog(n_iter * nc)
     cs.run(n_iter)
     return fwd, cs
 
@@ -38,7 +44,9 @@ ia, da = a.steplog(); ib, db = b.steplog()
 print("rows", len(ia), len(ib))
 n = min(len(ia), len(ib))
 bad = np.nonzero(np.any(ia[:n] != ib[:n], axis=1))[0]
-if len(bad):
+if n == 0:
+    print("(no step log)")
+elif len(bad):
     k = bad[0]
     print("FIRST DIFFERENT STEP row %d:\n pipe %s %s\n flow %s %s" % (k, ia[k], da[k], ib[k], db[k]))
     for j in range(max(0, k - 2 * nc), k):
@@ -56,6 +64,11 @@ print("counters equal:", np.array_equal(ca[0], cb[0]) and np.array_equal(ca[1], 
 la, lb = a.likelihood_trace(), b.likelihood_trace()
 print("lik records:", len(la[0]), len(lb[0]), "iters equal", np.array_equal(la[0], lb[0]), "chains equal", np.array_equal(la[1], lb[1]),
       "max rel", float(np.max(np.abs(la[2] - lb[2]) / np.abs(lb[2]))) if len(la[2]) == len(lb[2]) and len(la[2]) else None)
+if len(la[2]) == len(lb[2]) and len(la[2]):
+    rel = np.abs(la[2] - lb[2]) / np.abs(lb[2])
+    badr = np.nonzero(rel > 1e-9)[0]
+    if len(badr):
+        print("first differing lik record %d: iteration %d chain %d  pipe %.12g flow %.12g  (%d differ)" % (badr[0], la[0][badr[0]], la[1][badr[0]], la[2][badr[0]], lb[2][badr[0]], len(badr)))
 sa, sb = a.samples(), b.samples()
 print("samples:", len(sa["iter"]), len(sb["iter"]), "iter/chain equal", np.array_equal(sa["iter"], sb["iter"]) and np.array_equal(sa["chain"], sb["chain"]),
       "values equal", all(np.array_equal(sa[k], sb[k]) for k in ("vs", "qs", "hypo", "t_corr", "a_corr")) if len(sa["iter"]) == len(sb["iter"]) else None)

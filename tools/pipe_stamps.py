@@ -10,6 +10,8 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
 from hypotremormcmc_amd import _lib
 
+os.environ.setdefault("HTM_PIPE", "1")
+
 _lib.LIB_PATH = os.environ.get("HTM_STAMPS_LIB") or os.path.join(ROOT, "hypotremormcmc_amd", "lib", "libhtm_hip_stamps.so")
 from hypotremormcmc_amd import driver, synth
 from hypotremormcmc_amd.obs_data import ObsData
@@ -37,8 +39,8 @@ d = [a[k] - base[k] for k in range(128)]
 f, dd, e, cc = d[32:40], d[40:48], d[48:56], d[56:64]
 it = max(1, dd[4])
 print("shader cycles (s_memtime) per iteration unless stated")
-print("F  produced %d (%.2f of them with inputs not requested ahead): busy %.1f  idle %.1f  orders %.1f" %
-      (f[2], f[4] / max(1, f[2]), f[0] / it, f[1] / it, f[3] / it))
+print("F  produced %d (%.2f of them with inputs not requested ahead): looking ahead %.1f  records %.1f  window %.1f  orders %.1f  idle %.1f" %
+      (f[2], f[4] / max(1, f[2]), f[5] / it, f[6] / it, f[7] / it, f[3] / it, f[1] / it))
 print("D  iterations %d  flushes %d: waiting for the records %.1f  for the evaluations %.1f  deciding %.1f  top %.1f" %
       (dd[4], dd[5], dd[0] / it, dd[1] / it, dd[2] / it, dd[3] / it))
 print("E  (five waves, summed) single-event tasks %d (%d evaluated twice): waiting for records %.1f  evaluation %.1f per task  loop top %.1f" %

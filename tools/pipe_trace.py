@@ -8,6 +8,8 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
 from hypotremormcmc_amd import _lib
 
+os.environ.setdefault("HTM_PIPE", "1")
+
 _lib.LIB_PATH = os.environ.get("HTM_STAMPS_LIB") or os.path.join(ROOT, "hypotremormcmc_amd", "lib", "libhtm_hip_stamps.so")
 from hypotremormcmc_amd import driver, synth
 from hypotremormcmc_amd.obs_data import ObsData
