@@ -776,6 +776,9 @@ struct ChainsDev {
     unsigned long long *diag;        // [32] what a wait that gave up was waiting for (written once, on the failure path; the host reports it)
     const PriorRec *prior;           // [element of the rank's parameter vector] (layout of xall)
     int prior_same;                  // all chains share chain 0's records: element (group, chain c, idx) reads (group, 0, idx)
+    unsigned long long xwait_ticks;  // how long a rank waits for the peers' swap records (100 MHz ticks; 20 s, HTM_XCHG_TIMEOUT_MS)
+    int xown;                        // a rank's own swap record is read from LDS instead of its inbox (default; HTM_XOWN=0: through memory like a peer's)
+    int dbg_xfail_iter;              // test switch (HTM_DEBUG_XCHG_FAIL_ITER): from this iteration on the rank posts its swap records to nobody (0 = off)
     unsigned long long *lo_gran;     // [n_chains][16] tagged granules of the pipelined master's orders (htm_pipe.hpp): [0..3] the proposed values of the two
                                      // hypocentre steps before the order's step (master -> workers), [8..15] the left-out events' sums at both positions (back)
 };

@@ -844,6 +844,7 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
         sh.i0 = sh.c.iter_done; sh.last_iter = sh.c.iter_target; sh.stop_code = 0;
         sh.n_full_w = 0ull; sh.n_part_w = 0ull;
         sh.xdone = sh.c.iter_done; sh.xclaim = sh.c.iter_done; sh.xcount[0] = sh.xcount[1] = sh.xcount[2] = sh.xcount[3] = 0;
+        sh.xctl = 0u; sh.xctl_iter = -1;
     }
     __syncthreads();
     const int i0 = sh.i0;

@@ -830,6 +830,9 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
     if ((rc = dev_alloc(hc->pool, &d.smp_data, (size_t)d.cap_smp * hc->rec_len))) return cleanup(rc);
     d.slog_i = nullptr; d.slog_d = nullptr;
     { const char *e = getenv("HTM_DEBUG_NO_DROP"); d.dbg = (e && atoi(e) != 0) ? 1 : 0; }
+    { const char *e = getenv("HTM_XCHG_TIMEOUT_MS"); const double ms = e ? atof(e) : 20000.0; d.xwait_ticks = (unsigned long long)(std::max(1.0, ms) * 1.0e5); }
+    { const char *e = getenv("HTM_DEBUG_XCHG_FAIL_ITER"); d.dbg_xfail_iter = e ? atoi(e) : 0; }
+    { const char *e = getenv("HTM_XOWN"); d.xown = (e && e[0] == '0') ? 0 : 1; }
     if ((rc = dev_alloc(hc->pool, &d.diag, 32))) return cleanup(rc);
     HIPCHK(hipMemset(d.diag, 0, 32 * sizeof(unsigned long long)));
     d.stamps = nullptr;
@@ -949,7 +952,11 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
         long room = (long)per_cu * n_cu - 1;
         // Several ranks on one GPU (more masters instead of more rounds per master: 4 ranks x 8 chains run 2.7 M steps/s where one
         // rank x 32 chains runs 1.7 M): every rank's blocks must be resident at once, so each takes its share of the CUs
-        if (const char *e = getenv("HTM_RANKS_PER_GPU")) { const int k = atoi(e); if (k > 1) room = (long)per_cu * n_cu / k - 1; }
+        if (const char *e = getenv("HTM_RANKS_PER_GPU")) {
+            const int k = atoi(e);
+            const long per_xcd = (long)per_cu * n_cu / 8;      // (blocks are dealt to the 8 XCDs in turn: htm_chains_share_gpu)
+            if (k > 1) room = per_xcd >= k ? 8 * (per_xcd / k) - 1 : (long)per_cu * n_cu / k - 1;
+        }
         if (room < 1) hc->persist = false;      // not even one worker fits next to the master: two-kernel path
         else if (hc->dev.n_workers > room) hc->dev.n_workers = worker_blocks(h->E, 8, room);
     }
@@ -1803,9 +1810,14 @@ int htm_chains_checkpoint_load(htm_chains *hc, const void *blob, size_t bytes)
         return fail(HTM_EINVAL, "checkpoint shape (%d chains, %d x %d, rank %d/%d) does not match this chain set", h.n_chains,
                     h.n_events, h.n_sta, h.rank, h.n_procs);
     if (bytes < ckpt_bytes(hc)) return fail(HTM_EINVAL, "checkpoint blob truncated");
-    int rc = htm_chains_sync(hc);
+    // A load REPLACES the control block -- iteration counter, stage, error word -- so it must work on a chain set whose last
+    // run failed (the roll-back of a failed lock-step run, parallel.py): wait for the stream, do not report what is about to
+    // be overwritten.  (An iteration of the per-launch lock-step in flight -- records out, swap not applied -- is dropped too.)
+    HIPCHK(hipSetDevice(hc->fwd->device));
+    hc->pending_gathered = nullptr;
+    int rc = bounded_stream_sync(hc, "waiting for the chain kernels before a checkpoint load");
     if (rc) return rc;
-    if (hc->h_ctrl.stage != ST_IDLE) return fail(HTM_ESTATE, "a lock-step iteration is in flight");
+    hc->ctrl_fresh = false;
     HIPCHK(hipStreamSynchronize(hc->side));
     const char *p = static_cast<const char *>(blob) + sizeof(h);
     const size_t n = hc->dev.n_chains;
@@ -1836,6 +1848,8 @@ int htm_chains_checkpoint_load(htm_chains *hc, const void *blob, size_t bytes)
         const ChainsDev &d = hc->dev;
         HIPCHK(hipMemset(d.slots, 0, (size_t)d.slot_rep * d.slot_stride * sizeof(unsigned long long)));
         HIPCHK(hipMemset(d.pgran, 0, (size_t)d.n_chains * d.n_workers * d.pgran_stride * sizeof(unsigned long long)));
+        HIPCHK(hipMemset(d.lo_gran, 0, (size_t)d.n_chains * 16 * sizeof(unsigned long long)));
+        HIPCHK(hipMemset(d.diag, 0, 24 * sizeof(unsigned long long)));      // (what a failed wait left for the error message; [24], [25] are counters)
         // The swap-record inbox too: its tags are bare iteration numbers, and the iterations after the saved one are about
         // to be run again (records and stop / error words of the first time must not be taken for the second).  For a
         // multi-rank job a load is therefore COLLECTIVE: every rank loads, then the ranks meet at a barrier before the next
@@ -1876,7 +1890,11 @@ int htm_chains_share_gpu(htm_chains *hc, int ranks_on_this_gpu)
     if (getenv("HTM_RANKS_PER_GPU") || !hc->persist || ranks_on_this_gpu == 1) return HTM_OK;      // (an explicit setting stands)
     // (a chain set that has already run keeps the launch shape it ran with: ADVICE r3 -- a world built around it must not fail)
     if (hc->launch_seq > 0) return HTM_OK;
-    const long room = hc->blocks_fit / ranks_on_this_gpu - 1;
+    // Blocks go to the 8 XCDs of the GPU in turn, every launch starting with the first: a rank's blocks must be spread evenly over
+    // them (a multiple of 8) and the ranks' shares of one XCD's CUs must add up to no more than it has -- 5 ranks x 51 blocks are
+    // 255 of 256 CUs and still do not fit (7 blocks x 5 ranks on XCDs 0..2: the launches wait for each other's CUs forever).
+    const long per_xcd = hc->blocks_fit / 8;
+    const long room = per_xcd >= ranks_on_this_gpu ? 8 * (per_xcd / ranks_on_this_gpu) - 1 : hc->blocks_fit / ranks_on_this_gpu - 1;
     if (room < 1) return fail(HTM_ESTATE, "%d ranks on one GPU: not even one worker block per rank fits next to the masters", ranks_on_this_gpu);
     if (hc->dev.n_workers > room) hc->dev.n_workers = worker_blocks(hc->fwd->E, 8, room);
     hc->dev.n_wg = hc->dev.n_workers;

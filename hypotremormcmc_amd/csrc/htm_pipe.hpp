@@ -1154,6 +1154,7 @@ __device__ __forceinline__ void pipe_body(FwRef f_, CsRef cs_, int target_arg, i
         sh.d_done = sh.c.iter_done; sh.landed_it = sh.c.iter_done; sh.f_it = sh.c.iter_done; sh.f_stop_it = 0; sh.quit = 0;
         sh.n_flush = 0ull; sh.trace_n = 0u;
         sh.win_lo = 0; sh.win_want = 0; sh.win_seq = 0; sh.win_ack = 0;
+        sh.xctl = 0u; sh.xctl_iter = -1;
     }
     __syncthreads();
     for (int c = tid; c < kMaxChains; c += blockDim.x) {

@@ -76,6 +76,8 @@ struct StepShared {
     double xrec[4 + 2 * kMaxChains];   // MODE_LOCKRUN: this rank's swap record of the iteration (what goes to every rank's inbox)
     int xdone;                    // MODE_LOCKRUN: the swap of every iteration <= xdone has been applied (see exchange_finish)
     int xstop, xspec;             // decided by role V: this rank asks for a stop; the next iteration starts before the swap is known
+    unsigned xctl;                // the control word this rank posted with its latest record (exchange_post; read back by exchange_finish)
+    int xctl_iter;                // ... and the iteration it belongs to
     Ctrl c;
 #ifdef HTM_STAMPS
     unsigned long long stamp_acc[96];   // diagnostic cycle accounting of this launch, flushed to ChainsDev::stamps at its end
@@ -941,12 +943,14 @@ __device__ __forceinline__ bool want_stop_now(CsRef cs_, const StepShared &sh, i
 }
 
 // one wave: this rank's record of iteration `iter` into every rank's inbox
-__device__ __forceinline__ void exchange_post(CsRef cs_, const StepShared &sh, int iter, int lane, bool want_stop)
+__device__ __forceinline__ void exchange_post(CsRef cs_, StepShared &sh, int iter, int lane, bool want_stop)
 {
     CsRef cs = rebase(cs_);
     const int nc = cs.n_chains, RW = 4 + 2 * nc, G = cs.xg, np = cs.n_procs, par = iter & 1;
     const unsigned tag = (unsigned)iter;
     const unsigned ctl = (want_stop ? 1u : 0u) | (sh.c.err ? 2u : 0u);
+    if (lane == 0) { sh.xctl = ctl; sh.xctl_iter = iter; }      // (this rank's own record is taken from LDS when the records are collected)
+    if (__builtin_expect(cs.dbg_xfail_iter > 0 && iter >= cs.dbg_xfail_iter, 0)) return;      // (fault injection: the peers never see this record)
     for (int g0 = 0; g0 < G; g0 += 64) {
         const int g = g0 + lane;
         if (g < G) {
@@ -975,6 +979,9 @@ __device__ __forceinline__ void exchange_finish(CsRef cs_, StepShared &sh, doubl
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();       // 100 MHz
     unsigned anyctl = 0;
     bool dead = false;
+    // This rank's own record does not travel: it is read from LDS where exchange_post took it from (sh.xrec, sh.xctl) -- the round
+    // trip of the rank's own stores through fine-grained memory was on the path of every lock-step iteration (HTM_XOWN=0 restores it).
+    const bool own_lds = cs.xown != 0 && sh.xctl_iter == iter;
     for (int row0 = 0; row0 < rows && !dead; row0 += kXLoads) {
         unsigned long long v[kXLoads];
         for (;;) {
@@ -983,12 +990,22 @@ __device__ __forceinline__ void exchange_finish(CsRef cs_, StepShared &sh, doubl
             for (int j = 0; j < kXLoads; ++j) {
                 const int row = row0 + j, r = row / chunks, k = (row - r * chunks) * 64 + lane;
                 v[j] = (unsigned long long)tag << 32;
-                if (row < rows && k < G) v[j] = ld_sys(in + (size_t)r * G + k);
+                if (row < rows && k < G) {
+                    if (own_lds && r == cs.rank) {
+                        const int w = k >> 1;
+                        unsigned pay;
+                        if (w < RW) {
+                            const unsigned long long b = (unsigned long long)__double_as_longlong(sh.xrec[w]);
+                            pay = (k & 1) ? (unsigned)b : (unsigned)(b >> 32);
+                        } else pay = (k & 1) ? 0u : sh.xctl;
+                        v[j] = ((unsigned long long)tag << 32) | pay;
+                    } else v[j] = ld_sys(in + (size_t)r * G + k);
+                }
             }
 #pragma unroll
             for (int j = 0; j < kXLoads; ++j) ok = ok && (unsigned)(v[j] >> 32) == tag;
             if (__all(ok)) break;
-            if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000000ull) {       // 20 s: a peer is gone
+            if (__builtin_amdgcn_s_memrealtime() - t0 > cs.xwait_ticks) {       // 20 s: a peer is gone
                 if (lane == 0) sh.c.err = -10;
                 dead = true;
                 break;
@@ -1117,7 +1134,7 @@ __device__ __forceinline__ void step_body(FwRef f_, CsRef cs_, int mode, int tar
         const long long av = sh.hop_end - sh.c.spos;
         sh.avail = av > (1 << 30) ? (1 << 30) : (int)av;
         sh.fill = 0; sh.base = 0; sh.redo = -1; sh.sw_do = 0; sh.catchup = 0; sh.rolep_iter = -1;
-        sh.xdone = sh.c.iter_done; sh.xstop = 0; sh.xspec = 0;
+        sh.xdone = sh.c.iter_done; sh.xstop = 0; sh.xspec = 0; sh.xctl = 0u; sh.xctl_iter = -1;
     }
     for (int c = tid; c < kMaxChains; c += blockDim.x) { sh.pre_p[0][c] = -1; sh.pre_p[1][c] = -1; sh.redone[c] = 0; }
     {
