@@ -31,6 +31,9 @@
 #ifndef HTM_FAIR
 #define HTM_FAIR 1        // diagnostics: 0 = no priority hand-over between the two waves of a SIMD
 #endif
+#ifndef HTM_FAIR_LOCK
+#define HTM_FAIR_LOCK 1   // ... on a lock-step rank too (one rank: 5.87 -> 5.26 us per iteration; ranks sharing a GPU: no difference)
+#endif
 
 namespace htm {
 
@@ -58,13 +61,21 @@ struct FlowShared : StepShared {
     // 1 / vs and pi f / (qs vs) of every chain (what event_misfit multiplies by: cls_forward.f90:118, :204), renewed by the chain's
     // own wave when it commits a new vs or qs: a partial update reads them instead of dividing twice (28 instructions)
     double rbeta[kMaxChains], katt[kMaxChains];
-    // a lock-step rank (k_mcmc<.., 4>): chains of this rank that have committed iteration i (index i & 3: the last one posts the
-    // rank's swap record); the iteration whose records a wave has taken on to collect
-    int xcount[4], xclaim;
+    // a lock-step rank (k_mcmc<.., 4>): the bet that judge_swap's draw is not this rank's is settled for the swaps of iterations
+    // <= xanch (the next iteration re-anchored if it was lost); xanch_claim: the iteration a wave has taken on to settle it for
+    int xanch, xanch_claim;
+    int xctl4[4];                          // [i & 3] {i << 2 | control word} of this rank's own header of iteration i (its own waves read it here)
 };
 
 // a wave-uniform value that reached a vector register (read from LDS) back in a scalar one
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// lane l of a 64-bit word, as a wave-uniform value
+__device__ __forceinline__ unsigned long long rl_u64(unsigned long long v, int l)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+    return ((unsigned long long)hi << 32) | lo;
+}
 
 // LDS words shared between the waves: relaxed accesses in program order.  LDS operations of a wave are executed in
 // issue order and the LDS is one serialisation point for the workgroup, so "release" and "acquire" are compiler
@@ -214,69 +225,171 @@ __device__ __forceinline__ bool flow_adopt(CsRef cs_, FlowShared &sh, const Ring
     return true;
 }
 
-// ---- a lock-step rank (k_mcmc<.., 4>): the swap records of htm_step.hpp's exchange_post / exchange_finish in the free-running loop ----
-// The chain wave that commits the LAST step of iteration `iter` on this rank posts the rank's record -- pair (rank 0's
-// select_pair), this rank's pending judge_swap draw (peeked), (T, L) of all its chains -- into every rank's inbox.
-__device__ __forceinline__ void flow_post_record(CsRef cs_, FlowShared &sh, const Ring &rg, int iter, int lane, int wmax)
+// ---- a lock-step rank (k_mcmc<.., 4>, MODE_LOCKRUN): the temperature swap between chains of ANY two ranks (cls_parallel.f90:
+// ---- 100-216) without a meeting of the rank's waves.
+// The swap after iteration j needs: the pair (rank 0's select_pair, :226-230), judge_swap's draw (from the stream of the rank
+// that owns the pair's first chain, :163) and (T, L) of the two chains -- nothing else.  So every CHAIN posts its own (T, L) when it
+// commits its step of iteration j, and the wave of the rank's LAST chain posts a HEADER {pair (rank 0), the draw this rank would
+// take, stop / failure word} -- tagged 8-byte granules {iteration : 32, payload : 32} written with system-scope stores into every
+// rank's inbox (fine-grained memory, over xGMI for a peer).  A chain wave at its decision of iteration j + 1 looks at rank 0's
+// header (the pair); only if its own chain is one of the two does it wait for the partner's record (and the draw's owner's
+// header) -- the waves of the other chains go on with the temperature they have.  What the free-running loop does inside one
+// rank through LDS (L4 / T4 / done) is done between ranks through the inboxes; a partner on the same rank is read from LDS.
+// A STOP (record buffers or produced stream nearly used up on some rank) asked for in the headers of iteration j ends the job
+// after iteration j + 2 on every rank: every wave reads the headers of iteration i - 2 before it commits a step of iteration i
+// (two iterations old: they are there), and all ranks read the same headers.  A FAILURE travels the same way (or as a timeout).
+// Ranks other than 0 bet that judge_swap's draw is not theirs (flow_swap_at); the first wave that learns the pair settles the
+// bet for the rank (xanch): lost, it anchors the next iteration one position later under a new epoch -- the very mechanism
+// of a prior rejection -- before any wave of the rank commits a step of that iteration.
+// Inbox: region A [2][n_procs][xg] is the barrier loop's (exchange_post / exchange_finish, htm_step.hpp); region B
+// [kXSlots][n_procs][xg], slot = iteration & 7, is this loop's.  Per (slot, rank): granules 0..6 = header {i1, i2, draw hi,
+// lo, its log hi, lo, control word}, 8 + 4 c .. 8 + 4 c + 3 = chain c {T hi, lo, L hi, lo}.  Eight slots: a wave still reading
+// the headers of iteration j - 4 (its decision of j - 2) may see a peer post those of j (tools/flow_protocol_sim.py found the
+// deadlock of a four-slot ring); a tag newer than the one waited for is a fail-stop (-15).
+constexpr int kXSlots = 8, kXHdr = 8;
+__device__ __forceinline__ size_t flow_xoff(int np, int G, int iter, int rank) { return ((size_t)(2 + (iter & (kXSlots - 1))) * np + rank) * G; }
+
+// chain c's (T, L) after iteration `iter` into every rank's inbox
+// (xout: the ranks' inboxes as mapped here, cached in LDS by flow_body; this rank's own waves read its records from LDS, so
+// nothing is posted to its own inbox -- one rank alone has no memory traffic for the swap at all)
+__device__ __forceinline__ void flow_post_chain(CsRef cs_, unsigned long long *const *xout, int iter, int c, double T, double L, int lane)
 {
     CsRef cs = rebase(cs_);
-    const int nc = cs.n_chains, M = rg.mask;
-    const int E = lds_ld(&sh.Eof[iter & 3]);          // every chain of the rank has committed: this is where the swap starts
-    int i1 = -1, i2 = -1, nd = 0;
-    flow_swap_at(cs, sh, rg, E, 1 << 30, i1, i2, nd);
-    const int own = (cs.rank == 0 && i1 >= 0 && i1 / nc == 0) ? 1 : 0;
-    const int jp = E + nd - own;                      // position of the pending judge_swap draw (after rank 0's pair draws)
-    if (lane < nc) { sh.xrec[4 + 2 * lane] = sh.temp[lane]; sh.xrec[5 + 2 * lane] = sh.L[lane]; }
-    // this rank asks everybody to stop after this iteration: record buffers or produced stream nearly used up
-    const bool my_stop = sh.c.n_lik + 3 * nc > cs.cap_lik || sh.c.n_smp + 3 * nc > cs.cap_smp || sh.avail < jp + 4 * wmax;
-    if (lane == 0) {
-        sh.xrec[0] = (double)i1; sh.xrec[1] = (double)i2; sh.xrec[2] = rg.U[jp & M]; sh.xrec[3] = (double)iter;
-        sh.c.swap_i1 = i1; sh.c.swap_i2 = i2; sh.c.swap_r = rg.U[jp & M]; sh.c.swap_logr = rg.LOGU[jp & M];
-        sh.c.spos = sh.origin + jp;                   // RNG commit: draws consumed so far (apply_swap adds the judge draw if it is ours)
-        sh.c.stage = ST_WAIT_SWAP;
-        sh.xcount[(iter + 1) & 3] = 0;                // (nobody commits a step of the next iteration before this record is in)
+    const int np = cs.n_procs, G = cs.xg;
+    if (np == 1) return;
+    if (__builtin_expect(cs.dbg_xfail_iter > 0 && iter >= cs.dbg_xfail_iter, 0)) return;      // (fault injection: nobody sees this rank's records)
+    const unsigned long long tb = (unsigned long long)__double_as_longlong(T), lb = (unsigned long long)__double_as_longlong(L);
+    for (int k = lane; k < 4 * np; k += 64) {
+        const int q = k >> 2, g = k & 3;
+        const unsigned pay = g == 0 ? (unsigned)(tb >> 32) : g == 1 ? (unsigned)tb : g == 2 ? (unsigned)(lb >> 32) : (unsigned)lb;
+        if (q != cs.rank) st_sys(xout[q] + flow_xoff(np, G, iter, cs.rank) + kXHdr + 4 * c + g, ((unsigned long long)(unsigned)iter << 32) | pay);
     }
-    exchange_post(cs, sh, iter, lane, my_stop);
 }
-// One wave (whichever needs the outcome first) collects the n_procs records of iteration `iter`, applies the swap
-// (cls_parallel.f90:118-213), and -- if the judge draw turned out to be this rank's and was not predicted -- anchors the next
-// iteration one position later under a new epoch; then everybody may go on (xdone).
-__device__ __forceinline__ void flow_collect_records(CsRef cs_, FlowShared &sh, const Ring &rg, double *s_gath, int iter, int lane)
+// the rank's header of iteration `iter` (by the wave of its last chain, at its commit: E = where the chain steps end)
+__device__ __forceinline__ void flow_post_header(CsRef cs_, FlowShared &sh, unsigned long long *const *xout, int iter, int wmax, int lane)
 {
     CsRef cs = rebase(cs_);
-    const int nc = cs.n_chains;
-    const int E = lds_ld(&sh.Eof[iter & 3]);
-    int i1 = -1, i2 = -1, nd = 0;
-    flow_swap_at(cs, sh, rg, E, 1 << 30, i1, i2, nd);        // what this rank PREDICTED the swap to draw here
-    exchange_finish(cs, sh, s_gath, iter, lane, false);
-    if (lane == 0) {
-        const int base = (int)(sh.c.spos - sh.origin);        // where the next iteration really starts
-        if (sh.c.err == 0 && base != E + nd) {
-            const int e1 = sh.epoch + 1;
-            // (anchor of a step 0: `pos` = end of the iteration before + what the prediction adds there, flow_from_anchor)
-            lds_st(&sh.anch[e1 & 1], ((unsigned long long)(unsigned)((iter + 1 - sh.i0) * nc) << 32) | (unsigned)(base - nd));
-            lds_st(&sh.epoch, e1);
-        }
-        if (sh.c.stop != 0 || sh.c.err != 0) lds_st(&sh.last_iter, min(sh.last_iter, iter));
-        __hip_atomic_store(&sh.xdone, iter, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const int np = cs.n_procs, G = cs.xg, nc = cs.n_chains, k4 = iter & 3;
+    // (pair and draw as this wave published them with the iteration's end position when its step passed its check)
+    const int i1 = sh.sw_i1[k4], i2 = sh.sw_i2[k4];
+    const unsigned long long ub = (unsigned long long)__double_as_longlong(sh.sw_r[k4]), lb = (unsigned long long)__double_as_longlong(sh.sw_logr[k4]);
+    // this rank asks everybody to stop: record buffers or produced stream nearly used up.  It takes effect two iterations on: until
+    // then the rank's other chains may still write their records of this iteration and all chains those of the next two (< 3 n_chains)
+    const bool my_stop = sh.c.n_lik + 3 * nc > cs.cap_lik || sh.c.n_smp + 3 * nc > cs.cap_smp || sh.avail < sh.Eof[k4] + 8 * wmax;
+    const unsigned ctl = (my_stop ? 1u : 0u) | (sh.c.err ? 2u : 0u);
+    if (lane == 0) lds_st(&sh.xctl4[k4], (int)(((unsigned)iter << 2) | ctl));
+    if (np == 1) return;
+    if (__builtin_expect(cs.dbg_xfail_iter > 0 && iter >= cs.dbg_xfail_iter, 0)) return;
+    for (int k = lane; k < 8 * np; k += 64) {
+        const int q = k >> 3, g = k & 7;
+        const unsigned pay = g == 0 ? (unsigned)i1 : g == 1 ? (unsigned)i2 : g == 2 ? (unsigned)(ub >> 32) : g == 3 ? (unsigned)ub
+                           : g == 4 ? (unsigned)(lb >> 32) : g == 5 ? (unsigned)lb : ctl;
+        if (g < 7 && q != cs.rank) st_sys(xout[q] + flow_xoff(np, G, iter, cs.rank) + g, ((unsigned long long)(unsigned)iter << 32) | pay);
     }
 }
-// every wave, before it needs the outcome of iteration `iter`'s swap (its decision of the next iteration, or leaving the loop)
-__device__ __forceinline__ bool flow_settle(CsRef cs, FlowShared &sh, const Ring &rg, double *s_gath, int iter, int lane)
+// What a step of iteration `iter` reads from the rank's inbox before its decision, requested when its evaluation is done (a load
+// from fine-grained memory takes ~1 us and vector loads return in order: in front of the step's own loads it would hold them up;
+// here it runs under the turn): lane q < n_procs, q another rank: rank q's control word of iteration iter - 2; lanes 62, 63, on a
+// rank other than 0: the pair in rank 0's header of iteration iter - 1.
+__device__ __forceinline__ unsigned long long flow_xload(CsRef cs_, int iter, int lane)
 {
-    if (iter <= uni(sh.i0) || lds_ld(&sh.xdone) >= iter) return true;
-    int mine = 0;
-    if (lane == 0) mine = atomicCAS(&sh.xclaim, iter - 1, iter) == iter - 1 ? 1 : 0;
-    if (uni(mine)) { flow_collect_records(cs, sh, rg, s_gath, iter, lane); return lds_ld(&sh.c.err) == 0; }
+    CsRef cs = rebase(cs_);
+    const int np = cs.n_procs, G = cs.xg;
+    unsigned long long v = 0ull;
+    if (lane < np) { if (lane != cs.rank) v = ld_sys(cs.inbox + flow_xoff(np, G, iter - 2, lane) + 6); }
+    else if (lane >= 62 && cs.rank != 0) v = ld_sys(cs.inbox + flow_xoff(np, G, iter - 1, 0) + (lane - 62));
+    return v;
+}
+// `n` granules (n <= 64) from `base` in this rank's inbox, all tagged `iter`: polls until they are (false: gave up, sh.c.err set)
+__device__ __forceinline__ bool flow_xwait(CsRef cs_, FlowShared &sh, const unsigned long long *base, int n, int iter, int lane, unsigned long long &v)
+{
+    CsRef cs = rebase(cs_);
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    for (unsigned spin = 0; lds_ld(&sh.xdone) < iter; ++spin) {
-        if ((spin & 15u) == 15u) {
+    for (unsigned spin = 0;; ++spin) {
+        v = lane < n ? ld_sys(base + lane) : ((unsigned long long)(unsigned)iter << 32);
+        const unsigned tg = (unsigned)(v >> 32);
+        if (__all(tg == (unsigned)iter)) return true;
+        if (__any(tg != 0u && (int)tg > iter)) { if (lane == 0) sh.c.err = -15; return false; }      // overwritten: the ring is too short
+        if ((spin & 7u) == 7u) {
             if (lds_ld(&sh.c.err) != 0) return false;
-            if (__builtin_amdgcn_s_memrealtime() - t0 > 2500000000ull) { if (lane == 0) sh.c.err = -10; return false; }
+            if (__builtin_amdgcn_s_memrealtime() - t0 > cs.xwait_ticks) { if (lane == 0) sh.c.err = -10; return false; }
         }
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(2);
     }
-    return lds_ld(&sh.c.err) == 0;
+}
+// the swap of iteration `it` as chain c of this rank sees it (cls_parallel.f90:121-136, :285-302): is the chain one of the pair,
+// and if so does it take the partner's temperature?  T, rT: the chain's temperature during `it` in, after the swap out; L: its
+// log-likelihood after `it`.  Both chains' waves (on whichever ranks) evaluate the same expression on the same values.
+__device__ __forceinline__ bool flow_lock_swap(CsRef cs_, FlowShared &sh, int it, int c, int i1, int i2, double L, double &T, double &rT, int lane)
+{
+    CsRef cs = rebase(cs_);
+    const int nc = cs.n_chains, np = cs.n_procs, G = cs.xg, par = it & 3;
+    const int g = cs.rank * nc + c;
+    if (g != i1 && g != i2) return true;
+    const int gp = g == i1 ? i2 : i1, rp = gp / nc, cp = gp - rp * nc, r1 = i1 / nc;
+    double Tp, rTp, Lp, u, logu;
+    if (rp == cs.rank) {
+        const int want = (it - sh.i0) * nc + cp;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (unsigned spin = 0; lds_ld(&sh.done[cp]) < want; ++spin) {
+            if ((spin & 15u) == 15u) {
+                if (sh.c.err != 0) return false;
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) { if (lane == 0) sh.c.err = -12; return false; }
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        Tp = sh.T4[par][cp]; rTp = sh.rT4[par][cp]; Lp = sh.L4[par][cp];
+    } else {
+        unsigned long long v;
+        if (!flow_xwait(cs, sh, cs.inbox + flow_xoff(np, G, it, rp) + kXHdr + 4 * cp, 4, it, lane, v)) return false;
+        Tp = gran_f64(rl_u64(v, 0), rl_u64(v, 1)); Lp = gran_f64(rl_u64(v, 2), rl_u64(v, 3));
+        rTp = 1.0 / Tp;
+    }
+    if (r1 == cs.rank) { u = sh.sw_r[par]; logu = sh.sw_logr[par]; }      // (this rank's own draw, published with the iteration's end)
+    else {
+        unsigned long long v;
+        if (!flow_xwait(cs, sh, cs.inbox + flow_xoff(np, G, it, r1) + 2, 4, it, lane, v)) return false;
+        u = gran_f64(rl_u64(v, 0), rl_u64(v, 1)); logu = gran_f64(rl_u64(v, 2), rl_u64(v, 3));
+    }
+    const double rT1 = g == i1 ? rT : rTp, rT2 = g == i1 ? rTp : rT, L1 = g == i1 ? L : Lp, L2 = g == i1 ? Lp : L;
+    const double del_s = (L2 - L1) * (rT1 - rT2);                              // :292
+    if (u >= kEps && logu <= del_s) { T = Tp; rT = rTp; }                      // :131-136
+    return true;
+}
+
+// After the loop (wave 0; every step up to the last iteration is committed): the swap of the launch's LAST iteration applied to
+// this rank's own chains, the rank's stream position and iteration counter settled -- the state the next launch (or the host) finds.
+__device__ __forceinline__ void flow_lock_finish(CsRef cs_, FlowShared &sh, int lane)
+{
+    CsRef cs = rebase(cs_);
+    const int nc = cs.n_chains, np = cs.n_procs, G = cs.xg, i0 = sh.i0;
+    const int last = min(sh.last_iter, sh.c.iter_target);
+    if (last <= i0) return;
+    const int par = last & 3, E = sh.Eof[par];
+    int i1 = -1, i2 = -1, extra = 0;
+    if (np * nc > 1) {
+        if (cs.rank == 0) { i1 = uni(sh.sw_i1[par]); i2 = uni(sh.sw_i2[par]); }
+        else {
+            unsigned long long v;
+            if (!flow_xwait(cs, sh, cs.inbox + flow_xoff(np, G, last, 0), 2, last, lane, v)) return;
+            i1 = (int)(unsigned)rl_u64(v, 0); i2 = (int)(unsigned)rl_u64(v, 1);
+        }
+        for (int k = 0; k < 2; ++k) {
+            const int g = k == 0 ? i1 : i2;
+            if (g / nc != cs.rank) continue;
+            const int c = g - cs.rank * nc;
+            double T = sh.T4[par][c], rT = sh.rT4[par][c];      // (the partner, if it is this rank's too, is read from the same rings: its value before the swap)
+            if (!flow_lock_swap(cs, sh, last, c, i1, i2, sh.L4[par][c], T, rT, lane)) return;
+            if (lane == 0) { sh.temp[c] = T; sh.rtemp[c] = rT; }
+        }
+        extra = (cs.rank != 0 && i1 / nc == cs.rank) ? 1 : 0;       // judge_swap's draw came from this rank's stream (rank 0 counted it: sw_nd)
+    }
+    if (lane == 0) {
+        sh.c.swap_i1 = i1; sh.c.swap_i2 = i2; sh.c.swap_r = sh.sw_r[par]; sh.c.swap_logr = sh.sw_logr[par];
+        sh.c.spos = sh.origin + E + sh.sw_nd[par] + extra;
+        sh.c.iter_done = last;
+        sh.c.stage = ST_IDLE;
+    }
 }
 
 // One chain step from its front to its commit and the orders of the chain's coming full evaluations (the free-running
@@ -295,7 +408,7 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
     const int M = rg.mask;
     p = __builtin_amdgcn_readfirstlane(p);
 #ifdef HTM_STAMPS
-    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long st_acc[7] = {0, 0, 0, 0, 0, 0, 0};      // ([6]: a lock-step rank's look at the inbox, the bet and the pair's wait)
     unsigned long long t_last = __builtin_amdgcn_s_memtime(), t_wait = 0;
     const unsigned long long t_step0 = t_last;
 #endif
@@ -395,6 +508,12 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
         flow_swap_at(cs, sh, rg, E, 1 << 30, i1, i2, nd);
         if (lane == 0) {
             sh.sw_i1[k4] = i1; sh.sw_i2[k4] = i2; sh.sw_nd[k4] = nd;
+            if constexpr (LOCK) {
+                // the draw THIS rank takes if the pair's first chain is its own (rank 0 knows: then it is the last of the nd draws;
+                // another rank peeks at the position after its chain steps): what goes into the rank's header
+                const int own = (cs.rank == 0 && i1 >= 0 && i1 / nc_ == 0) ? 1 : 0;
+                sh.sw_r[k4] = rg.U[(E + nd - own) & M]; sh.sw_logr[k4] = rg.LOGU[(E + nd - own) & M];
+            } else
             if (nd > 0) { sh.sw_r[k4] = rg.U[(E + nd - 1) & M]; sh.sw_logr[k4] = rg.LOGU[(E + nd - 1) & M]; }
             lds_st(&sh.Eof[k4], E);
         }
@@ -546,6 +665,9 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
         }
     }
     FSTAMP(2);
+    // a lock-step rank: the other ranks' stop words of two iterations ago and rank 0's pair of the iteration before (flow_xload)
+    unsigned long long xv = 0ull;
+    if constexpr (LOCK) { if (cs.n_procs > 1) xv = flow_xload(cs, iter, lane); }
 
     // ---- the step's turn: every step before it in stream order has passed its check in this epoch (or lies before the
     // ---- epoch's anchor: checked earlier, final).  Lanes <-> chains.
@@ -586,17 +708,97 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
     const int par = iter & 3, ppar = (iter - 1) & 3;
     double T = sh.T4[par][c], rT = sh.rT4[par][c];        // (first iteration of a launch: written by the prologue)
     if constexpr (LOCK) {
-        // a lock-step rank: the swap of the iteration before is decided from ALL ranks' records (flow_settle); it may end the
-        // job (a rank asked everybody to stop, or failed) or move this rank's stream (the judge draw was ours after all)
-        if (!flow_settle(cs, sh, rg, s_gath, iter - 1, lane)) return kFlowAbort;
-        if (iter > lds_ld(&sh.last_iter)) return kFlowStop;
-        if (lds_ld(&sh.epoch) != W.epoch) {
-            bool stands = false;
-            while (!flow_adopt(cs, sh, rg, W, lds_ld(&sh.epoch), iter, c, true, stands)) { }
-            flow_void_books(cs, sh, wave, NW, nc_, lane);
-            if (!stands) return kFlowRestart;
-        }
+        // a lock-step rank (see flow_post_chain): the stop words of iteration iter - 2, the pair of iteration iter - 1, the bet on
+        // judge_swap's draw; then -- only if this chain is one of the pair -- the partner's (T, L)
+        const int np = cs.n_procs, i0_ = sh.i0;
+        // (what the block reads from LDS, requested in one batch: each of these used to be a round trip of its own behind a branch)
         T = sh.temp[c]; rT = sh.rtemp[c];
+        const int own = sh.xctl4[(iter - 2) & 3];
+        int l_it = sh.last_iter, ep = sh.epoch;
+        const int si1 = sh.sw_i1[ppar], si2 = sh.sw_i2[ppar], xa = sh.xanch;
+        asm volatile("" ::: "memory");
+        if (np > 1) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            for (unsigned spin = 0;; ++spin) {
+                const unsigned tg = (unsigned)(xv >> 32);
+                bool okl = true;
+                if (lane < np) okl = iter - 2 <= i0_ || lane == cs.rank || tg == (unsigned)(iter - 2);
+                else if (lane >= 62) okl = iter - 1 <= i0_ || cs.rank == 0 || tg == (unsigned)(iter - 1);
+                if (__all(okl)) break;
+                if (__any(((lane < np && lane != cs.rank) || (lane >= 62 && cs.rank != 0)) && tg != 0u && (int)tg > iter)) { if (lane == 0) sh.c.err = -15; return kFlowAbort; }
+                if ((spin & 7u) == 7u) {
+                    if (lds_ld(&sh.c.err) != 0) return kFlowAbort;
+                    if (iter > lds_ld(&sh.last_iter)) return kFlowStop;
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > cs.xwait_ticks) { if (lane == 0) sh.c.err = -10; return kFlowAbort; }
+                }
+                __builtin_amdgcn_s_sleep(2);
+                xv = flow_xload(cs, iter, lane);
+            }
+        }
+        if (iter - 2 > i0_) {
+            // (this rank's own word: LDS.  Its last chain's wave finished iteration iter - 2 before it began the step of iter - 1
+            // whose check this step's turn has seen)
+            if (__builtin_expect((own >> 2) != iter - 2, 0)) { if (lane == 0) sh.c.err = -12; return kFlowAbort; }
+            const unsigned ctl = lane == cs.rank ? (unsigned)own & 3u : lane < np ? (unsigned)xv : 0u;
+            if (__any((ctl & 2u) != 0u)) { if (lane == 0 && sh.c.err == 0) sh.c.err = -11; return kFlowAbort; }      // a peer reported a failure
+            if (__any((ctl & 1u) != 0u)) {      // somebody asked for a stop two iterations ago: this iteration is the job's last (on every rank)
+                if (lane == 0) { atomicMin(&sh.last_iter, iter); sh.c.stop = 3; }
+                l_it = min(l_it, iter);
+            }
+        }
+        if (iter > uni(l_it)) return kFlowStop;
+        if (iter - 1 > i0_ && np * nc_ > 1) {
+            int i1, i2;
+            if (cs.rank == 0) { i1 = uni(si1); i2 = uni(si2); }      // (this step's turn has seen the last chain's check)
+            else { i1 = (int)(unsigned)rl_u64(xv, 62); i2 = (int)(unsigned)rl_u64(xv, 63); }
+            if (cs.rank != 0 && uni(xa) < iter - 1) {
+                // the bet that the draw is not this rank's, settled once per iteration by whoever learns the pair first
+                int mine = 0;
+                if (lane == 0) mine = atomicMax(&sh.xanch_claim, iter - 1) < iter - 1 ? 1 : 0;
+                if (uni(mine)) {
+                    if (lane == 0) {
+                        if (i1 / nc_ == cs.rank) {
+                            // lost: the next iteration starts one position later (anchor of a step 0: flow_from_anchor adds what this
+                            // rank predicts the swap to draw there -- nothing)
+                            const int e1 = sh.epoch + 1;
+                            lds_st(&sh.anch[e1 & 1], ((unsigned long long)(unsigned)((iter - i0_) * nc_) << 32) | (unsigned)(sh.Eof[ppar] + 1));
+                            lds_st(&sh.epoch, e1);
+                        }
+                        lds_st(&sh.xanch, iter - 1);
+                    }
+                } else {
+                    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                    for (unsigned spin = 0; lds_ld(&sh.xanch) < iter - 1; ++spin) {
+                        if ((spin & 15u) == 15u) {
+                            if (sh.c.err != 0) return kFlowAbort;
+                            if (__builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) { if (lane == 0) sh.c.err = -12; return kFlowAbort; }
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                ep = lds_ld(&sh.epoch);
+            }
+            if (uni(ep) != W.epoch) {
+                bool stands = false;
+                while (!flow_adopt(cs, sh, rg, W, lds_ld(&sh.epoch), iter, c, true, stands)) { }
+                flow_void_books(cs, sh, wave, NW, nc_, lane);
+                if (!stands) return kFlowRestart;
+            }
+#ifdef HTM_STAMPS_SPLIT
+            FSTAMP(6);
+#endif
+            const double T_was = T;
+            if (!flow_lock_swap(cs, sh, iter - 1, c, i1, i2, L_cur, T, rT, lane)) return kFlowAbort;
+            if (T != T_was && lane == 0) { sh.temp[c] = T; sh.rtemp[c] = rT; }
+        }
+        // the rank's header of this iteration, from the wave of its last chain: where the chain steps end is final (the turn), the bet
+        // on the draw of the iteration before is settled (it moves a rank's stream, and with it the draw the rank would take)
+        if (c == nc_ - 1) flow_post_header(cs, sh, reinterpret_cast<unsigned long long *const *>(s_gath), iter, wmax, lane);
+#ifdef HTM_STAMPS_SPLIT      // (diagnostics: [6] = the block up to the pair's wait; the wait and the header go to phase 4)
+        FSTAMP(4);
+#else
+        FSTAMP(6);
+#endif
     } else if (iter - 1 > sh.i0) {
         T = sh.T4[ppar][c]; rT = sh.rT4[ppar][c];
         if (cs.n_procs * nc_ > 1) {
@@ -644,10 +846,9 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
         lds_st(&sh.done[c], key);
     }
     if constexpr (LOCK) {
-        // the last chain of the rank to commit this iteration posts the rank's swap record
-        int last = 0;
-        if (lane == 0) last = atomicAdd(&sh.xcount[iter & 3], 1) == nc_ - 1 ? 1 : 0;
-        if (uni(last)) flow_post_record(cs, sh, rg, iter, lane, wmax);
+        // this chain's (T, L) after the iteration (the rank's header went out before the decision, from the wave of its last chain)
+        unsigned long long *const *xout = reinterpret_cast<unsigned long long *const *>(s_gath);
+        flow_post_chain(cs, xout, iter, c, T, L_post, lane);
     }
     FSTAMP(4);
     // ---- a rejected prior: this step was one draw shorter than the hop tables assume.  Everything after it starts
@@ -782,7 +983,7 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
     if (lane == 0 && cs.stamps) {
         unsigned long long *a = sh.stamp_acc + 12 * (wave & 7);
         if (need_full) { a[6] += t_last - t_step0; a[8] += 1; a[10] += t_wait; }
-        else { for (int k = 0; k < 6; ++k) a[k] += st_acc[k]; a[7] += 1; }
+        else { for (int k = 0; k < 6; ++k) a[k] += st_acc[k]; a[9] += st_acc[6]; a[7] += 1; }
     }
 #endif
     return p + cnt;
@@ -833,6 +1034,9 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
     for (int k = tid; k < 96; k += blockDim.x) sh.stamp_acc[k] = 0ull;
 #endif
     for (int k = tid; k < rg.mir_n; k += blockDim.x) { rg.mx[k] = cs.xall[k]; if (rg.mir_steps) rg.mstep[k] = cs.stall[k]; }
+    if constexpr (LOCK) {      // where the peers' inboxes are mapped (flow_post_chain / flow_post_header)
+        for (int q = tid; q < cs.n_procs && q < kGathStage; q += blockDim.x) reinterpret_cast<unsigned long long **>(s_gath)[q] = cs.outbox[q];
+    }
     __syncthreads();
     if (tid == 0) {
         if (target_arg >= 0) sh.c.iter_target = target_arg;
@@ -843,7 +1047,8 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
         sh.epoch = 0; sh.anch[0] = 0ull; sh.anch[1] = 0ull;
         sh.i0 = sh.c.iter_done; sh.last_iter = sh.c.iter_target; sh.stop_code = 0;
         sh.n_full_w = 0ull; sh.n_part_w = 0ull;
-        sh.xdone = sh.c.iter_done; sh.xclaim = sh.c.iter_done; sh.xcount[0] = sh.xcount[1] = sh.xcount[2] = sh.xcount[3] = 0;
+        sh.xdone = sh.c.iter_done; sh.xanch = sh.c.iter_done; sh.xanch_claim = sh.c.iter_done;
+        sh.xctl4[0] = sh.xctl4[1] = sh.xctl4[2] = sh.xctl4[3] = 0;
         sh.xctl = 0u; sh.xctl_iter = -1;
     }
     __syncthreads();
@@ -890,7 +1095,7 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
         // ---- top of a step: the epoch its position is predicted in
         FlowTop tp;
         {
-            const int co = (HTM_FAIR && !LOCK && (c ^ 4) < nc) ? (c ^ 4) : c;
+            const int co = (HTM_FAIR && (!LOCK || HTM_FAIR_LOCK) && (c ^ 4) < nc) ? (c ^ 4) : c;
             tp.epoch = lds_ld(&sh.epoch); tp.last_iter = lds_ld(&sh.last_iter); tp.err = lds_ld(&sh.c.err);
             tp.pk = (int)(unsigned)lds_ld(&sh.prog[co]);
             tp.book_pos = sh.ob_pos[c]; tp.book_mode = sh.ob_mode[c]; tp.book_mid = sh.ob_mid[c]; tp.book_tag = sh.ob_tag[c];
@@ -907,11 +1112,7 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
                 continue;      // (the book read above is void with it: from the top)
             }
         }
-        if (iter > tp.last_iter || tp.err != 0) {
-            // (a lock-step rank leaves only when the swap of its last iteration has been applied)
-            if constexpr (LOCK) { if (sh.c.err == 0) flow_settle(cs, sh, rg, s_gath, iter - 1, lane); }
-            break;
-        }
+        if (iter > tp.last_iter || tp.err != 0) break;      // (a lock-step rank: the swap of its last iteration is applied after the loop)
         if (__builtin_expect(W.rpos1 < 0 || W.B2 < 0, 0)) {      // predictions the window did not cover when they were made
             if (W.rpos1 < 0) { W.rpos1 = flow_next_base(cs, sh, rg, W.rpos, nc - W.rc, sh.fill); W.rc1 = 0; }
             if (W.B2 < 0 && W.rpos1 >= 0) W.B2 = flow_next_base(cs, sh, rg, W.rpos1, nc - W.rc1, sh.fill);
@@ -943,7 +1144,7 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
         // ~10 k cycles and wait ~2.7 k in their turns for waves 4-7, which need ~12 k.  The wave that is BEHIND its SIMD's
         // other wave (a step or more, by the checks published) asks for priority; the one ahead gives it up.
         // (Not between lock-step ranks: there the hand-over costs 2-3 %, profiles/r03_n_fair.txt.)
-        if (HTM_FAIR && !LOCK && (c ^ 4) < nc) {      // (chain c ^ 4 is the corresponding chain of the SIMD's other wave, whatever the number of chains per wave)
+        if (HTM_FAIR && (!LOCK || HTM_FAIR_LOCK) && (c ^ 4) < nc) {      // (chain c ^ 4 is the corresponding chain of the SIMD's other wave, whatever the number of chains per wave)
             const int pk = tp.pk;
             if (pk >= (iter - i0) * nc + (c ^ 4)) __builtin_amdgcn_s_setprio(1);
             else __builtin_amdgcn_s_setprio(0);
@@ -978,11 +1179,15 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
         for (int k = tid; k < 96; k += blockDim.x) if (sh.stamp_acc[k]) atomicAdd(&cs.stamps[32 + k], sh.stamp_acc[k]);      // (the workers' own stamps sit at 20..28)
 #endif
     // ---- every step up to last_iter is committed: the swap of the last iteration, counters, the launch's end state
+    if constexpr (LOCK) {
+        if (wave == 0 && sh.c.err == 0) flow_lock_finish(cs, sh, lane);
+        __syncthreads();
+    }
     if (tid == 0 && sh.c.err == 0) {
         if constexpr (LOCK) {
-            // (iteration counter, stream position, temperatures and the stop word were settled with the last swap)
+            // (iteration counter, stream position and temperatures were settled with the last swap: flow_lock_finish)
             const int last = sh.c.iter_done;
-            for (int k = 0; k < nc; ++k) cs.L[k] = sh.L[k];
+            for (int k = 0; k < nc; ++k) { cs.L[k] = sh.L[k]; cs.temp[k] = sh.temp[k]; }
             if (sh.c.slog_cap > 0) sh.c.slog_n = min(sh.c.slog_cap, sh.c.slog_n + (last - i0) * nc);
             sh.c.n_full_evals += (long long)sh.n_full_w;
             sh.c.n_partial_evals += (long long)sh.n_part_w;

@@ -971,7 +971,7 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
         const bool window_ok = hc->persist && !(e && e[0] == '0') && d.dbg == 0 && hc->dev.mirror_n > 0 &&
                                hc->ring_size >= 4 * wd + 32 + 2 * c_max + 16;
         hc->flow = window_ok && d.n_procs == 1;
-        hc->flow_lock = window_ok && !(getenv("HTM_FLOW_LOCK") && getenv("HTM_FLOW_LOCK")[0] == '0');      // (MODE_LOCKRUN: any number of ranks)
+        hc->flow_lock = window_ok && d.n_procs <= 60 && !(getenv("HTM_FLOW_LOCK") && getenv("HTM_FLOW_LOCK")[0] == '0');      // (MODE_LOCKRUN: up to 60 ranks -- a lane per rank reads its stop word, flow_xload)
         // The pipelined master (htm_pipe.hpp; HTM_PIPE=0 keeps the free-running one): front / evaluators / decider over an LDS ring
         // of iteration slots.  Needs the LDS mirror of the non-hypocentre parameters (what its evaluators read) and one or two
         // stations per lane.
@@ -1134,6 +1134,7 @@ static int ctrl_error(const htm_chains *hc)
     case -7: return fail(HTM_ESTATE, "random stream underrun in lock-step mode (iteration %d)", hc->h_ctrl.iter_done + 1);
     case -10: return fail(HTM_ESTATE, "swap records of the other ranks did not arrive within 20 s (iteration %d)", hc->h_ctrl.iter_done + 1);
     case -11: return fail(HTM_ESTATE, "another rank reported a failure (iteration %d)", hc->h_ctrl.iter_done + 1);
+    case -15: return fail(HTM_EDESYNC, "a swap record in the inbox was overwritten before it was read (after iteration %d): the ranks are more than the ring's depth apart", hc->h_ctrl.iter_done);
     default: return fail(HTM_ESTATE, "device error flag %d", hc->h_ctrl.err);
     }
 }
@@ -1436,7 +1437,8 @@ static int xchg_alloc(htm_chains *hc)
     if (hc->d_inbox) return HTM_OK;
     ChainsDev &d = hc->dev;
     d.xg = 2 * (4 + 2 * d.n_chains) + 2;
-    hc->inbox_bytes = 2 * (size_t)d.n_procs * d.xg * sizeof(unsigned long long);
+    // (region A [2][n_procs][xg]: the barrier loop's records; region B [kXSlots][n_procs][xg]: the free-running lock-step loop's, htm_flow.hpp)
+    hc->inbox_bytes = (size_t)(2 + kXSlots) * d.n_procs * d.xg * sizeof(unsigned long long);
     void *p = nullptr;
     // fine-grained: peers write it over xGMI while this rank's kernel polls it (system-scope accesses, no L2 copy)
     hipError_t e = hipExtMallocWithFlags(&p, hc->inbox_bytes, hipDeviceMallocFinegrained);

@@ -27,9 +27,10 @@ def test_free_running_protocol_equals_the_serial_loop(first):
 
 @pytest.mark.parametrize("first", [1, 201, 401])
 def test_lock_step_ranks_protocol_equals_the_serial_ranks(first):
-    """the lock-step ranks' part (flow_post_record / flow_settle / flow_collect_records): 1-4 ranks with their own streams, the
-    pair drawn by rank 0, the judge draw by the pair's first chain's rank (src/cls_parallel.f90:121-213), a stop request by any
-    rank, a rank that is scheduled rarely"""
+    """the lock-step ranks' part (flow_post_chain / flow_post_header / flow_lock_swap / flow_lock_finish): 1-4 ranks with their own
+    streams, per-chain (T, L) records and per-rank headers in eight-slot inbox rings, the pair drawn by rank 0, the judge draw by
+    the pair's first chain's rank (src/cls_parallel.f90:121-213), only the pair's two chains waiting for anybody, the lost bet on
+    the draw, a stop request by any rank that ends the job two iterations on, a rank that is scheduled rarely"""
     sim = _sim()
     for seed in range(first, first + 200):
         assert sim.run_case_lock(seed), "lock-step seed %d differs from the serial ranks" % seed

@@ -11,10 +11,15 @@ This script runs those rules as coroutines (one per wave) under a random schedul
 shared-memory accesses, with state-dependent rejections, swaps and a stop request, and compares everything -- the
 position every step started at, final chain states, temperatures, final stream position -- with the serial loop.
 
-The second half models the LOCK-STEP ranks (k_mcmc<.., 4>): several ranks with their own streams, the rank's last committer
-posting its swap record into every inbox, the first wave that needs the outcome collecting the records, the bet of ranks != 0
-that the judge draw is not theirs (lost: the next iteration is anchored one position later under a new epoch), a stop request
-travelling with the records -- against the serial ranks of cls_parallel.f90:121-213.
+The second half models the LOCK-STEP ranks (k_mcmc<.., 4>): several ranks with their own streams and NO meeting of a rank's
+waves: every chain posts its own (T, L) when it commits, the wave of the rank's last chain posts the rank's header (pair on
+rank 0, the judge draw the rank would take, its stop request) -- into eight-slot rings in every rank's inbox; a chain wave
+looks at rank 0's header for the pair and waits for the partner's record only if its own chain is one of the two; ranks != 0
+bet that the judge draw is not theirs (lost: whoever learns the pair first anchors the next iteration one position later under
+a new epoch, before any wave of the rank commits a step of it); a stop asked for in the headers of iteration j ends the job
+after iteration j + 2 on every rank; after the loop the swap of the last iteration is applied to the rank's own chains --
+against the serial ranks of cls_parallel.f90:121-213.  (With four-slot rings the model deadlocks: a reader of the headers of
+iteration j - 4 can still be at work when a peer posts those of j.)
 
     python tools/flow_protocol_sim.py [n_cases]          # exits non-zero on the first difference
 """
@@ -312,12 +317,10 @@ def run_case(seed, verbose=False):
 
 
 # ======================================================================================================================
-# Lock-step ranks (k_mcmc<.., 4>: flow_post_record / flow_settle / flow_collect_records of csrc/htm_flow.hpp).  R ranks, each
-# with its own stream and nc chains; the pair of an iteration's swap is drawn by rank 0 from ITS stream (select_pair), the
-# judge draw by the rank of the pair's first chain from its own (cls_parallel.f90:121-213).  Every rank's last committer of an
-# iteration posts the rank's record into all inboxes; the first wave that needs the outcome collects the R records, applies
-# the swap, re-anchors the next iteration if the judge draw turned out to be this rank's (ranks != 0 bet that it is not),
-# spreads a stop request, and publishes xdone.
+# Lock-step ranks (k_mcmc<.., 4>: flow_post_chain / flow_post_header / flow_lock_swap / flow_lock_finish of csrc/htm_flow.hpp).
+# R ranks, each with its own stream and nc chains; the pair of an iteration's swap is drawn by rank 0 from ITS stream
+# (select_pair), the judge draw by the rank of the pair's first chain from its own (cls_parallel.f90:121-213).  Chains post their
+# (T, L), the last chain's wave the rank's header; nobody collects: each wave reads what its own chain needs.
 # ======================================================================================================================
 class LockStream(Stream):
     def __init__(self, seed, nc, p_rej, rank, R):
@@ -371,7 +374,8 @@ def serial_lock(sts, nc, R, n_iter, x0, L0, T0):
 
 
 def wave_lock(sh, st, net, w, NW, nc, R, rank, i0, rnd, trace):
-    """one chain wave of a lock-step rank; `net` = the inboxes of all ranks"""
+    """one chain wave of a lock-step rank; `net[q]` = rank q's inbox: "H"[j & 7][r] = (j, header of rank r), "C"[j & 7][(r, c)] =
+    (j, T, L) of chain c of rank r after iteration j"""
     key = lambda i, c: (i - i0) * nc + c
     nextB = lambda pos, n: st.next_from(pos, n)[1]
     my_epoch, my_akey = 0, 0
@@ -421,70 +425,6 @@ def wave_lock(sh, st, net, w, NW, nc, R, rank, i0, rnd, trace):
                 return e, a_key, a_pos
             e = e2
 
-    def collect(j):
-        """flow_collect_records(j): this wave has claimed iteration j's records"""
-        E = sh.Eof[j & 3]; yield
-        nd = st.nd_pred(E)
-        while True:                                   # exchange_finish: all R records of iteration j
-            box = dict(net[rank][j & 1]); yield
-            if all(box.get(q, (None,))[0] == j for q in range(R)):
-                break
-        recs = [box[q][1] for q in range(R)]
-        stop_any = any(rc_["stop"] for rc_ in recs)
-        i1, i2 = recs[0]["i1"], recs[0]["i2"]
-        if R * nc > 1:
-            r1, c1, r2, c2 = i1 // nc, i1 % nc, i2 // nc, i2 % nc
-            u = recs[r1]["u"]
-            if swap_outcome_lock(u, recs[r1]["L"][c1], recs[r2]["L"][c2], recs[r1]["T"][c1], recs[r2]["T"][c2]):
-                if rank == r1: sh.temp[c1] = recs[r2]["T"][c2]
-                if rank == r2: sh.temp[c2] = recs[r1]["T"][c1]
-            if rank == r1:
-                sh.spos += 1                           # the judge draw was this rank's
-        yield
-        base = sh.spos
-        if base != E + nd:
-            e1 = sh.epoch + 1
-            sh.anchor[e1 & 1] = (key(j + 1, 0), base - nd); yield
-            sh.epoch = e1; yield
-        if stop_any:
-            sh.last_iter = min(sh.last_iter, j); yield
-        sh.iter_done = j
-        sh.xdone = j; yield
-
-    def settle(j):
-        """flow_settle(j)"""
-        if j <= i0:
-            return
-        xd = sh.xdone; yield
-        if xd >= j:
-            return
-        mine = False
-        if sh.xclaim == j - 1:                        # (atomic compare-and-swap)
-            sh.xclaim = j; mine = True
-        yield
-        if mine:
-            yield from collect(j)
-            return
-        while True:
-            xd = sh.xdone; yield
-            if xd >= j:
-                return
-
-    def post(j):
-        """flow_post_record(j): the rank's last committer of iteration j"""
-        E = sh.Eof[j & 3]; yield
-        i1, i2, z = st.pair(E) if rank == 0 else (-1, -1, 0)
-        nd = st.nd_pred(E)
-        own = 1 if (rank == 0 and i1 >= 0 and i1 // nc == 0) else 0
-        jp = E + nd - own
-        rec = {"i1": i1, "i2": i2, "u": st.u(jp), "T": list(sh.temp), "L": list(sh.L),
-               "stop": sh.stop_at == j}
-        sh.spos = jp
-        sh.xcount[(j + 1) & 3] = 0; yield
-        order = list(range(R)); rnd.shuffle(order)
-        for q in order:                               # peer writes land one rank after the other
-            net[q][j & 1][rank] = (j, rec); yield
-
     while True:
         c = chains[ci]
         e = sh.epoch; yield
@@ -494,7 +434,6 @@ def wave_lock(sh, st, net, w, NW, nc, R, rank, i0, rnd, trace):
             adopt(e, a_key, a_pos, i, c, False)
         last = sh.last_iter; yield
         if i > last:
-            yield from settle(i - 1)                  # (a rank leaves only when the swap of its last iteration is applied)
             break
         assert c >= rc
         P = st.hop(rpos, c - rc)
@@ -540,27 +479,104 @@ def wave_lock(sh, st, net, w, NW, nc, R, rank, i0, rnd, trace):
             continue
         if stop:
             break
-        # ---- the swap of the iteration before: from ALL ranks' records
-        yield from settle(i - 1)
+        # ---- the swap of the iteration before (flow_step, LOCK): the pair is rank 0's; only the two chains it names look at
+        # ---- anybody's (T, L); a stop asked for in the headers of iteration i - 2 ends the job after THIS iteration
+        T_now = sh.temp[c]; yield
+        if i - 1 > i0 and R * nc > 1:
+            if i - 2 > i0:
+                while True:
+                    box = dict(net[rank]["H"][(i - 2) & 7]); yield
+                    if all(box.get(q, (None,))[0] == i - 2 for q in range(R)):
+                        break
+                if any(box[q][1]["stop"] for q in range(R)):
+                    sh.last_iter = min(sh.last_iter, i); yield          # (atomic min)
+            if rank == 0:
+                E1 = sh.Eof[(i - 1) & 3]; yield
+                i1, i2, z1 = st.pair(E1)
+            else:
+                while True:
+                    h = net[rank]["H"][(i - 1) & 7].get(0); yield
+                    if h is not None and h[0] == i - 1:
+                        break
+                i1, i2 = h[1]["i1"], h[1]["i2"]
+                E1 = sh.Eof[(i - 1) & 3]; yield
+                z1 = 0
+            r1 = i1 // nc
+            if rank != 0:
+                # the bet that the judge draw is not this rank's: whoever learns the pair first settles it for the rank
+                xa = sh.xanch; yield
+                if xa < i - 1:
+                    mine = False
+                    if sh.xanch_claim < i - 1:                         # (atomic max)
+                        sh.xanch_claim = i - 1; mine = True
+                    yield
+                    if mine:
+                        if r1 == rank:
+                            e1 = sh.epoch + 1
+                            sh.anchor[e1 & 1] = (key(i, 0), E1 + 1); yield
+                            sh.epoch = e1; yield
+                        sh.xanch = i - 1; yield
+                    else:
+                        while True:
+                            xa = sh.xanch; yield
+                            if xa >= i - 1:
+                                break
+            e = sh.epoch; yield
+            if e != my_epoch:
+                e, a_key, a_pos = yield from read_anchor()
+                if not adopt(e, a_key, a_pos, i, c, True):
+                    continue                               # the step starts elsewhere: again
+            g = rank * nc + c
+            if g == i1 or g == i2:
+                gp = i2 if g == i1 else i1
+                rp, cp = gp // nc, gp % nc
+                if rp == rank:
+                    while True:
+                        d = sh.done[cp]; yield
+                        if d >= key(i - 1, cp):
+                            break
+                    Tp, Lp = sh.T4[(i - 1) & 3][cp], sh.L4[(i - 1) & 3][cp]; yield
+                else:
+                    while True:
+                        cr = net[rank]["C"][(i - 1) & 7].get((rp, cp)); yield
+                        if cr is not None and cr[0] == i - 1:
+                            break
+                    Tp, Lp = cr[1], cr[2]
+                if r1 == rank:
+                    u = st.u(E1 + z1)
+                else:
+                    while True:
+                        h1 = net[rank]["H"][(i - 1) & 7].get(r1); yield
+                        if h1 is not None and h1[0] == i - 1:
+                            break
+                    u = h1[1]["u"]
+                if g == i1:
+                    acc_s = swap_outcome_lock(u, L, Lp, T_now, Tp)
+                else:
+                    acc_s = swap_outcome_lock(u, Lp, L, Tp, T_now)
+                if acc_s:
+                    T_now = Tp
+                sh.temp[c] = T_now; yield
         last = sh.last_iter; yield
         if i > last:
             break
-        e = sh.epoch; yield
-        if e != my_epoch:
-            e, a_key, a_pos = yield from read_anchor()
-            if not adopt(e, a_key, a_pos, i, c, True):
-                continue                               # the step starts elsewhere: again
-        T_now = sh.temp[c]; yield
         ok, cnt, acc, x2, L2_ = step_outcome(st, P, x, L, T_now)
         assert ok == ok_pre
         trace[(rank, i, c)] = P
         sh.x[c], sh.L[c] = x2, L2_; yield
+        sh.T4[i & 3][c], sh.L4[i & 3][c] = T_now, L2_; yield
         sh.done[c] = key(i, c); yield
-        sh.xcount[i & 3] += 1                          # (atomic)
-        is_last = sh.xcount[i & 3] == nc
-        yield
-        if is_last:
-            yield from post(i)
+        order = list(range(R)); rnd.shuffle(order)
+        for q in order:                               # this chain's record: peer writes land one rank after the other
+            net[q]["C"][i & 7][(rank, c)] = (i, T_now, L2_); yield
+        if c == nc - 1:
+            # the rank's header: pair (rank 0), the judge draw this rank would take, its stop request
+            E = P + cnt
+            i1h, i2h, zh = st.pair(E) if rank == 0 else (-1, -1, 0)
+            rec = {"i1": i1h, "i2": i2h, "u": st.u(E + zh), "stop": sh.stop_at == i}
+            rnd.shuffle(order)
+            for q in order:
+                net[q]["H"][i & 7][rank] = (i, rec); yield
         if not ok:
             a = (key(i, c) + 1, P + cnt)
             sh.anchor[(my_epoch + 1) & 1] = a; yield
@@ -577,6 +593,56 @@ def wave_lock(sh, st, net, w, NW, nc, R, rank, i0, rnd, trace):
     return
 
 
+def finish_lock(sh, st, net, nc, R, rank, i0, waves_alive):
+    """flow_body's epilogue on a lock-step rank: when all its waves have left, the swap of the last iteration is applied to the
+    rank's own chains and the stream position settled"""
+    while waves_alive[rank]:
+        yield
+    last = min(sh.last_iter, sh.target)
+    if last > i0 and R * nc > 1:
+        E = sh.Eof[last & 3]; yield
+        if rank == 0:
+            i1, i2, z = st.pair(E)
+        else:
+            while True:
+                h = net[rank]["H"][last & 7].get(0); yield
+                if h is not None and h[0] == last:
+                    break
+            i1, i2, z = h[1]["i1"], h[1]["i2"], 0
+        r1 = i1 // nc
+        for g, gp in ((i1, i2), (i2, i1)):
+            if g // nc != rank:
+                continue
+            c, rp, cp = g % nc, gp // nc, gp % nc
+            if rp == rank:
+                Tp, Lp = sh.T4[last & 3][cp], sh.L4[last & 3][cp]
+            else:
+                while True:
+                    cr = net[rank]["C"][last & 7].get((rp, cp)); yield
+                    if cr is not None and cr[0] == last:
+                        break
+                Tp, Lp = cr[1], cr[2]
+            if r1 == rank:
+                u = st.u(E + z)
+            else:
+                while True:
+                    h1 = net[rank]["H"][last & 7].get(r1); yield
+                    if h1 is not None and h1[0] == last:
+                        break
+                u = h1[1]["u"]
+            Tm, Lm = sh.T4[last & 3][c], sh.L4[last & 3][c]
+            acc_s = swap_outcome_lock(u, Lm, Lp, Tm, Tp) if g == i1 else swap_outcome_lock(u, Lp, Lm, Tp, Tm)
+            sh.newT[c] = Tp if acc_s else Tm
+        for c in range(nc):
+            if sh.newT[c] is not None:
+                sh.temp[c] = sh.newT[c]
+        sh.spos = E + z + (1 if r1 == rank else 0)
+    elif last > i0:
+        sh.spos = sh.Eof[last & 3]
+    sh.iter_done = last
+    yield
+
+
 def run_case_lock(seed, verbose=False):
     rnd = random.Random(seed * 7919 + 1)
     R = rnd.choice([1, 2, 2, 3, 4])
@@ -589,23 +655,31 @@ def run_case_lock(seed, verbose=False):
     L0 = [[h32(seed, 11, r, c) % 100000 for c in range(nc)] for r in range(R)]
     T0 = [[1 + r * nc + c for c in range(nc)] for r in range(R)]
     stop = rnd.choice([None, None, (rnd.randrange(R), rnd.randint(1, n_iter))])      # (rank, iteration) that asks everybody to stop
-    n_run = stop[1] if stop else n_iter
+    # a stop asked for in the headers of iteration j ends the job after iteration j + 2 (every rank reads the same headers)
+    n_run = min(n_iter, stop[1] + 2) if (stop and R * nc > 1) else n_iter
     xs, Ls, Ts, ps, tr_s = serial_lock(sts, nc, R, n_run, x0, L0, T0)
-    net = [[{}, {}] for _ in range(R)]
+    net = [{"H": [{} for _ in range(8)], "C": [{} for _ in range(8)]} for _ in range(R)]
     shs, gens, trace = [], [], {}
     i0 = 0
+    waves_alive = [0] * R
     for r in range(R):
         sh = Shared()
         sh.epoch, sh.anchor = 0, [(0, 0), (0, 0)]
         sh.prog = [(0, c, 0) for c in range(nc)]
         sh.done = [c for c in range(nc)]
         sh.x, sh.L, sh.temp = list(x0[r]), list(L0[r]), list(T0[r])
-        sh.last_iter = n_iter
+        sh.T4 = [[None] * nc for _ in range(4)]; sh.L4 = [[None] * nc for _ in range(4)]
+        sh.newT = [None] * nc
+        sh.last_iter = n_iter; sh.target = n_iter
         sh.stop_at = stop[1] if (stop and stop[0] == r) else None
         sh.Eof = [0, 0, 0, 0]
-        sh.xcount, sh.xclaim, sh.xdone, sh.spos, sh.iter_done = [0, 0, 0, 0], i0, i0, 0, i0
+        sh.xanch, sh.xanch_claim, sh.spos, sh.iter_done = i0, i0, 0, i0
         shs.append(sh)
-        gens += [(r, wave_lock(sh, sts[r], net, w, NW, nc, R, r, i0, rnd, trace)) for w in range(NW)]
+        for w in range(NW):
+            if w < nc:
+                waves_alive[r] += 1
+            gens.append((r, True, wave_lock(sh, sts[r], net, w, NW, nc, R, r, i0, rnd, trace)))
+        gens.append((r, False, finish_lock(sh, sts[r], net, nc, R, r, i0, waves_alive)))
     alive = list(range(len(gens)))
     slow_rank = rnd.choice([None, None, rnd.randrange(R)])      # a rank that is scheduled rarely
     steps = 0
@@ -614,11 +688,19 @@ def run_case_lock(seed, verbose=False):
         if slow_rank is not None and gens[k][0] == slow_rank and rnd.random() < 0.8:
             continue
         try:
-            next(gens[k][1])
+            next(gens[k][2])
         except StopIteration:
             alive.remove(k)
+            if gens[k][1] and k % (NW + 1) < nc:
+                waves_alive[gens[k][0]] -= 1
         steps += 1
-        if steps > 20_000_000:
+        if steps > 3_000_000:
+            for k2 in alive:                              # where every coroutine stands
+                fr = gens[k2][2].gi_frame
+                print("  rank %d %s line %d  i=%s c=%s my_epoch=%s" % (gens[k2][0], "wave" if gens[k2][1] else "finish", fr.f_lineno,
+                      fr.f_locals.get("i"), fr.f_locals.get("c"), fr.f_locals.get("my_epoch")))
+            for r in range(R):
+                print("  rank %d epoch %d anchor %s prog %s xanch %d last %d" % (r, shs[r].epoch, shs[r].anchor, shs[r].prog, shs[r].xanch, shs[r].last_iter))
             raise RuntimeError("no progress (deadlock or livelock): lock-step seed %d" % seed)
     ok = all(shs[r].x == xs[r] and shs[r].L == Ls[r] and shs[r].temp == Ts[r] and shs[r].spos == ps[r] and
              shs[r].iter_done == n_run for r in range(R)) and trace == tr_s
@@ -630,6 +712,9 @@ def run_case_lock(seed, verbose=False):
                 if trace.get(k) != tr_s[k]:
                     print("  first differing step (rank, iteration, chain)", k, "serial", tr_s[k], "flow", trace.get(k))
                     break
+            extra = sorted(k for k in trace if k not in tr_s)
+            if extra:
+                print("  steps the serial ranks did not take:", extra[:6])
             for r in range(R):
                 print("  rank", r, "x", shs[r].x == xs[r], "L", shs[r].L == Ls[r], "T", shs[r].temp == Ts[r], "pos", shs[r].spos, ps[r],
                       "done", shs[r].iter_done, n_run)

@@ -21,10 +21,10 @@ data = synth.make_synthetic(E_, S_, 1)
 params = dict(synth.DEFAULT_PARAMS, n_procs=1, n_chains=nc, n_cool=1, n_iter=10**7, n_burn=10**9, n_interval=1000)
 obs = ObsData.from_arrays(data.sta_x, data.sta_y, data.t_obs, data.t_stdv, data.a_obs, data.a_stdv)
 fwd, cs = driver.build_rank(params, data.sta_x, data.sta_y, data.sta_z, obs, 0, n_procs=1)
-if os.environ.get("HTM_STAMPS_LOCK") == "1":        # the lock-step ranks' loop (k_mcmc<.., 4>), one rank
-    from hypotremormcmc_amd.parallel import LocalWorld
-    _w = LocalWorld([cs])
-    _run = _w.run
+if os.environ.get("HTM_STAMPS_LOCK") == "1":        # the lock-step ranks' loop (k_mcmc<.., 4>, MODE_LOCKRUN), one rank: its own inbox only
+    cs.xchg_handle()
+    cs.xchg_connect(None)
+    _run = cs.run_lockstep_direct
 else:
     _run = cs.run
 _run(2000 if E_ <= 1000 else 300)
@@ -41,16 +41,16 @@ lib.htm_chains_read_stamps(cs.handle, a)
 d = [a[k] - base[k] for k in range(128)]
 names = ["front: loads issued", "proposal, check published", "evaluation (2 positions)", "turn", "swap + decision + commit", "records + orders"]
 print("ticks per step, by wave (partial-update steps); full-evaluation steps: total ticks per step (of which waiting for the workers)")
-print("%-4s %8s " % ("wave", "steps") + " ".join("%9s" % s[:9] for s in names) + " %9s | %7s %9s %9s | %9s %9s" % ("sum", "jobs", "ticks", "wait", "loop/iter", "between"))
+print("%-4s %8s " % ("wave", "steps") + " ".join("%9s" % s[:9] for s in names) + " %9s %9s | %7s %9s %9s | %9s %9s" % ("lock-step", "sum", "jobs", "ticks", "wait", "loop/iter", "between"))
 for w in range(min(8, nc)):
     b = d[32 + 12 * w:32 + 12 * w + 12]
     ns, nj = max(1, b[7]), max(1, b[8])
     ph = [b[k] / ns for k in range(6)]
     steps = b[7] + b[8]
     iters = steps / max(1, len(range(w, nc, 8)))
-    inside = sum(b[:6]) + b[6]
-    print("%-4d %8d " % (w, b[7]) + " ".join("%9.0f" % x for x in ph) + " %9.0f | %7d %9.0f %9.0f | %9.0f %9.0f" %
-          (sum(ph), b[8], b[6] / nj, b[10] / nj, b[11] / max(1.0, iters), (b[11] - inside) / max(1, steps)))
+    inside = sum(b[:6]) + b[6] + b[9]
+    print("%-4d %8d " % (w, b[7]) + " ".join("%9.0f" % x for x in ph) + " %9.0f %9.0f | %7d %9.0f %9.0f | %9.0f %9.0f" %
+          (b[9] / ns, sum(ph) + b[9] / ns, b[8], b[6] / nj, b[10] / nj, b[11] / max(1.0, iters), (b[11] - inside) / max(1, steps)))
 
 # worker block 0, thread 0 (100 MHz ticks summed over its jobs): order seen -> its events evaluated -> block sum stored
 jobs_all = sum(d[32 + 12 * w + 8] for w in range(min(8, nc)))
