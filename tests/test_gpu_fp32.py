@@ -15,6 +15,14 @@ sum (:281-299), the Metropolis decision (src/cls_mcmc.f90:194-199) -- checked ag
   T4  chains: over a few hundred iterations at the configs[4] per-GPU shape (16 chains) the fp32 and the fp64 run
       accept the same number of proposals per type within 4 binomial sigma + 2 % and their cold chains'
       log-likelihoods agree to 2e-3 relative.
+  T5  near the posterior: a model within one (small) step of the truth, proposals of 0.05 km -- the differences judged are of
+      order one, where a 5e-4 error can reach a Metropolis comparison: over 10 000 proposals with common random numbers fewer
+      than 0.2 % of the decisions differ, and the error keeps T2's bounds;
+  T6  posterior level, the only tolerance that means something for a sampler: the same job run with the fp64 forward, with the
+      fp64 forward and other random seeds, and with the fp32 forward; medians and 2.5 % / 97.5 % points of EVERY parameter from
+      the device's step-6 statistics (htm_quantiles).  The fp32 run differs from the fp64 run by no more than two fp64 runs
+      with different seeds differ from each other (in units of each parameter's posterior width): rms <= 1.3 x + 0.05 -- both
+      with the first run's seeds (common random numbers: the runs part only where a decision flips) and with the other seeds.
 The measured values are written to gpurun_out/fp32_tolerances.txt."""
 import os
 
@@ -90,6 +98,80 @@ def test_fp32_full_and_partial_likelihood_against_fp64(E, S, seed):
           f"differences rms {np.sqrt((dL ** 2).mean()):.3e}; T3 decision flips {flips:.4f}")
     assert abs(err.mean()) <= 2e-3 and np.sqrt((err ** 2).mean()) <= 1e-2
     assert flips <= 0.005
+
+
+def test_fp32_decisions_near_the_posterior():
+    """T5: where |dL| ~ 1 (src/cls_mcmc.f90:193-203 compares log r with dL / T + prior ratio)"""
+    from hypotremormcmc_amd import synth
+    from oracle import oracle
+
+    E, S = 1000, 64
+    data = synth.make_synthetic(E, S, 1)
+    f64, f32 = _forwards(data)
+    orc = oracle.Forward(data.sta_x, data.sta_y, data.sta_z, data.t_obs, data.t_stdv, data.a_obs, data.a_stdv, True, True)
+    rng = np.random.default_rng(77)
+    step = 0.05
+    h = (data.ev_xyz + rng.normal(0, step, data.ev_xyz.shape)).reshape(-1)
+    tc, ac, vs, qs = rng.normal(0, 0.01, S), rng.normal(0, 0.002, S), 3.0 + rng.normal(0, 0.005), 250.0 + rng.normal(0, 2.0)
+    L0 = orc.calc_log_likelihood(h, tc, vs, ac, qs)
+    n = 10000
+    err, dL = np.empty(n), np.empty(n)
+    for k in range(n):
+        evt = int(rng.integers(1, E + 1))
+        h2 = h.copy()
+        h2[3 * (evt - 1) + int(rng.integers(0, 3))] += rng.normal(0, step)
+        d64 = orc.partially_update_log_likelihood(evt, h, L0, h2, tc, vs, ac, qs) - L0
+        d32 = f32.partially_update_log_likelihood(evt, h, L0, h2, tc, vs, ac, qs) - L0
+        err[k], dL[k] = d32 - d64, d64
+    logr = np.log(rng.uniform(size=n))
+    flips = int(np.sum((logr <= dL) != (logr <= dL + err)))
+    acc = float(np.mean(logr <= dL))
+    _note(f"T5 {E}x{S} near the truth (step {step} km): judged differences median |dL| {np.median(np.abs(dL)):.3f}, rms {np.sqrt((dL ** 2).mean()):.3f}, "
+          f"acceptance {acc:.3f}; error mean {err.mean():.3e} rms {np.sqrt((err ** 2).mean()):.3e} max {np.abs(err).max():.3e}; "
+          f"decisions that differ {flips}/{n}")
+    assert 0.05 < acc < 0.95 and np.median(np.abs(dL)) < 5.0, "not the regime this test is about"
+    assert abs(err.mean()) <= 2e-3 and np.sqrt((err ** 2).mean()) <= 1e-2
+    assert flips <= 0.002 * n
+
+
+@pytest.mark.parametrize("E,S,nc,n_iter", [(100, 16, 8, 4_000_000), (1000, 64, 8, 600_000)])
+def test_fp32_posterior_quantiles_within_monte_carlo_error(E, S, nc, n_iter, monkeypatch):
+    """T6: medians and 2.5 % / 97.5 % points of every parameter (src/cls_statistics.f90:216-264) from the fp32-forward run against
+    the Monte-Carlo error of the fp64 run -- two fp64 runs whose random streams start from other seeds
+    (src/hypo_tremor_mcmc.f90:72)"""
+    from hypotremormcmc_amd import driver, statistics, synth
+    from hypotremormcmc_amd.obs_data import ObsData
+
+    data = synth.make_synthetic(E, S, 3)
+    obs = ObsData.from_arrays(data.sta_x, data.sta_y, data.t_obs, data.t_stdv, data.a_obs, data.a_stdv)
+
+    def run(prec, seeds):
+        monkeypatch.setattr(driver, "SEEDS", seeds)
+        params = dict(synth.DEFAULT_PARAMS, n_procs=1, n_chains=nc, n_cool=2, n_iter=n_iter, n_burn=n_iter // 3, n_interval=100,
+                      forward_precision=prec)
+        fwd, cs = driver.build_rank(params, data.sta_x, data.sta_y, data.sta_z, obs, 0, n_procs=1)
+        cs.run(n_iter)
+        sm = cs.samples()
+        cols = np.concatenate([sm["vs"][:, None], sm["qs"][:, None], sm["t_corr"], sm["a_corr"], sm["hypo"]], axis=1)
+        acc = cs.counts()
+        del cs, fwd
+        return statistics.quantiles(cols), len(cols), acc
+
+    base, other = (5551111, 453222, 4444431, 6765), (7712345, 991234, 1357911, 424242)
+    qa, na, _ = run("fp64", base)
+    qb, nb, _ = run("fp64", other)
+    q32, n32, _ = run("fp32", base)          # common random numbers with the first run: differs from it only through flipped decisions
+    q32b, n32b, _ = run("fp32", other)       # ... and against the first run as an independent sampler
+    assert na == nb == n32 == n32b == 2 * (n_iter - n_iter // 3) // 100
+    width = np.maximum((qa[:, 2] - qa[:, 0]) / 3.92, 1e-12)[:, None]
+    rms = lambda z: float(np.sqrt(np.mean(z ** 2)))
+    zb, z32, z32b = (qb - qa) / width, (q32 - qa) / width, (q32b - qa) / width
+    _note(f"T6 {E}x{S}x{nc}, {n_iter} iterations, {na} samples, {qa.shape[0]} parameters x 3 quantiles, in posterior widths: "
+          f"fp64 (other seeds) - fp64: rms {rms(zb):.3f} max {np.abs(zb).max():.3f};  fp32 (same seeds) - fp64: rms {rms(z32):.3f} max "
+          f"{np.abs(z32).max():.3f};  fp32 (other seeds) - fp64: rms {rms(z32b):.3f} max {np.abs(z32b).max():.3f}; "
+          f"medians only: {rms(zb[:, 1]):.3f} / {rms(z32[:, 1]):.3f} / {rms(z32b[:, 1]):.3f}")
+    assert rms(z32) <= 1.3 * rms(zb) + 0.05 and rms(z32b) <= 1.3 * rms(zb) + 0.05
+    assert np.abs(z32).max() <= 1.5 * np.abs(zb).max() + 0.25
 
 
 def test_fp32_chains_at_the_configs4_shape_agree_statistically():
