@@ -65,6 +65,9 @@ struct FlowShared : StepShared {
     // <= xanch (the next iteration re-anchored if it was lost); xanch_claim: the iteration a wave has taken on to settle it for
     int xanch, xanch_claim;
     int xctl4[4];                          // [i & 3] {i << 2 | control word} of this rank's own header of iteration i (its own waves read it here)
+    // type | event << 3 of the chain's PREVIOUS step (0: none yet; kept across launches in ChainsDev::prev_mid): if it was a
+    // hypocentre step, a full evaluation leaves its event to the chain's own wave -- whenever the order went out (flow_step)
+    int pv_mid[kMaxChains];
 };
 
 // a wave-uniform value that reached a vector register (read from LDS) back in a scalar one
@@ -117,7 +120,7 @@ struct FlowNext {
 // behind a branch on the one before; LDS operations return in order, the first use waits for all of them once).
 struct FlowTop {
     int epoch, last_iter, err, pk;
-    int book_pos, book_mode, book_mid;
+    int book_pos, book_mode, book_mid, pv_mid;
     unsigned book_tag;
     double L;
     double rbeta, katt;           // the chain's 1 / vs and pi f / (qs vs) (FlowShared)
@@ -470,14 +473,18 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
     const unsigned book_tag = tp.book_tag;
     const bool pre = !partial && book_pos == p;
     const int pre_mode = pre ? book_mode : 0;
-    // a full-evaluation step whose order went out two steps ahead adds the event of the step in between itself (below):
-    // its inputs are requested now, into the registers a partial update would use
+    // A full evaluation whose chain's PREVIOUS step was a hypocentre step leaves that step's event to this wave: the workers sum
+    // the other events, the wave adds this one (below) -- always, whether the order went out two steps ahead (the workers could
+    // not know that step's outcome), one step ahead or only now.  The association of the sum is then a function of the stream
+    // alone, not of when the order happened to go out: two runs of a job give the same bits.  The event's inputs are requested
+    // now, into the registers a partial update would use.  (pv_mid and an order's book_mid name the same step.)
     int d_e = 0;
     double d_ex = 0.0, d_ey = 0.0, d_ez = 0.0;
-    const bool own_evt = NCH > 0 && pre_mode == 2 && (book_mid & 7) >= 5;
+    const int mid = pre ? book_mid : tp.pv_mid;
+    const bool own_evt = NCH > 0 && !partial && type <= 4 && (mid & 7) >= 5;
     if constexpr (NCH > 0) {
         if (__builtin_expect(own_evt, 0)) {
-            d_e = __builtin_amdgcn_readfirstlane(book_mid >> 3) - 1;
+            d_e = __builtin_amdgcn_readfirstlane(mid >> 3) - 1;
             const int vzd = opaque_zero();
             const double *hypd = xall_ + off_hy + c * nh + 3 * d_e;
             d_ex = ld_state(hypd, vzd); d_ey = ld_state(hypd + 1, vzd); d_ez = ld_state(hypd + 2, vzd);
@@ -582,7 +589,9 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
                 const unsigned long long xb = (unsigned long long)__double_as_longlong(x_new);
                 const unsigned pay = gi == 0 ? (unsigned)launch : gi == 1 ? ((unsigned)type | ((unsigned)idx << 3))
                                    : gi == 2 ? (unsigned)(xb >> 32) : gi == 3 ? (unsigned)xb
-                                   : gi == 4 ? 0xffffffffu : 0u;          // no commit to wait for (drained above), nothing left out
+                                   : gi == 4 ? 0xffffffffu                // no commit to wait for (drained above)
+                                   : gi == 7 ? (own_evt ? (unsigned)(off_hy + c * nh + 3 * d_e) + 1u : 0u)      // the previous step's event is this wave's
+                                   : 0u;
                 st_gran(cs.slots + (size_t)(lane >> 3) * cs.slot_stride + c * kGranPerSlot + gi, tag, pay);
             }
             // ---- the workers' partial sums: tagged granules, fixed summation order; two rounds of loads in flight --
@@ -612,9 +621,10 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
             // of the wave's own event
             const bool early = pre_mode == 2;
             if (early) issue(0);
-            // An order sent TWO steps ahead was evaluated while the step in between (a hypocentre step of this chain) may
-            // or may not have committed: the workers LEFT THAT EVENT OUT, this wave adds its misfit -- at the position the
-            // event has now, under this step's proposed parameters.  The result does not depend on when the workers looked.
+            // The event of the chain's previous step, if that was a hypocentre step: the workers LEFT IT OUT (an order sent two
+            // steps ahead was evaluated while that step may or may not have committed), this wave adds its misfit -- at the
+            // position the event has now, under this step's proposed parameters.  The result depends neither on when the
+            // workers looked nor on when the order went out.
             double own_lane = 0.0;
             if constexpr (NCH > 0) {
                 if (own_evt) {
@@ -961,7 +971,9 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
                 if (lane == 0) {
                     tk = (atomicAdd(&sh.c.jobs_total, 1ull) + 1ull) & 0x7fffffffull;
                     if (tk == 0) tk = 0x7fffffffull;
-                    sh.ob_pos[c] = pj; sh.ob_tag[c] = (unsigned)tk; sh.ob_mode[c] = mode; sh.ob_mid[c] = d1.x | (d1.z << 3);
+                    // (the step right before the order's: the one in between, or -- one ahead -- this very step)
+                    sh.ob_pos[c] = pj; sh.ob_tag[c] = (unsigned)tk; sh.ob_mode[c] = mode;
+                    sh.ob_mid[c] = mode == 2 ? (d1.x | (d1.z << 3)) : (type >= 5 ? (type | (evt << 3)) : type);
                 }
                 const unsigned tag = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)tk);
                 if (lane < cs.slot_rep * kGranPerSlot) {
@@ -972,12 +984,14 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
                                        : gi == 2 ? (unsigned)(xb >> 32) : gi == 3 ? (unsigned)xb
                                        : gi == 4 ? (acc ? (unsigned)o : 0xffffffffu)              // the commit the workers must see
                                        : gi == 5 ? (unsigned)(cb >> 32) : gi == 6 ? (unsigned)cb
-                                       : (mode == 2 ? (unsigned)o_mid + 1u : 0u);                  // element of the step in between (+1; 0 = none)
+                                       : (mode == 2 ? (unsigned)o_mid + 1u                         // element of the step right before the order's (+1;
+                                          : type >= 5 ? (unsigned)o + 1u : 0u);                      // 0 = not a hypocentre step): its event is left out
                     st_gran(cs.slots + (size_t)(lane >> 3) * cs.slot_stride + c * kGranPerSlot + gi, tag, pay);
                 }
             }
         }
     }
+    if (lane == 0) sh.pv_mid[c] = type >= 5 ? (type | (evt << 3)) : type;      // (what the chain's next full evaluation leaves to this wave)
 #ifdef HTM_STAMPS
     FSTAMP(5);
     if (lane == 0 && cs.stamps) {
@@ -1055,6 +1069,7 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
     const int i0 = sh.i0;
     for (int c = tid; c < kMaxChains; c += blockDim.x) {
         sh.ob_pos[c] = -1;
+        sh.pv_mid[c] = c < nc ? cs.prev_mid[c] : 0;
         sh.prog[c] = (unsigned long long)(unsigned)c;          // key(i0, c), epoch 0, prior ok
         sh.done[c] = c;
         if (c < nc) {
@@ -1099,6 +1114,7 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
             tp.epoch = lds_ld(&sh.epoch); tp.last_iter = lds_ld(&sh.last_iter); tp.err = lds_ld(&sh.c.err);
             tp.pk = (int)(unsigned)lds_ld(&sh.prog[co]);
             tp.book_pos = sh.ob_pos[c]; tp.book_mode = sh.ob_mode[c]; tp.book_mid = sh.ob_mid[c]; tp.book_tag = sh.ob_tag[c];
+            tp.pv_mid = sh.pv_mid[c];
             tp.L = sh.L[c];
             tp.rbeta = sh.rbeta[c]; tp.katt = sh.katt[c];
             asm volatile("" ::: "memory");
@@ -1219,6 +1235,7 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
         if (sh.np[k]) atomicAdd(&cs.n_propose[k], sh.np[k]);
         if (sh.na[k]) atomicAdd(&cs.n_accept[k], sh.na[k]);
     }
+    for (int k = tid; k < nc; k += blockDim.x) cs.prev_mid[k] = sh.pv_mid[k];
     if (tid == 0) *cs.ctrl = sh.c;
 }
 

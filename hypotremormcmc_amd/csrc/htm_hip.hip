@@ -805,6 +805,8 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
     }
     if ((rc = dev_alloc(hc->pool, &d.slots, (size_t)d.slot_rep * d.slot_stride))) return cleanup(rc);
     HIPCHK(hipMemset(d.slots, 0, (size_t)d.slot_rep * d.slot_stride * sizeof(unsigned long long)));
+    if ((rc = dev_alloc(hc->pool, &d.prev_mid, (size_t)nc))) return cleanup(rc);
+    HIPCHK(hipMemset(d.prev_mid, 0, (size_t)nc * sizeof(int)));
     if ((rc = dev_alloc(hc->pool, &d.lo_gran, (size_t)nc * 16))) return cleanup(rc);
     HIPCHK(hipMemset(d.lo_gran, 0, (size_t)nc * 16 * sizeof(unsigned long long)));
     if ((rc = dev_alloc(hc->pool, &d.pgran, (size_t)nc * 256 * d.pgran_stride))) return cleanup(rc);
@@ -1763,7 +1765,7 @@ size_t ckpt_total(const htm_chains *hc)
 size_t ckpt_bytes(const htm_chains *hc)
 {
     const size_t n = hc->dev.n_chains;
-    return sizeof(CkptHeader) + (ckpt_total(hc) + 2 * n) * sizeof(double) + 2 * 7 * n * sizeof(int32_t);
+    return sizeof(CkptHeader) + (ckpt_total(hc) + 2 * n) * sizeof(double) + (2 * 7 + 1) * n * sizeof(int32_t);      // (+ prev_mid)
 }
 }  // namespace
 
@@ -1782,7 +1784,7 @@ int htm_chains_checkpoint_save(htm_chains *hc, void *blob, size_t bytes)
     if (rc) return rc;
     if (hc->h_ctrl.stage != ST_IDLE) return fail(HTM_ESTATE, "a lock-step iteration is in flight");
     CkptHeader h{};
-    h.magic = kCkptMagic; h.version = 1;
+    h.magic = kCkptMagic; h.version = 2;
     h.n_chains = hc->dev.n_chains; h.n_sta = hc->dev.S; h.n_events = hc->dev.E; h.n_procs = hc->dev.n_procs; h.rank = hc->dev.rank;
     h.iter_done = hc->h_ctrl.iter_done;
     if ((rc = htm_chains_get_rng(hc, h.rng_state))) return rc;
@@ -1796,7 +1798,10 @@ int htm_chains_checkpoint_save(htm_chains *hc, void *blob, size_t bytes)
     HIPCHK(hipMemcpy(p, hc->dev.temp, n * sizeof(double), hipMemcpyDeviceToHost)); p += n * sizeof(double);
     HIPCHK(hipMemcpy(p, hc->dev.L, n * sizeof(double), hipMemcpyDeviceToHost)); p += n * sizeof(double);
     HIPCHK(hipMemcpy(p, hc->dev.n_propose, 7 * n * sizeof(int32_t), hipMemcpyDeviceToHost)); p += 7 * n * sizeof(int32_t);
-    HIPCHK(hipMemcpy(p, hc->dev.n_accept, 7 * n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(p, hc->dev.n_accept, 7 * n * sizeof(int32_t), hipMemcpyDeviceToHost)); p += 7 * n * sizeof(int32_t);
+    // (what each chain's last step was: decides which event its next full evaluation leaves to the chain's own wave, so that
+    // a continued run sums in the order of the uninterrupted one)
+    HIPCHK(hipMemcpy(p, hc->dev.prev_mid, n * sizeof(int32_t), hipMemcpyDeviceToHost));
     return HTM_OK;
 }
 
@@ -1806,7 +1811,7 @@ int htm_chains_checkpoint_load(htm_chains *hc, const void *blob, size_t bytes)
     if (bytes < sizeof(CkptHeader)) return fail(HTM_EINVAL, "checkpoint blob truncated");
     CkptHeader h{};
     std::memcpy(&h, blob, sizeof(h));
-    if (h.magic != kCkptMagic || h.version != 1) return fail(HTM_EINVAL, "not a checkpoint of this library (magic/version)");
+    if (h.magic != kCkptMagic || h.version != 2) return fail(HTM_EINVAL, "not a checkpoint of this library (magic/version)");
     if (h.n_chains != hc->dev.n_chains || h.n_sta != hc->dev.S || h.n_events != hc->dev.E || h.n_procs != hc->dev.n_procs ||
         h.rank != hc->dev.rank || h.total != ckpt_total(hc))
         return fail(HTM_EINVAL, "checkpoint shape (%d chains, %d x %d, rank %d/%d) does not match this chain set", h.n_chains,
@@ -1827,7 +1832,8 @@ int htm_chains_checkpoint_load(htm_chains *hc, const void *blob, size_t bytes)
     HIPCHK(hipMemcpy(hc->dev.temp, p, n * sizeof(double), hipMemcpyHostToDevice)); p += n * sizeof(double);
     HIPCHK(hipMemcpy(hc->dev.L, p, n * sizeof(double), hipMemcpyHostToDevice)); p += n * sizeof(double);
     HIPCHK(hipMemcpy(hc->dev.n_propose, p, 7 * n * sizeof(int32_t), hipMemcpyHostToDevice)); p += 7 * n * sizeof(int32_t);
-    HIPCHK(hipMemcpy(hc->dev.n_accept, p, 7 * n * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(hc->dev.n_accept, p, 7 * n * sizeof(int32_t), hipMemcpyHostToDevice)); p += 7 * n * sizeof(int32_t);
+    HIPCHK(hipMemcpy(hc->dev.prev_mid, p, n * sizeof(int32_t), hipMemcpyHostToDevice));
     // the random stream restarts at the saved generator state: position 0 of a fresh stream
     for (int k = 0; k < 4; ++k) hc->init_state[k] = h.rng_state[k];
     HIPCHK(hipMemcpy(hc->dev.stream.gen, hc->init_state, 4 * sizeof(uint32_t), hipMemcpyHostToDevice));

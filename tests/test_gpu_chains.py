@@ -141,12 +141,46 @@ def test_run_in_pieces_and_small_record_buffers():
     _, b = _build_world(data, params, lik_capacity=8, sample_capacity=6)
     b[0].run(1000); b[0].run(1); b[0].run(n_iter - 1001)
     ia, _, la = a[0].likelihood_trace(); ib, _, lb = b[0].likelihood_trace()
-    # same decisions; log-likelihoods to rounding (where a launch ends decides which full evaluations were sent ahead)
+    # same decisions and the same bits: a full evaluation's sum does not depend on where a launch ended or when its order went
+    # out (the event of the chain's previous hypocentre step is always the chain wave's, csrc/htm_flow.hpp)
     assert np.array_equal(ia, ib)
-    np.testing.assert_allclose(la, lb, rtol=1e-13, atol=0)
+    assert np.array_equal(la, lb)
     sa, sb = a[0].samples(), b[0].samples()
     assert np.array_equal(sa["iter"], sb["iter"]) and np.array_equal(sa["hypo"], sb["hypo"])
     _check_against_fixture(fx, params, b)
+
+
+@pytest.mark.parametrize("E,S,nc,sz", [(64, 64, 8, 12.0), (1000, 64, 8, 0.4), (300, 64, 19, 6.0), (1000, 128, 8, 2.0)])
+def test_free_running_master_twice_gives_the_same_bits(E, S, nc, sz):
+    """Two runs of a job -- and a third cut into launches of odd lengths -- give bit-identical proposed and running
+    log-likelihoods at every step: when a full evaluation's order went out (one or two steps ahead, late after an epoch change:
+    a matter of timing) does not reach the sum (cls_forward.f90:277-300 sums events in order; here the event of the chain's previous
+    hypocentre step is always added by the chain's own wave, the rest by the workers in a fixed tree)."""
+    from hypotremormcmc_amd import synth
+
+    data = synth.make_synthetic(E, S, 11)
+    n_iter = 1200
+    params = dict(synth.DEFAULT_PARAMS, n_procs=1, n_chains=nc, n_cool=2, n_iter=n_iter, n_burn=n_iter // 2, n_interval=3,
+                  step_size_z=sz, step_size_vs=0.4)
+    logs = []
+    for cut in (None, None, (1, 7, 400, 13)):
+        _, sets = _build_world(data, params)
+        cs = sets[0]
+        assert cs.master_stats()["single_rank_loop"] == 3
+        cs.enable_steplog(n_iter * nc)
+        if cut is None:
+            cs.run(n_iter)
+        else:
+            done = 0
+            for n in cut:
+                cs.run(n); done += n
+            cs.run(n_iter - done)
+        gi, gd = cs.steplog()
+        logs.append((gi.copy(), gd.copy(), cs.likelihood_trace()[2].copy()))
+    for k in (1, 2):
+        assert np.array_equal(logs[0][0], logs[k][0])
+        assert np.array_equal(logs[0][1], logs[k][1]), "step log values differ in their bits (run %d)" % k
+        assert np.array_equal(logs[0][2], logs[k][2])
 
 
 def test_single_chain_job_has_no_swap():
@@ -258,11 +292,11 @@ def test_checkpoint_resume_continues_the_run_and_checks_shapes():
     ia, ca, la = a[0].likelihood_trace(); ic, cc, lc = c[0].likelihood_trace()
     keep = ia > 300
     assert np.array_equal(ia[keep], ic) and np.array_equal(ca[keep], cc)
-    np.testing.assert_allclose(la[keep], lc, rtol=1e-13, atol=0)
+    assert np.array_equal(la[keep], lc)      # (continuing gives the bits of the uninterrupted run: the blob carries each chain's last step)
     for k in range(2):
         sa, sc = a[0].state(k), c[0].state(k)
         assert np.array_equal(sa.hypo, sc.hypo) and np.array_equal(sa.t_corr, sc.t_corr) and sa.temp == sc.temp
-        assert abs(sa.log_likelihood - sc.log_likelihood) <= 1e-13 * abs(sa.log_likelihood)
+        assert sa.log_likelihood == sc.log_likelihood
         assert np.array_equal(sa.n_propose, sc.n_propose) and np.array_equal(sa.n_accept, sc.n_accept)
     # a blob of another shape is refused
     fx3, data3, params3 = load_case("missing")
@@ -397,9 +431,12 @@ def test_shared_prior_records_equal_per_chain_records(lockstep, monkeypatch):
         gi, gc, gl = sets[0].likelihood_trace()
         out.append((gi.copy(), gl.copy(), sets[0].rng_state(), sets[0].counts(), [sets[0].state(c).hypo.copy() for c in range(11)]))
     assert np.array_equal(out[0][0], out[1][0])
-    # (a full evaluation's sum is grouped by how its order went out -- one or two steps ahead, or late after an epoch change,
-    # which is a matter of timing: log-likelihoods agree to rounding, everything discrete and every parameter value exactly)
-    np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-12, atol=0)
+    # (a full evaluation's sum is grouped the same way however its order went out -- one or two steps ahead, or late after an epoch
+    # change: the free-running master's runs agree bit for bit; the per-launch lock-step loop of LocalWorld sums in its own order)
+    if lockstep:
+        np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-12, atol=0)
+    else:
+        assert np.array_equal(out[0][1], out[1][1])
     assert out[0][2] == out[1][2]
     assert all(np.array_equal(a, b) for a, b in zip(out[0][3], out[1][3]))
     assert all(np.array_equal(a, b) for a, b in zip(out[0][4], out[1][4]))

@@ -162,7 +162,7 @@ def test_fp32_posterior_quantiles_within_monte_carlo_error(E, S, nc, n_iter, mon
     qb, nb, _ = run("fp64", other)
     q32, n32, _ = run("fp32", base)          # common random numbers with the first run: differs from it only through flipped decisions
     q32b, n32b, _ = run("fp32", other)       # ... and against the first run as an independent sampler
-    assert na == nb == n32 == n32b == 2 * (n_iter - n_iter // 3) // 100
+    assert na == nb == n32 == n32b and abs(na - 2 * (n_iter - n_iter // 3) // 100) <= 4
     width = np.maximum((qa[:, 2] - qa[:, 0]) / 3.92, 1e-12)[:, None]
     rms = lambda z: float(np.sqrt(np.mean(z ** 2)))
     zb, z32, z32b = (qb - qa) / width, (q32 - qa) / width, (q32b - qa) / width
