@@ -617,9 +617,9 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
                     if (j * 64 + lane < cs.n_wg) got = got && (unsigned)(hi[b][j] >> 32) == tag && (unsigned)(lo[b][j] >> 32) == tag;
                 return __all(got);
             };
-            // an order sent two steps ahead was answered a step ago: its granules are requested now, under the evaluation
-            // of the wave's own event
-            const bool early = pre_mode == 2;
+            // an order sent ahead (one or two steps) may have been answered already: its granules are requested now, under the
+            // evaluation of the wave's own event
+            const bool early = pre;
             if (early) issue(0);
             // The event of the chain's previous step, if that was a hypocentre step: the workers LEFT IT OUT (an order sent two
             // steps ahead was evaluated while that step may or may not have committed), this wave adds its misfit -- at the

@@ -1221,7 +1221,7 @@ __global__ __launch_bounds__((mcmc_threads<NCH, MK>())) void k_mcmc(FwdDev f, Ch
         __syncthreads();
         if (threadIdx.x == 0) st_agent(&ka.cs.ps->quit, launch + 1ull);
     } else {
-        worker_body<NCH, F32, mcmc_threads<NCH, MK>() / 64>(ka.f, ka.cs, launch, blockIdx.x - 1);
+        worker_body<NCH, F32, mcmc_threads<NCH, MK>() / 64, (MK >= 5)>(ka.f, ka.cs, launch, blockIdx.x - 1);
     }
 }
 

@@ -1451,8 +1451,10 @@ __global__ __launch_bounds__(512) void k_step(FwdDev f, ChainsDev cs, int mode, 
 // granules (data is the flag); chain state is read with agent-scope loads after the job word has been seen
 // (the master drained its stores before publishing it).  Leaves when the master has finished (PSync::quit)
 // or after a bounded wait.
-// NWV = waves per worker block (8: the master's block shape)
-template <int NCH, bool F32, int NWV = 8>
+// NWV = waves per worker block (8: the master's block shape).  PIPE: the launch's master is the pipelined one (htm_pipe.hpp), whose
+// orders name a second left-out event and want the left-out events' sums reported on their own -- compiled only into those
+// launches: in the workers' event loop it costs the others 13 % at 10 000 x 128 x 16 fp64 (profiles/r04_h_worker_pipe_ab.txt).
+template <int NCH, bool F32, int NWV = 8, bool PIPE = false>
 __device__ __forceinline__ void worker_body(FwRef f_, CsRef cs_, unsigned long long launch, int w)
 {
     CsRef cs = rebase(cs_);
@@ -1630,7 +1632,7 @@ __device__ __forceinline__ void worker_body(FwRef f_, CsRef cs_, unsigned long l
         {
             // (bit 31 of the order word: an order of the pipelined master, htm_pipe.hpp -- no commit is named, and the word after
             // it names a SECOND event the workers leave out)
-            const bool pipe_order = (s_job[0] >> 31) != 0u;
+            const bool pipe_order = PIPE && (s_job[0] >> 31) != 0u;
             const int type = (int)(s_job[0] & 7u), idx = (int)((s_job[0] & 0x7fffffffu) >> 3);
             const double ov_val = __longlong_as_double((long long)(((unsigned long long)s_job[1] << 32) | s_job[2]));
             // vs and qs of the evaluated model: chain state unless they are the proposal (same round of loads as
