@@ -4,9 +4,11 @@
 // encoding), fp64 VALU.  No MFMA: the path is elementwise geometry + reductions.
 //
 // Mapping: lane <-> station, wave <-> event (full evaluation) or wave <-> chain (partial
-// update); the station table is staged in LDS once per workgroup and then held in registers, the four
-// observation streams t_obs/t_prec/a_obs/a_prec are read with coalesced 512-B wave loads in the
-// reference's own (n_sta, n_events) column-major layout.
+// update).  The station table (3 S doubles) is staged in LDS by the chain master's workgroup and copied from there into
+// each wave's registers; the full-evaluation kernels (k_full, the worker blocks) read it straight into registers once per
+// wave -- one coalesced load per coordinate that L2 serves, a second LDS hop would only add latency (a stated
+// deviation from "LDS staging of the station table").  The four observation streams t_obs/t_prec/a_obs/a_prec are read with
+// coalesced 512-B wave loads in the reference's own (n_sta, n_events) column-major layout.
 #pragma once
 #include <type_traits>
 #include <hip/hip_runtime.h>

@@ -1134,9 +1134,15 @@ static int ctrl_error(const htm_chains *hc)
         return fail(HTM_ESTATE, "persistent workers did not answer within 5 s (iteration %d)%s", hc->h_ctrl.iter_done + 1, extra);
     }
     case -7: return fail(HTM_ESTATE, "random stream underrun in lock-step mode (iteration %d)", hc->h_ctrl.iter_done + 1);
-    case -10: return fail(HTM_ESTATE, "swap records of the other ranks did not arrive within 20 s (iteration %d)", hc->h_ctrl.iter_done + 1);
+    case -10: return fail(HTM_ESTATE, "swap records of another rank did not arrive within %.1f s (after iteration %d; HTM_XCHG_TIMEOUT_MS)",
+                          (double)hc->dev.xwait_ticks * 1.0e-8, hc->h_ctrl.iter_done);
     case -11: return fail(HTM_ESTATE, "another rank reported a failure (iteration %d)", hc->h_ctrl.iter_done + 1);
     case -15: return fail(HTM_EDESYNC, "a swap record in the inbox was overwritten before it was read (after iteration %d): the ranks are more than the ring's depth apart", hc->h_ctrl.iter_done);
+    case -12: return fail(HTM_ESTATE, "a chain wave of the master waited 5 s for another chain's step (its check, its commit before a swap, or the "
+                          "rank's own header) after iteration %d: a wave has stopped making progress", hc->h_ctrl.iter_done);
+    case -13: return fail(HTM_ESTATE, "the master's window of the random stream did not reach a step's position within 5 s (after iteration %d)",
+                          hc->h_ctrl.iter_done);
+    case -14: return fail(HTM_ESTATE, "an evaluator of the pipelined master waited 5 s for a proposal record (after iteration %d)", hc->h_ctrl.iter_done);
     default: return fail(HTM_ESTATE, "device error flag %d", hc->h_ctrl.err);
     }
 }

@@ -386,7 +386,7 @@ __device__ __forceinline__ int chain_pass(FwRef f_, CsRef cs_, StepShared &sh, c
     int ok = 1;
     if (__builtin_expect(ptype == 1, 0)) {                      // :178-187
         if (x_new <= mu) { lpr = (double)-1.0e+30f; ok = 0; }
-        else lpr = lpr + log(x_new - mu) - log(x_old - mu);
+        else lpr = lpr + htm_log(x_new - mu) - htm_log(x_old - mu);      // (the same logarithm as flow_step and the pipelined front: whichever loop runs a job, the decisions agree)
     }
     const double r = ok ? r_ring : 0.0, logr = ok ? logr_ring : 0.0;
     const int cnt = dec_w - 1 + ok;                             // the judge draw happens only if prior_ok

@@ -44,4 +44,4 @@ class Model:
             elif self.prior_type[i] == 1:
                 self.x[i] = self.mu[i] + rng.rand_r() * self.sigma[i]
             else:
-                raise ValueError(f"unsupported prior type : prior_type = {self.prior_type[i]}")
+                raise ValueError(f"element {i + 1}: prior type {self.prior_type[i]} is neither 0 (Gaussian) nor 1 (Rayleigh)")
