@@ -781,6 +781,7 @@ struct ChainsDev {
     unsigned long long xwait_ticks;  // how long a rank waits for the peers' swap records (100 MHz ticks; 20 s, HTM_XCHG_TIMEOUT_MS)
     int xown;                        // a rank's own swap record is read from LDS instead of its inbox (default; HTM_XOWN=0: through memory like a peer's)
     int dbg_xfail_iter;              // test switch (HTM_DEBUG_XCHG_FAIL_ITER): from this iteration on the rank posts its swap records to nobody (0 = off)
+    struct MbShared *mb;             // what the chains of a rank share when several master workgroups run them (htm_flow.hpp)
     int *prev_mid;                   // [n_chains] type | event << 3 of the chain's last step (free-running master: FlowShared::pv_mid), 0 = none
     unsigned long long *lo_gran;     // [n_chains][16] tagged granules of the pipelined master's orders (htm_pipe.hpp): [0..3] the proposed values of the two
                                      // hypocentre steps before the order's step (master -> workers), [8..15] the left-out events' sums at both positions (back)

@@ -88,6 +88,64 @@ __device__ __forceinline__ unsigned long long lds_ld(const unsigned long long *p
 __device__ __forceinline__ void lds_st(int *p, int v) { asm volatile("" ::: "memory"); __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_st(unsigned long long *p, unsigned long long v) { asm volatile("" ::: "memory"); __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
+// ---- SEVERAL MASTER WORKGROUPS in one launch (k_mcmc<.., 7>; block b runs chains 8 b .. 8 b + 7, a wave each) -----------------
+// One CU issues the instructions of eight chain waves and no more: more chains per rank than eight used to take
+// turns on the same waves.  Here the words the chains of a rank share -- what FlowShared holds in LDS for one workgroup -- live in
+// memory, written and read with agent-scope accesses, every one of them self-validating (a single 8-byte word, or tagged granules
+// {tag : 32, payload : 32} whose tag says which iteration / epoch they belong to), so that no ordering between stores to
+// different addresses is relied upon:
+//   prog[c]       as FlowShared::prog: {epoch << 1 | prior rejected, key} of chain c's latest checked step
+//   crec[i & 3][c]   chain c after iteration i: {i, T hi | T lo | L hi | L lo} -- also what FlowShared::done says
+//   swrec[i & 3]     the swap the stream holds after iteration i: {i, Eof | i1 | i2 | draws | r hi | r lo | log r hi | lo}
+//   anch[e & 1]      the anchor of epoch e: {e, key}, {e, pos}
+//   word[]           0 epoch, 1 last iteration of the launch, 2 failure word, 3 stop code, 4 / 5 likelihood / sample records
+//                    written, 6 master blocks that have finished, 7 -
+// A step looks at all of it ONCE, with one load instruction per lane issued when its own check is published -- the round trip
+// (~1 us) runs under the evaluation -- and again only while its turn has not come.  Same job, same stream order, same results
+// as one workgroup: the protocol is FlowShared's (tools/flow_protocol_sim.py), only the medium differs.
+struct MbShared {
+    unsigned long long prog[kMaxChains];
+    unsigned long long crec[4][kMaxChains][4];
+    unsigned long long swrec[4][8];
+    unsigned long long anch[2][2];
+    unsigned long long word[8];
+    unsigned long long n_full, n_part;
+};
+enum { MW_EPOCH = 0, MW_LAST = 1, MW_ERR = 2, MW_STOP = 3, MW_NLIK = 4, MW_NSMP = 5, MW_FIN = 6 };
+
+struct MbWave {                   // what a chain wave of a multi-block launch saw with its latest look at MbShared
+    int epoch, last_iter, err, n_lik, n_smp;
+    unsigned long long pv;        // lane < n_chains: prog[lane]
+};
+// one look: lane < nc: prog[lane]; lanes 59..63: words 4, 5 (records written), 0 (epoch), 1 (last iteration), 2 (failure)
+__device__ __forceinline__ unsigned long long mb_look(const MbShared *g, int nc, int lane)
+{
+    unsigned long long v = 0ull;
+    if (lane < nc) v = ld_agent(&g->prog[lane]);
+    else if (lane >= 59) { const int k = lane == 59 ? MW_NLIK : lane == 60 ? MW_NSMP : lane - 61; v = ld_agent(&g->word[k]); }
+    return v;
+}
+__device__ __forceinline__ void mb_take(MbWave &mw, unsigned long long v)
+{
+    mw.pv = v;
+    mw.n_lik = (int)(unsigned)rl_u64(v, 59); mw.n_smp = (int)(unsigned)rl_u64(v, 60);
+    mw.epoch = (int)(unsigned)rl_u64(v, 61); mw.last_iter = (int)(unsigned)rl_u64(v, 62); mw.err = (int)(unsigned)rl_u64(v, 63);
+}
+// `n` granules from `base`, all tagged `tag`: polls until they are (false: gave up, sh.c.err set)
+__device__ __forceinline__ bool mb_wait(FlowShared &sh, const unsigned long long *base, int n, unsigned tag, int lane, unsigned long long &v, int code = -12)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (unsigned spin = 0;; ++spin) {
+        v = lane < n ? ld_agent(base + lane) : ((unsigned long long)tag << 32);
+        if (__all((unsigned)(v >> 32) == tag)) return true;
+        if ((spin & 7u) == 7u) {
+            if (sh.c.err != 0) return false;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) { if (lane == 0) sh.c.err = code; return false; }
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
 struct FlowWave {                 // a wave's predictions (wave-uniform)
     int epoch, akey;              // the epoch they are made in, that epoch's anchor key
     int rc, rpos;                 // "chain rc's step of the current iteration starts at rpos" (rc = 0: the iteration's base)
@@ -198,12 +256,22 @@ __device__ __forceinline__ void flow_void_books(CsRef cs, FlowShared &sh, int wa
 // this wave adopts epoch e (read from sh.epoch a moment ago).  `standing`: its current step (it, c) has passed its check and lies
 // before the anchor -- it stands, and everything the wave runs after it starts at or after the anchor; else the current
 // step itself starts at or after the anchor.  Returns false if the epoch moved on meanwhile (the caller looks again).
-__device__ __forceinline__ bool flow_adopt(CsRef cs_, FlowShared &sh, const Ring &rg, FlowWave &W, int e, int it, int c, bool in_turn, bool &stands)
+// (g != nullptr: a multi-block launch -- epoch and anchor are MbShared's; false: the anchor of epoch e is not there (yet, or
+// any more): the caller looks at the epoch again)
+__device__ __forceinline__ bool flow_adopt(CsRef cs_, FlowShared &sh, const Ring &rg, FlowWave &W, int e, int it, int c, bool in_turn, bool &stands,
+                                           const MbShared *g = nullptr)
 {
     CsRef cs = rebase(cs_);
     const int nc = cs.n_chains;
-    const unsigned long long a = lds_ld(&sh.anch[e & 1]);
-    if (lds_ld(&sh.epoch) != e) return false;
+    unsigned long long a;
+    if (g) {
+        const unsigned long long a0 = ld_agent(&g->anch[e & 1][0]), a1 = ld_agent(&g->anch[e & 1][1]);
+        if ((int)(unsigned)(a0 >> 32) != e || (int)(unsigned)(a1 >> 32) != e) return false;
+        a = (a0 << 32) | (a1 & 0xffffffffull);
+    } else {
+        a = lds_ld(&sh.anch[e & 1]);
+        if (lds_ld(&sh.epoch) != e) return false;
+    }
     const int akey = (int)(unsigned)(a >> 32);
     const int key = (it - sh.i0) * nc + c;
     int ia, ca, ap;
@@ -399,9 +467,9 @@ __device__ __forceinline__ void flow_lock_finish(CsRef cs_, FlowShared &sh, int 
 // counterpart of chain_pass).  All 64 lanes execute with identical (uniform) values; lane <-> station only inside
 // event_misfit.  `ext`: this wave keeps the LDS window of the stream ahead (chain 0's wave, one round of <= 64 positions
 // per step, in flight under the step's own loads).  Returns the stream position after the step, kFlowRestart or kFlowAbort.
-template <int NCH, bool F32, bool LOCK>
+template <int NCH, bool F32, bool LOCK, bool MB = false>
 __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, const Ring &rg, FlowWave &W, FlowNext &nx,
-                                         double *s_gath, int wmax,
+                                         MbShared *g_mb, MbWave &mw, double *s_gath, int wmax,
                                          const double *s_sx, const double *s_sy, const double *s_sz, int c, int p, int iter,
                                          int lane, int wave, int NW, unsigned long long launch, bool ext, int look, int back,
                                          bool rec_now, const FlowTop &tp)
@@ -417,16 +485,18 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
 #endif
     // ---- the LDS window of the stream rings, one round per step of chain 0's wave: requested first, stored behind the
     // ---- step's own loads (which return after it: vector-memory operations complete in order)
-    PfRegs pf;
-    pf.p = -1;
+    PfRegs pf, pf2;
+    pf.p = -1; pf2.p = -1;
     int fill_to = 0;
     if (ext) {
         const int fl = sh.fill;
         // (this step is chain c's: the iteration's base lies 4 c .. 6 c positions back; the other waves may still read `back`
         // positions behind it, and want `look` positions ahead of it)
         fill_to = min(min(p - 4 * c + look, sh.avail), p - 6 * c - back + M + 1);
-        if (fill_to > fl + 64) fill_to = fl + 64;
+        // (several master workgroups: the wave has ONE step per iteration for all the draws of the rank's chains -- two rounds)
+        if (fill_to > fl + (MB ? 128 : 64)) fill_to = fl + (MB ? 128 : 64);
         if (fill_to > fl) pf_load(pf, cs, sh, fl + lane, fill_to);
+        if constexpr (MB) { if (fill_to > fl + 64) pf_load(pf2, cs, sh, fl + 64 + lane, fill_to); }
     }
     const double *xall_ = cs.xall;
     const PriorRec *prior_ = cs.prior;
@@ -524,12 +594,33 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
             if (nd > 0) { sh.sw_r[k4] = rg.U[(E + nd - 1) & M]; sh.sw_logr[k4] = rg.LOGU[(E + nd - 1) & M]; }
             lds_st(&sh.Eof[k4], E);
         }
+        if constexpr (MB) {
+            // (the same, for the chains of the other workgroups: eight granules tagged with the iteration)
+            const int je = nd > 0 ? (E + nd - 1) & M : 0;
+            const unsigned long long rb = nd > 0 ? (unsigned long long)__double_as_longlong(rg.U[je]) : 0ull;
+            const unsigned long long lb = nd > 0 ? (unsigned long long)__double_as_longlong(rg.LOGU[je]) : 0ull;
+            if (lane < 8) {
+                const unsigned pay = lane == 0 ? (unsigned)E : lane == 1 ? (unsigned)i1 : lane == 2 ? (unsigned)i2 : lane == 3 ? (unsigned)nd
+                                   : lane == 4 ? (unsigned)(rb >> 32) : lane == 5 ? (unsigned)rb : lane == 6 ? (unsigned)(lb >> 32) : (unsigned)lb;
+                st_agent(&g_mb->swrec[k4][lane], ((unsigned long long)(unsigned)iter << 32) | pay);
+            }
+        }
     }
-    if (lane == 0) {
-        lds_st(&sh.prog[c], ((unsigned long long)(((unsigned)W.epoch << 1) | (ok ? 0u : 1u)) << 32) | (unsigned)key);
+    {
+        const unsigned long long pword = ((unsigned long long)(((unsigned)W.epoch << 1) | (ok ? 0u : 1u)) << 32) | (unsigned)key;
+        if constexpr (MB) { if (lane == 0) st_agent(&g_mb->prog[c], pword); }
+        else { if (lane == 0) lds_st(&sh.prog[c], pword); }
+    }
+    // several master workgroups: this step's look at what the chains share (MbShared), in flight under the evaluation; with it
+    // the swap the stream holds after the iteration before (read for good when the turn has come)
+    unsigned long long mbv = 0ull, mbs = 0ull;
+    if constexpr (MB) {
+        mbv = mb_look(g_mb, nc_, lane);
+        if (lane < 8) mbs = ld_agent(&g_mb->swrec[(iter - 1) & 3][lane]);
     }
     if (ext && fill_to > sh.fill) {                             // (the window's loads were issued before the step's: they are there)
         pf_store(pf, rg);
+        if constexpr (MB) pf_store(pf2, rg);
         if (lane == 0) lds_st(&sh.fill, fill_to);
     }
 
@@ -548,7 +639,9 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
             double out[2];
             // look-ahead, first round trip (a wave with one chain): the hop-table entries that give the start of this chain's
             // next step, of its step after that, and the end of the iteration after next -- issued here, used behind the evaluation
-            if (NW >= nc_ && W.rpos1 >= 0 && W.B2 >= 0 && c >= W.rc1 && iter + 1 <= sh.c.iter_target && rg.mir_n > 0) {
+            // (the hop tables reach kHops steps: with more chains than that -- several master workgroups -- the positions are looked
+            // up at the top of the next step instead)
+            if (NW >= nc_ && nc_ <= kHops && W.rpos1 >= 0 && W.B2 >= 0 && c >= W.rc1 && iter + 1 <= sh.c.iter_target && rg.mir_n > 0) {
                 la = 1; la_epoch = W.epoch;
                 const int n1 = c - W.rc1;
                 if (n1 > 0) hA = rg.hop[(W.rpos1 & M) * kHops + n1 - 1];
@@ -685,11 +778,21 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
         const int key_i = (iter - sh.i0) * nc_, key_m = key_i - nc_;
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         for (unsigned spin = 0;; ++spin) {
-            const unsigned long long pv = lane < nc_ ? lds_ld(&sh.prog[lane]) : 0ull;
-            const int e = lds_ld(&sh.epoch);
+            unsigned long long pv;
+            int e;
+            if constexpr (MB) {
+                if (spin > 0) mbv = mb_look(g_mb, nc_, lane);      // (the first round uses the look issued before the evaluation)
+                mb_take(mw, mbv);
+                pv = lane < nc_ ? mbv : 0ull; e = mw.epoch;
+                if (__builtin_expect(mw.err != 0, 0)) { if (lane == 0 && sh.c.err == 0) sh.c.err = mw.err; return kFlowAbort; }
+                if (__builtin_expect(iter > mw.last_iter, 0)) return kFlowStop;      // (the launch ends before this iteration: the step is not taken)
+            } else {
+                pv = lane < nc_ ? lds_ld(&sh.prog[lane]) : 0ull;
+                e = lds_ld(&sh.epoch);
+            }
             if (__builtin_expect(e != W.epoch, 0)) {
                 bool stands = false;
-                if (!flow_adopt(cs, sh, rg, W, e, iter, c, true, stands)) continue;
+                if (!flow_adopt(cs, sh, rg, W, e, iter, c, true, stands, MB ? g_mb : nullptr)) { if (MB) __builtin_amdgcn_s_sleep(1); continue; }
                 flow_void_books(cs, sh, wave, NW, nc_, lane);
                 if (!stands) return kFlowRestart;
                 continue;
@@ -707,7 +810,14 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
             }
             if ((spin & 15u) == 15u) {
                 if (sh.c.err != 0) return kFlowAbort;
-                if (__builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) { if (lane == 0) sh.c.err = -12; return kFlowAbort; }
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) {
+                    if constexpr (MB) {      // (what the turn was waiting for: the host puts it into its message)
+                        const unsigned long long bad = __ballot(!okl);
+                        if (lane == 0) { unsigned long long *dg = cs.diag; dg[1] = c; dg[2] = iter; dg[3] = bad; dg[4] = W.epoch; dg[5] = mw.epoch; dg[6] = rl_u64(pv, __ffsll((long long)bad) - 1); dg[0] = 2; }
+                    }
+                    if (lane == 0) sh.c.err = MB ? -16 : -12;
+                    return kFlowAbort;
+                }
             }
             __builtin_amdgcn_s_sleep(HTM_TURN_SLEEP);
         }
@@ -809,6 +919,26 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
 #else
         FSTAMP(6);
 #endif
+    } else if (MB && iter - 1 > sh.i0) {
+        // several master workgroups: the pair and the draw from MbShared::swrec (requested before the evaluation), the other
+        // chain's (T, L) from its record -- this chain's own from LDS, where its wave keeps them
+        T = sh.T4[ppar][c]; rT = sh.rT4[ppar][c];
+        if (nc_ > 1) {
+            if (!__all(lane >= 8 || (unsigned)(mbs >> 32) == (unsigned)(iter - 1))) {
+                if (!mb_wait(sh, &g_mb->swrec[ppar][0], 8, (unsigned)(iter - 1), lane, mbs, -17)) return kFlowAbort;
+            }
+            const int i1 = (int)(unsigned)rl_u64(mbs, 1), i2 = (int)(unsigned)rl_u64(mbs, 2);
+            if (c == i1 || c == i2) {
+                const int o2 = c == i1 ? i2 : i1;
+                unsigned long long cv;
+                if (!mb_wait(sh, &g_mb->crec[ppar][o2][0], 4, (unsigned)(iter - 1), lane, cv, -18)) return kFlowAbort;
+                const double To = gran_f64(rl_u64(cv, 0), rl_u64(cv, 1)), Lo = gran_f64(rl_u64(cv, 2), rl_u64(cv, 3)), rTo = 1.0 / To;
+                const double sr = gran_f64(rl_u64(mbs, 4), rl_u64(mbs, 5)), slr = gran_f64(rl_u64(mbs, 6), rl_u64(mbs, 7));
+                const double rT1 = c == i1 ? rT : rTo, rT2 = c == i1 ? rTo : rT, L1 = c == i1 ? L_cur : Lo, L2 = c == i1 ? Lo : L_cur;
+                const double del_s = (L2 - L1) * (rT1 - rT2);                            // :292
+                if (sr >= kEps && slr <= del_s) { T = To; rT = rTo; }                    // :131-136
+            }
+        }
     } else if (iter - 1 > sh.i0) {
         T = sh.T4[ppar][c]; rT = sh.rT4[ppar][c];
         if (cs.n_procs * nc_ > 1) {
@@ -860,18 +990,41 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
         unsigned long long *const *xout = reinterpret_cast<unsigned long long *const *>(s_gath);
         flow_post_chain(cs, xout, iter, c, T, L_post, lane);
     }
+    if constexpr (MB) {
+        // this chain after the iteration, for the chains of the other workgroups (the pair of the swap that follows)
+        const unsigned long long tb = (unsigned long long)__double_as_longlong(T), lb = (unsigned long long)__double_as_longlong(L_post);
+        if (lane < 4) {
+            const unsigned pay = lane == 0 ? (unsigned)(tb >> 32) : lane == 1 ? (unsigned)tb : lane == 2 ? (unsigned)(lb >> 32) : (unsigned)lb;
+            st_agent(&g_mb->crec[par][c][lane], ((unsigned long long)(unsigned)iter << 32) | pay);
+        }
+    }
     FSTAMP(4);
     // ---- a rejected prior: this step was one draw shorter than the hop tables assume.  Everything after it starts
     // ---- elsewhere: new epoch, anchored at the step after this one
     if (__builtin_expect(ok == 0, 0)) {
         const int e1 = W.epoch + 1;
+        bool stands = false;
+        if constexpr (MB) {
+            if (lane == 0) {
+                st_agent(&g_mb->anch[e1 & 1][0], ((unsigned long long)(unsigned)e1 << 32) | (unsigned)(key + 1));
+                st_agent(&g_mb->anch[e1 & 1][1], ((unsigned long long)(unsigned)e1 << 32) | (unsigned)(p + cnt));
+                st_agent(&g_mb->word[MW_EPOCH], (unsigned long long)(unsigned)e1);
+            }
+            // (this wave's own view: from what it has just written; a later rejection finds it at its next look)
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while (!flow_adopt(cs, sh, rg, W, e1, iter, c, true, stands, g_mb)) {
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) { if (lane == 0) sh.c.err = -19; return kFlowAbort; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            mw.epoch = e1;
+        } else {
         if (lane == 0) {
             lds_st(&sh.anch[e1 & 1], ((unsigned long long)(unsigned)(key + 1) << 32) | (unsigned)(p + cnt));
             lds_st(&sh.epoch, e1);
         }
-        bool stands = false;
         // (this wave's own view: as any wave whose step stands before the anchor; a later rejection may already have moved on)
         while (!flow_adopt(cs, sh, rg, W, lds_ld(&sh.epoch), iter, c, true, stands)) { }
+        }
         flow_void_books(cs, sh, wave, NW, nc_, lane);
     }
     // ---- records of this step (hypo_tremor_mcmc.f90:270-280): slots by LDS atomics, put in order on the host
@@ -887,8 +1040,13 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
     if (__builtin_expect(rec_now && cool, 0)) {
         int sl = 0, ss = -1;
         if (lane == 0) {
+            if constexpr (MB) {      // (the record slots of all workgroups' chains: counted in memory)
+                sl = (int)atomicAdd(&g_mb->word[MW_NLIK], 1ull);
+                if (iter > cs.n_burn) ss = (int)atomicAdd(&g_mb->word[MW_NSMP], 1ull);
+            } else {
             sl = atomicAdd(&sh.c.n_lik, 1);
             if (iter > cs.n_burn) ss = atomicAdd(&sh.c.n_smp, 1);
+            }
         }
         sl = __builtin_amdgcn_readfirstlane(sl); ss = __builtin_amdgcn_readfirstlane(ss);
         if (lane == 0 && sl < cs.cap_lik) { cs.lik_iter[sl] = iter; cs.lik_chain[sl] = c; cs.lik_val[sl] = L_post; }
@@ -1004,8 +1162,10 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
 }
 
 // block 0 of a k_mcmc<NCH, F32, 0> launch when the host selects the free-running master (htm_hip.hip: flow_ok)
-template <int NCH, bool F32, bool LOCK = false>
-__device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, int ring_size, int wmax, unsigned long long launch)
+// (MB: one of several master workgroups of the launch -- block b runs chains 8 b .. 8 b + 7; returns true in the workgroup that
+// finishes last, which has written the launch's end state and releases the workers)
+template <int NCH, bool F32, bool LOCK = false, bool MB = false>
+__device__ __forceinline__ bool flow_body(FwRef f_, CsRef cs_, int target_arg, int ring_size, int wmax, unsigned long long launch)
 {
     CsRef cs = rebase(cs_);
     FwRef f = rebase(f_);
@@ -1081,11 +1241,13 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
             sh.rbeta[c] = 1.0 / b_; sh.katt[c] = (kPi * kFreq) / (q_ * b_);
         }
     }
-    if (sh.c.iter_done >= sh.c.iter_target || sh.c.stop || sh.c.err) return;      // (uniform)
+    MbShared *g_mb = MB ? cs.mb : nullptr;
+    const int mb_b = MB ? (int)blockIdx.x : 0;                // this master workgroup; its chains are 8 b + wave
+    if (sh.c.iter_done >= sh.c.iter_target || sh.c.stop || sh.c.err) return !MB || mb_b == 0;      // (uniform; every master block reads the same control block)
     if (sh.avail < 3 * wmax) {                                 // the produced stream does not cover a safe stretch: the host refills
         __syncthreads();
-        if (tid == 0) { if (LOCK) sh.c.err = -7; else sh.c.stop = 2; *cs.ctrl = sh.c; }      // (lock-step ranks leave a launch only together: the host feeds the stream first)
-        return;
+        if (tid == 0 && mb_b == 0) { if (LOCK) sh.c.err = -7; else sh.c.stop = 2; *cs.ctrl = sh.c; }      // (lock-step ranks leave a launch only together: the host feeds the stream first)
+        return !MB || mb_b == 0;
     }
     // the draws an iteration can take: 6 per chain step + select_pair's and judge_swap's
     const int wd = 6 * nc + 16;
@@ -1101,8 +1263,10 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
     FlowNext nx;
     nx.p = -1; nx.it = 0; nx.c = 0; nx.epoch = 0; nx.type = 5; nx.idx = 0; nx.evt = 1; nx.dec_w = 6; nx.g = 0.0; nx.r = 0.0; nx.logr = 0.0; nx.b3 = -1;
     int iter = i0 + 1;
-    int c = wave;
-    bool alive = wave < nc && wave < NW;
+    int c = MB ? 8 * mb_b + wave : wave;
+    bool alive = MB ? (wave < 8 && c < nc) : (wave < nc && wave < NW);
+    MbWave mw;
+    mw.epoch = 0; mw.last_iter = sh.c.iter_target; mw.err = 0; mw.n_lik = sh.c.n_lik; mw.n_smp = sh.c.n_smp; mw.pv = 0ull;
 #ifdef HTM_STAMPS
     const unsigned long long t_loop0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -1111,8 +1275,13 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
         FlowTop tp;
         {
             const int co = (HTM_FAIR && (!LOCK || HTM_FAIR_LOCK) && (c ^ 4) < nc) ? (c ^ 4) : c;
+            if constexpr (MB) {      // (what the wave saw with its latest look at MbShared: a step old, checked again in the turn)
+                tp.epoch = mw.epoch; tp.last_iter = mw.last_iter; tp.err = mw.err != 0 ? mw.err : lds_ld(&sh.c.err);
+                tp.pk = (int)(unsigned)rl_u64(mw.pv, co);
+            } else {
             tp.epoch = lds_ld(&sh.epoch); tp.last_iter = lds_ld(&sh.last_iter); tp.err = lds_ld(&sh.c.err);
             tp.pk = (int)(unsigned)lds_ld(&sh.prog[co]);
+            }
             tp.book_pos = sh.ob_pos[c]; tp.book_mode = sh.ob_mode[c]; tp.book_mid = sh.ob_mid[c]; tp.book_tag = sh.ob_tag[c];
             tp.pv_mid = sh.pv_mid[c];
             tp.L = sh.L[c];
@@ -1123,8 +1292,11 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
             const int e = tp.epoch;
             if (__builtin_expect(e != W.epoch, 0)) {
                 bool stands = false;
-                if (!flow_adopt(cs, sh, rg, W, e, iter, c, false, stands)) continue;
-                flow_void_books(cs, sh, wave, NW, nc, lane);
+                if (!flow_adopt(cs, sh, rg, W, e, iter, c, false, stands, g_mb)) {
+                    if constexpr (MB) { mb_take(mw, mb_look(g_mb, nc, lane)); }      // (the anchor of that epoch is gone or not there yet: look again)
+                    continue;
+                }
+                flow_void_books(cs, sh, MB ? c : wave, MB ? 64 : NW, nc, lane);
                 continue;      // (the book read above is void with it: from the top)
             }
         }
@@ -1141,9 +1313,19 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
             // chain 0's wave decides where the launch ends: record buffers or produced stream nearly used up.  Everybody
             // learns it before committing a step of this iteration (its turn waits for chain 0's check)
             int code = 0;
+            if constexpr (MB) {
+                // (the records are counted in memory; this wave's latest look is a step old: a margin of one more iteration)
+                if (mw.n_lik + 5 * nc > cs.cap_lik || mw.n_smp + 5 * nc > cs.cap_smp) code = 1;
+                else if (sh.avail < p + 3 * wd + 32) code = 2;
+                if (code && mw.last_iter > iter) {
+                    st_agent(&g_mb->word[MW_STOP], (unsigned long long)(unsigned)code);
+                    st_agent(&g_mb->word[MW_LAST], (unsigned long long)(unsigned)iter);
+                }
+            } else {
             if (sh.c.n_lik + 3 * nc > cs.cap_lik || sh.c.n_smp + 3 * nc > cs.cap_smp) code = 1;
             else if (sh.avail < p + 3 * wd + 32) code = 2;
             if (code && lds_ld(&sh.last_iter) > iter) { sh.stop_code = code; lds_st(&sh.last_iter, iter); }
+            }
         }
         // the window covers this step (chain 0's wave keeps it 3 iterations ahead); a fail-stop, never expected to wait
         if (__builtin_expect(!known && p + 16 >= lds_ld(&sh.fill), 0)) {      // (a known start was checked against the window when it was looked up)
@@ -1165,14 +1347,15 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
             if (pk >= (iter - i0) * nc + (c ^ 4)) __builtin_amdgcn_s_setprio(1);
             else __builtin_amdgcn_s_setprio(0);
         }
-        const int r = flow_step<NCH, F32, LOCK>(f, cs, sh, rg, W, nx, s_gath, wmax, s_sx, s_sy, s_sz, c, p, iter, lane, wave, NW, launch, wave == 0,
-                                          look, back, rec_phase == 1, tp);
+        // (several master workgroups: a wave has one chain -- "wave" c of as many waves as there are chains)
+        const int r = flow_step<NCH, F32, LOCK, MB>(f, cs, sh, rg, W, nx, g_mb, mw, s_gath, wmax, s_sx, s_sy, s_sz, c, p, iter, lane, MB ? c : wave,
+                                              MB ? 64 : NW, launch, wave == 0, look, back, rec_phase == 1, tp);
         if (r == kFlowRestart) continue;
         if (r == kFlowAbort || r == kFlowStop) break;
         // ---- this wave's next step
-        c += NW;
+        c += MB ? nc : NW;
         if (c >= nc) {
-            c = wave;
+            c = MB ? 8 * mb_b + wave : wave;
             iter += 1;
             rec_phase = rec_phase + 1 == n_int ? 0 : rec_phase + 1;
             if (W.rpos1 < 0) {    // (the window did not cover the prediction when it was made: it does now)
@@ -1198,6 +1381,73 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
     if constexpr (LOCK) {
         if (wave == 0 && sh.c.err == 0) flow_lock_finish(cs, sh, lane);
         __syncthreads();
+    }
+    if constexpr (MB) {
+        // Several master workgroups: each writes its own chains' end state and adds its counters; the one that finishes LAST
+        // (a ticket) applies the swap of the last iteration -- from the records in MbShared -- and writes the control block.
+        const int nb = (nc + 7) / 8;
+        if (tid == 0) {
+            if (sh.c.err != 0) st_agent(&g_mb->word[MW_ERR], (unsigned long long)(unsigned)sh.c.err);      // (the other workgroups leave at their next look)
+            sh.last_iter = (int)(unsigned)ld_agent(&g_mb->word[MW_LAST]);
+        }
+        __syncthreads();
+        const int last = min(sh.last_iter, sh.c.iter_target);
+        if (tid < 8 && 8 * mb_b + tid < nc && last > i0) {
+            const int k = 8 * mb_b + tid;
+            cs.L[k] = sh.L[k]; cs.temp[k] = sh.T4[last & 3][k]; cs.prev_mid[k] = sh.pv_mid[k];
+        }
+        for (int k = tid; k < 7 * nc; k += blockDim.x) {          // flush this launch's counters (this workgroup's chains)
+            if (sh.np[k]) atomicAdd(&cs.n_propose[k], sh.np[k]);
+            if (sh.na[k]) atomicAdd(&cs.n_accept[k], sh.na[k]);
+        }
+        if (tid == 0) {
+            atomicAdd(&g_mb->n_full, sh.n_full_w); atomicAdd(&g_mb->n_part, sh.n_part_w);
+            atomicMax(&g_mb->word[7], sh.c.jobs_total);
+        }
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) sh.xdone = atomicAdd(&g_mb->word[MW_FIN], 1ull) == (unsigned long long)(nb - 1) ? 1 : 0;
+        __syncthreads();
+        if (sh.xdone == 0) return false;      // (uniform)
+        __threadfence();
+        if (tid == 0) {
+            const int gerr = (int)(unsigned)ld_agent(&g_mb->word[MW_ERR]);
+            if (sh.c.err == 0 && gerr != 0) sh.c.err = gerr;
+            if (sh.c.err == 0 && last > i0) {
+                const int par = last & 3;
+                unsigned sw[8];
+                for (int k = 0; k < 8; ++k) { const unsigned long long v = ld_agent(&g_mb->swrec[par][k]); sw[k] = (unsigned)v; if ((int)(unsigned)(v >> 32) != last) sh.c.err = -20; }
+                const int E = (int)sw[0], i1 = (int)sw[1], i2 = (int)sw[2], nd = (int)sw[3];
+                if (sh.c.err == 0 && nc > 1) {
+                    const double sr = __longlong_as_double((long long)(((unsigned long long)sw[4] << 32) | sw[5]));
+                    const double slr = __longlong_as_double((long long)(((unsigned long long)sw[6] << 32) | sw[7]));
+                    double TL[2][2];
+                    for (int k = 0; k < 2; ++k) {
+                        const unsigned long long *r = &g_mb->crec[par][k == 0 ? i1 : i2][0];
+                        const unsigned long long a0 = ld_agent(r), a1 = ld_agent(r + 1), a2 = ld_agent(r + 2), a3 = ld_agent(r + 3);
+                        if ((int)(unsigned)(a0 >> 32) != last || (int)(unsigned)(a3 >> 32) != last) sh.c.err = -21;
+                        TL[k][0] = gran_f64(a0, a1); TL[k][1] = gran_f64(a2, a3);
+                    }
+                    const double del_s = (TL[1][1] - TL[0][1]) * (1.0 / TL[0][0] - 1.0 / TL[1][0]);      // cls_parallel.f90:292
+                    if (sr >= kEps && slr <= del_s) { cs.temp[i1] = TL[1][0]; cs.temp[i2] = TL[0][0]; }   // :131-136
+                    sh.c.swap_i1 = i1; sh.c.swap_i2 = i2; sh.c.swap_r = sr; sh.c.swap_logr = slr;
+                }
+                if (sh.c.err == 0) {
+                    sh.c.spos = sh.origin + E + nd;
+                    sh.c.iter_done = last;
+                    sh.c.stage = ST_IDLE;
+                    if (sh.c.slog_cap > 0) sh.c.slog_n = min(sh.c.slog_cap, sh.c.slog_n + (last - i0) * nc);
+                    sh.c.n_full_evals += (long long)ld_agent(&g_mb->n_full);
+                    sh.c.n_partial_evals += (long long)ld_agent(&g_mb->n_part);
+                    sh.c.n_lik = (int)(unsigned)ld_agent(&g_mb->word[MW_NLIK]); sh.c.n_smp = (int)(unsigned)ld_agent(&g_mb->word[MW_NSMP]);
+                    sh.c.jobs_total = ld_agent(&g_mb->word[7]);
+                    if (last < sh.c.iter_target) sh.c.stop = (int)(unsigned)ld_agent(&g_mb->word[MW_STOP]);
+                }
+            }
+            *cs.ctrl = sh.c;
+        }
+        __syncthreads();
+        return true;
     }
     if (tid == 0 && sh.c.err == 0) {
         if constexpr (LOCK) {
@@ -1237,6 +1487,24 @@ __device__ __forceinline__ void flow_body(FwRef f_, CsRef cs_, int target_arg, i
     }
     for (int k = tid; k < nc; k += blockDim.x) cs.prev_mid[k] = sh.pv_mid[k];
     if (tid == 0) *cs.ctrl = sh.c;
+    return true;
+}
+
+// before a launch with several master workgroups (one wave): MbShared as the first step finds it
+__global__ __launch_bounds__(64) void k_mb_init(ChainsDev cs, int target_arg)
+{
+    MbShared *g = cs.mb;
+    const int lane = threadIdx.x;
+    unsigned long long *w = reinterpret_cast<unsigned long long *>(g);
+    for (int k = lane; k < (int)(sizeof(MbShared) / sizeof(unsigned long long)); k += 64) w[k] = 0ull;
+    __syncthreads();
+    for (int c = lane; c < kMaxChains; c += 64) g->prog[c] = (unsigned long long)(unsigned)c;          // key(i0, c), epoch 0, prior ok
+    if (lane == 0) {
+        const Ctrl c = *cs.ctrl;
+        g->word[MW_LAST] = (unsigned long long)(unsigned)(target_arg >= 0 ? target_arg : c.iter_target);
+        g->word[MW_NLIK] = (unsigned long long)(unsigned)c.n_lik; g->word[MW_NSMP] = (unsigned long long)(unsigned)c.n_smp;
+        g->word[7] = c.jobs_total;
+    }
 }
 
 }  // namespace htm

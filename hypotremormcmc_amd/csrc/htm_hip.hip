@@ -171,6 +171,7 @@ struct htm_chains {
     int worker_cap = 250;                      // most worker blocks a launch takes (HTM_WORKER_CAP)
     long blocks_fit = 0;                       // resident blocks of a k_mcmc launch on this device (htm_chains_share_gpu)
     bool flow_lock = false;                    // lock-step ranks (MODE_LOCKRUN) on the free-running master too
+    int mb_blocks = 1;                         // master workgroups of the single-rank loop (> 1: k_mcmc<.., 7>, eight chains each)
     bool pipe = false;                         // single-rank loop on the pipelined master (htm_pipe.hpp)
     bool pipe_lock = false;                    // lock-step ranks (MODE_LOCKRUN) on it too
     size_t pipe_smem = 0; int pipe_ring = 512; // its LDS size and stream window
@@ -231,7 +232,8 @@ int launch_full(htm_forward *h, const FullJob &jb, int gy)
 int launch_mcmc(htm_chains *hc, int mode, int target, const double *gathered)
 {
     htm_forward *h = hc->fwd;
-    dim3 grid(1 + hc->dev.n_workers), block(512);
+    const bool mb = mode == MODE_RUN && hc->flow && hc->mb_blocks > 1 && !hc->pipe;
+    dim3 grid((mb ? hc->mb_blocks : 1) + hc->dev.n_workers), block(512);
     hc->ctrl_fresh = false;
     const unsigned long long seq = ++hc->launch_seq;      // this chain set's k_mcmc launches, counted from 1
 #define HTM_LAUNCH_MCMC(N, F, K) hipLaunchKernelGGL((k_mcmc<N, F, K>), grid, block, hc->step_smem, h->stream, h->dev, hc->dev, mode, target, gathered, hc->ring_size, hc->wmax, seq)
@@ -257,6 +259,13 @@ int launch_mcmc(htm_chains *hc, int mode, int target, const double *gathered)
         else if (h->nch == 1) HTM_LAUNCH_PIPE(1, false);
         else HTM_LAUNCH_PIPE(2, false);
 #undef HTM_LAUNCH_PIPE
+    }
+    else if (mb) {
+        // several master workgroups: what their chains share lives in memory (MbShared), set up by a one-wave kernel first
+        hipLaunchKernelGGL(k_mb_init, dim3(1), dim3(64), 0, h->stream, hc->dev, target);
+        if (h->dev.fp32) { if (h->nch == 1) HTM_LAUNCH_MCMC(1, true, 7); else HTM_LAUNCH_MCMC(2, true, 7); }
+        else if (h->nch == 1) HTM_LAUNCH_MCMC(1, false, 7);
+        else HTM_LAUNCH_MCMC(2, false, 7);
     }
     else if (mode == MODE_RUN && hc->flow) HTM_LAUNCH_MCMC_K(3);
     else if (mode == MODE_RUN) HTM_LAUNCH_MCMC_K(0);
@@ -805,6 +814,11 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
     }
     if ((rc = dev_alloc(hc->pool, &d.slots, (size_t)d.slot_rep * d.slot_stride))) return cleanup(rc);
     HIPCHK(hipMemset(d.slots, 0, (size_t)d.slot_rep * d.slot_stride * sizeof(unsigned long long)));
+    {
+        unsigned long long *mbw = nullptr;
+        if ((rc = dev_alloc(hc->pool, &mbw, sizeof(MbShared) / sizeof(unsigned long long)))) return cleanup(rc);
+        d.mb = reinterpret_cast<MbShared *>(mbw);
+    }
     if ((rc = dev_alloc(hc->pool, &d.prev_mid, (size_t)nc))) return cleanup(rc);
     HIPCHK(hipMemset(d.prev_mid, 0, (size_t)nc * sizeof(int)));
     if ((rc = dev_alloc(hc->pool, &d.lo_gran, (size_t)nc * 16))) return cleanup(rc);
@@ -938,8 +952,11 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
         // block carries the master's LDS size).  Workers take events round-robin, so fewer of them only take longer.
 #define HTM_MCMC_FN(K) (h->dev.fp32 ? (h->nch == 1 ? (const void *)k_mcmc<1, true, K> : (const void *)k_mcmc<2, true, K>)                  \
                         : h->nch == 1 ? (const void *)k_mcmc<1, false, K> : h->nch == 2 ? (const void *)k_mcmc<2, false, K> : (const void *)k_mcmc<0, false, K>)
-        const void *fns[5] = {HTM_MCMC_FN(0), HTM_MCMC_FN(1), HTM_MCMC_FN(2), HTM_MCMC_FN(3), HTM_MCMC_FN(4)};
+        std::vector<const void *> fns = {HTM_MCMC_FN(0), HTM_MCMC_FN(1), HTM_MCMC_FN(2), HTM_MCMC_FN(3), HTM_MCMC_FN(4)};
 #undef HTM_MCMC_FN
+        // (several master workgroups, k_mcmc<.., 7>: one or two stations per lane)
+        if (h->nch == 1) fns.push_back(h->dev.fp32 ? (const void *)k_mcmc<1, true, 7> : (const void *)k_mcmc<1, false, 7>);
+        else if (h->nch == 2) fns.push_back(h->dev.fp32 ? (const void *)k_mcmc<2, true, 7> : (const void *)k_mcmc<2, false, 7>);
         if (hc->step_smem > 48 * 1024)
             for (const void *g : fns) HIPCHK(hipFuncSetAttribute(g, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hc->step_smem));
         // the residency bound holds for whichever main loop gets launched: the smallest of the instantiations' occupancies
@@ -973,6 +990,20 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
         const bool window_ok = hc->persist && !(e && e[0] == '0') && d.dbg == 0 && hc->dev.mirror_n > 0 &&
                                hc->ring_size >= 4 * wd + 32 + 2 * c_max + 16;
         hc->flow = window_ok && d.n_procs == 1;
+        // More than eight chains on a rank: a master workgroup for every eight (k_mcmc<.., 7>, htm_flow.hpp MbShared) instead of
+        // rounds on the same eight waves.  HTM_MB=0: one workgroup.
+        {
+            const char *em = getenv("HTM_MB");
+            const bool on = em && em[0] == '1';
+            if (hc->flow && on && nc > 8 && (h->nch == 1 || h->nch == 2)) {
+                const int nb = (nc + 7) / 8;
+                if (hc->blocks_fit - nb >= 1) {
+                    hc->mb_blocks = nb;
+                    const long room = hc->blocks_fit - nb;
+                    if (hc->dev.n_workers > room) { hc->dev.n_workers = worker_blocks(h->E, 8, room); hc->dev.n_wg = hc->dev.n_workers; }
+                }
+            }
+        }
         hc->flow_lock = window_ok && d.n_procs <= 60 && !(getenv("HTM_FLOW_LOCK") && getenv("HTM_FLOW_LOCK")[0] == '0');      // (MODE_LOCKRUN: up to 60 ranks -- a lane per rank reads its stop word, flow_xload)
         // The pipelined master (htm_pipe.hpp; HTM_PIPE=0 keeps the free-running one): front / evaluators / decider over an LDS ring
         // of iteration slots.  Needs the LDS mirror of the non-hypocentre parameters (what its evaluators read) and one or two
@@ -1143,6 +1174,16 @@ static int ctrl_error(const htm_chains *hc)
     case -13: return fail(HTM_ESTATE, "the master's window of the random stream did not reach a step's position within 5 s (after iteration %d)",
                           hc->h_ctrl.iter_done);
     case -14: return fail(HTM_ESTATE, "an evaluator of the pipelined master waited 5 s for a proposal record (after iteration %d)", hc->h_ctrl.iter_done);
+    case -16: {
+        unsigned long long dg[8] = {0};
+        (void)hipMemcpy(dg, hc->dev.diag, sizeof(dg), hipMemcpyDeviceToHost);
+        return fail(HTM_ESTATE, "several master workgroups: chain %llu waited 5 s in its turn of iteration %llu for the chains %#llx (its epoch %llu, "
+                    "the epoch in memory %llu, first awaited word %#llx)", dg[1], dg[2], dg[3], dg[4], dg[5], dg[6]);
+    }
+    case -17: case -18: case -19: case -20: case -21:
+        return fail(HTM_ESTATE, "several master workgroups: a wait for %s gave up after 5 s (after iteration %d)",
+                    hc->h_ctrl.err == -17 ? "the swap record of the iteration before" : hc->h_ctrl.err == -18 ? "the swap partner's record"
+                    : hc->h_ctrl.err == -19 ? "the anchor the wave had just written" : "the last iteration's records at the end of the launch", hc->h_ctrl.iter_done);
     default: return fail(HTM_ESTATE, "device error flag %d", hc->h_ctrl.err);
     }
 }
@@ -2034,7 +2075,7 @@ int htm_chains_last_run_stats(htm_chains *hc, double *device_us, int *graph_laun
 int htm_chains_master_stats(htm_chains *hc, int *single_rank_loop, int *lockstep_loop, int64_t *flushes)
 {
     if (!hc) return fail(HTM_EINVAL, "NULL argument");
-    if (single_rank_loop) *single_rank_loop = !hc->persist ? -1 : hc->pipe ? 5 : hc->flow ? 3 : 0;
+    if (single_rank_loop) *single_rank_loop = !hc->persist ? -1 : hc->pipe ? 5 : (hc->flow && hc->mb_blocks > 1) ? 7 : hc->flow ? 3 : 0;
     if (lockstep_loop) *lockstep_loop = !hc->persist ? -1 : hc->pipe_lock ? 6 : hc->flow_lock ? 4 : 2;
     if (flushes) {
         HIPCHK(hipStreamSynchronize(hc->fwd->stream));

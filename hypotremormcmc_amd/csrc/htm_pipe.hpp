@@ -1209,19 +1209,22 @@ __global__ __launch_bounds__((mcmc_threads<NCH, MK>())) void k_mcmc(FwdDev f, Ch
                                                unsigned long long launch)
 {
     const KArgLayout __attribute__((address_space(4))) &ka = *(const KArgLayout __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
-    if (blockIdx.x == 0) {
+    // MK 7: several master workgroups (blocks 0 .. n_mb - 1, eight chains each: flow_body<.., MB>); the workers follow them
+    const int n_mb = MK == 7 ? (ka.cs.n_chains + 7) / 8 : 1;
+    if ((int)blockIdx.x < n_mb) {
         // MK 3: the single-rank loop on the free-running master (flow_body); 0: the same loop with barriers (step_body)
         // 4: a lock-step rank (MODE_LOCKRUN, swap records exchanged inside the launch) on the free-running master; 2: with barriers
         if constexpr (MK == 3) flow_body<NCH, F32, false>(ka.f, ka.cs, target_arg, ring_size, wmax, launch);
         else if constexpr (MK == 4) flow_body<NCH, F32, true>(ka.f, ka.cs, target_arg, ring_size, wmax, launch);
         else if constexpr (MK == 5) pipe_body<NCH, F32, false>(ka.f, ka.cs, target_arg, ring_size, wmax, launch);      // the pipelined master: single rank
         else if constexpr (MK == 6) pipe_body<NCH, F32, true>(ka.f, ka.cs, target_arg, ring_size, wmax, launch);       // ... a lock-step rank (MODE_LOCKRUN)
+        else if constexpr (MK == 7) { if (!flow_body<NCH, F32, false, true>(ka.f, ka.cs, target_arg, ring_size, wmax, launch)) return; }      // (only the workgroup that finishes last goes on)
         else step_body<NCH, true, F32, MK>(ka.f, ka.cs, mode, target_arg, gathered, ring_size, wmax, launch);
         // every exit of the master comes through here (its returns are uniform over the block): release the workers
         __syncthreads();
         if (threadIdx.x == 0) st_agent(&ka.cs.ps->quit, launch + 1ull);
     } else {
-        worker_body<NCH, F32, mcmc_threads<NCH, MK>() / 64, (MK >= 5)>(ka.f, ka.cs, launch, blockIdx.x - 1);
+        worker_body<NCH, F32, mcmc_threads<NCH, MK>() / 64, (MK == 5 || MK == 6)>(ka.f, ka.cs, launch, (int)blockIdx.x - n_mb);
     }
 }
 

@@ -1,5 +1,5 @@
-"""Development check of the pipelined master (csrc/htm_pipe.hpp) on the GPU box: the same job on the pipelined master and on the
-free-running one (HTM_PIPE=0) -- every step's type / element / prior_ok / accept, values to rounding, RNG position, counters --
+"""Development check of another chain master on the GPU box: the same job on the pipelined master (csrc/htm_pipe.hpp; or, with
+CHECK_MB=1, on several master workgroups: HTM_MB=1, csrc/htm_flow.hpp MbShared) and on the free-running one (HTM_PIPE=0 / HTM_MB=0) -- every step's type / element / prior_ok / accept, values to rounding, RNG position, counters --
 then a timing of the pipelined master.      python tools/pipe_check.py [n_chains] [n_events] [n_sta] [n_iter] [time_iters]"""
 import os
 import sys
@@ -28,8 +28,14 @@ if os.environ.get("PIPE_CHECK_SZ"):
 obs = ObsData.from_arrays(data.sta_x, data.sta_y, data.t_obs, data.t_stdv, data.a_obs, data.a_stdv)
 
 
+MB = os.environ.get("CHECK_MB") == "1"
+
+
 def run(pipe):
-    os.environ["HTM_PIPE"] = "1" if pipe else "0"
+    if MB:
+        os.environ["HTM_MB"] = "1" if pipe else "0"
+    else:
+        os.environ["HTM_PIPE"] = "1" if pipe else "0"
     fwd, cs = driver.build_rank(params, data.sta_x, data.sta_y, data.sta_z, obs, 0, n_procs=1)
     if not os.environ.get("PIPE_CHECK_NOSLOG"):
         cs.enable_steplog(n_iter * nc)
