@@ -132,12 +132,13 @@ __device__ __forceinline__ void mb_take(MbWave &mw, unsigned long long v)
     mw.epoch = (int)(unsigned)rl_u64(v, 61); mw.last_iter = (int)(unsigned)rl_u64(v, 62); mw.err = (int)(unsigned)rl_u64(v, 63);
 }
 // `n` granules from `base`, all tagged `tag`: polls until they are (false: gave up, sh.c.err set)
-__device__ __forceinline__ bool mb_wait(FlowShared &sh, const unsigned long long *base, int n, unsigned tag, int lane, unsigned long long &v, int code = -12)
+__device__ __forceinline__ bool mb_wait(FlowShared &sh, const unsigned long long *base, int n, unsigned tag, int lane, unsigned long long &v, int code = -12,
+                                        unsigned mask = 0xffffffffu)
 {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     for (unsigned spin = 0;; ++spin) {
         v = lane < n ? ld_agent(base + lane) : ((unsigned long long)tag << 32);
-        if (__all((unsigned)(v >> 32) == tag)) return true;
+        if (__all(((unsigned)(v >> 32) & mask) == (tag & mask)) && __all((unsigned)(v >> 32) == (unsigned)(rl_u64(v, 0) >> 32) || lane >= n)) return true;
         if ((spin & 7u) == 7u) {
             if (sh.c.err != 0) return false;
             if (__builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) { if (lane == 0) sh.c.err = code; return false; }
@@ -602,14 +603,15 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
             if (lane < 8) {
                 const unsigned pay = lane == 0 ? (unsigned)E : lane == 1 ? (unsigned)i1 : lane == 2 ? (unsigned)i2 : lane == 3 ? (unsigned)nd
                                    : lane == 4 ? (unsigned)(rb >> 32) : lane == 5 ? (unsigned)rb : lane == 6 ? (unsigned)(lb >> 32) : (unsigned)lb;
-                st_agent(&g_mb->swrec[k4][lane], ((unsigned long long)(unsigned)iter << 32) | pay);
+                // (tag = epoch << 24 | iteration: a step run again under a new epoch posts a new version; the reader knows which it wants)
+                st_agent(&g_mb->swrec[k4][lane], ((unsigned long long)((((unsigned)W.epoch & 0xffu) << 24) | ((unsigned)iter & 0xffffffu)) << 32) | pay);
             }
         }
     }
     {
         const unsigned long long pword = ((unsigned long long)(((unsigned)W.epoch << 1) | (ok ? 0u : 1u)) << 32) | (unsigned)key;
-        if constexpr (MB) { if (lane == 0) st_agent(&g_mb->prog[c], pword); }
-        else { if (lane == 0) lds_st(&sh.prog[c], pword); }
+        if (lane == 0) lds_st(&sh.prog[c], pword);                       // (the chains of this workgroup read it here)
+        if constexpr (MB) { if (lane == 0) st_agent(&g_mb->prog[c], pword); }      // (the chains of the other workgroups)
     }
     // several master workgroups: this step's look at what the chains share (MbShared), in flight under the evaluation; with it
     // the swap the stream holds after the iteration before (read for good when the turn has come)
@@ -641,19 +643,35 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
             // next step, of its step after that, and the end of the iteration after next -- issued here, used behind the evaluation
             // (the hop tables reach kHops steps: with more chains than that -- several master workgroups -- the positions are looked
             // up at the top of the next step instead)
-            if (NW >= nc_ && nc_ <= kHops && W.rpos1 >= 0 && W.B2 >= 0 && c >= W.rc1 && iter + 1 <= sh.c.iter_target && rg.mir_n > 0) {
+            if (NW >= nc_ && W.rpos1 >= 0 && W.B2 >= 0 && c >= W.rc1 && iter + 1 <= sh.c.iter_target && rg.mir_n > 0) {
                 la = 1; la_epoch = W.epoch;
                 const int n1 = c - W.rc1;
-                if (n1 > 0) hA = rg.hop[(W.rpos1 & M) * kHops + n1 - 1];
-                if (c > 0) hB = rg.hop[(W.B2 & M) * kHops + c - 1];
-                hE = rg.hop[(W.B2 & M) * kHops + nc_ - 1];
+                if (nc_ <= kHops) {
+                    if (n1 > 0) hA = rg.hop[(W.rpos1 & M) * kHops + n1 - 1];
+                    if (c > 0) hB = rg.hop[(W.B2 & M) * kHops + c - 1];
+                    hE = rg.hop[(W.B2 & M) * kHops + nc_ - 1];
+                } else {
+                    // (more chains than the hop tables reach in one entry -- several master workgroups: the positions by
+                    // chained look-ups, here; what the stream holds there is still read under the evaluation)
+                    // (every table entry read must lie inside the window: a position past it holds another iteration's numbers)
+                    const int limh = uni(sh.fill) - 16;
+                    auto hops = [&](int pos, int n) __attribute__((always_inline)) {
+                        int q = pos;
+                        while (n > kHops) { if (q >= limh) return -1; q += rg.hop[(q & M) * kHops + kHops - 1]; n -= kHops; }
+                        if (n > 0) { if (q >= limh) return -1; q += rg.hop[(q & M) * kHops + n - 1]; }
+                        return q;
+                    };
+                    la_p1 = hops(W.rpos1, n1); la_p2 = hops(W.B2, c); la_E2 = hops(W.B2, nc_);
+                    la = (la_p1 >= 0 && la_p2 >= 0 && la_E2 >= 0) ? 3 : 0;
+                }
             }
             if constexpr (NCH > 0) event_misfit<NCH, 2, F32, true>(f, ob, lane, st, px, py, pz, tp.rbeta, tp.katt, out);
             else event_misfit_generic<2>(f, ev, lane, s_sx, s_sy, s_sz, tc, ac, 0, -1, 0.0, px, py, pz, beta, q, out);
             L_new = L_cur + wave_sum1(out[0] - out[1]);
             // look-ahead, second round trip: what the stream holds at those positions -- used after the commit
             if (la) {
-                la_p1 = W.rpos1 + uni(hA); la_p2 = W.B2 + uni(hB); la_E2 = W.B2 + uni(hE);
+                if (la == 1) { la_p1 = W.rpos1 + uni(hA); la_p2 = W.B2 + uni(hB); la_E2 = W.B2 + uni(hE); }
+                else { la_p1 = uni(la_p1); la_p2 = uni(la_p2); la_E2 = uni(la_E2); }
                 const int lim = uni(sh.fill) - 16;
                 if (la_p1 < lim && la_p2 < lim && la_E2 + 16 < lim) {
                     la = 2;
@@ -781,9 +799,12 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
             unsigned long long pv;
             int e;
             if constexpr (MB) {
-                if (spin > 0) mbv = mb_look(g_mb, nc_, lane);      // (the first round uses the look issued before the evaluation)
+                // the chains of this workgroup: LDS, as with one workgroup; the others' and the shared words: the look at memory
+                // (the first round uses the one issued before the evaluation; a constant lag between the workgroups is all the
+                // round trip costs: the steps of the OTHER workgroups a turn waits for are mostly an iteration old)
+                if (spin > 0) mbv = mb_look(g_mb, nc_, lane);
                 mb_take(mw, mbv);
-                pv = lane < nc_ ? mbv : 0ull; e = mw.epoch;
+                pv = lane < nc_ ? ((lane >> 3) == (c >> 3) ? lds_ld(&sh.prog[lane]) : mbv) : 0ull; e = mw.epoch;
                 if (__builtin_expect(mw.err != 0, 0)) { if (lane == 0 && sh.c.err == 0) sh.c.err = mw.err; return kFlowAbort; }
                 if (__builtin_expect(iter > mw.last_iter, 0)) return kFlowStop;      // (the launch ends before this iteration: the step is not taken)
             } else {
@@ -802,6 +823,16 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
             const unsigned ph = (unsigned)(pv >> 32);
             const bool okl = lane >= nc_ || lane == c || pk > need ||
                              (pk == need && (pk < W.akey || (ph == ((unsigned)W.epoch << 1))));
+            if constexpr (MB) {
+                // A check published under an epoch this wave has not seen yet: the epoch word (memory, a round trip old) lags the
+                // checks (LDS for this workgroup's chains, or simply a later store) -- a chain that is already past the anchor
+                // must not be taken for "ahead" before the anchor has been adopted.  Look again until the epoch shows.
+                if (__any(lane < nc_ && lane != c && (int)(ph >> 1) > W.epoch)) {
+                    if ((spin & 15u) == 15u && __builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) { if (lane == 0) sh.c.err = -16; return kFlowAbort; }
+                    __builtin_amdgcn_s_sleep(1);
+                    continue;
+                }
+            }
             if (__all(okl)) break;
             if constexpr (LOCK) {
                 // the job may have stopped after the iteration before (a wave that learnt it from the swap records has left
@@ -924,16 +955,47 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
         // chain's (T, L) from its record -- this chain's own from LDS, where its wave keeps them
         T = sh.T4[ppar][c]; rT = sh.rT4[ppar][c];
         if (nc_ > 1) {
-            if (!__all(lane >= 8 || (unsigned)(mbs >> 32) == (unsigned)(iter - 1))) {
-                if (!mb_wait(sh, &g_mb->swrec[ppar][0], 8, (unsigned)(iter - 1), lane, mbs, -17)) return kFlowAbort;
+            const bool sw_local = ((nc_ - 1) >> 3) == (c >> 3);      // the rank's last chain is this workgroup's: its LDS has the swap
+            int i1, i2;
+            double sr, slr;
+            if (sw_local) { i1 = uni(lds_ld(&sh.sw_i1[ppar])); i2 = uni(sh.sw_i2[ppar]); sr = sh.sw_r[ppar]; slr = sh.sw_logr[ppar]; }
+            else {
+                // WHICH version of the record: the one posted with the last chain's check of iteration iter - 1 as this step's
+                // turn has seen it -- its epoch is in that check's word.  (The record read before the evaluation may be the one
+                // of an earlier run of that step.)  The last chain already past that step: its record is final and long
+                // there -- read again now.
+                const unsigned long long lv = rl_u64(mbv, nc_ - 1);
+                const int needL = (iter - 1 - sh.i0) * nc_ + nc_ - 1;
+                if ((int)(unsigned)lv == needL) {
+                    const unsigned want = ((((unsigned)(lv >> 33)) & 0xffu) << 24) | ((unsigned)(iter - 1) & 0xffffffu);
+                    if (!__all(lane >= 8 || (unsigned)(mbs >> 32) == want)) {
+                        if (!mb_wait(sh, &g_mb->swrec[ppar][0], 8, want, lane, mbs, -17)) return kFlowAbort;
+                    }
+                } else {
+                    if (!mb_wait(sh, &g_mb->swrec[ppar][0], 8, (unsigned)(iter - 1) & 0xffffffu, lane, mbs, -17, 0xffffffu)) return kFlowAbort;
+                }
+                i1 = (int)(unsigned)rl_u64(mbs, 1); i2 = (int)(unsigned)rl_u64(mbs, 2);
+                sr = gran_f64(rl_u64(mbs, 4), rl_u64(mbs, 5)); slr = gran_f64(rl_u64(mbs, 6), rl_u64(mbs, 7));
             }
-            const int i1 = (int)(unsigned)rl_u64(mbs, 1), i2 = (int)(unsigned)rl_u64(mbs, 2);
             if (c == i1 || c == i2) {
                 const int o2 = c == i1 ? i2 : i1;
-                unsigned long long cv;
-                if (!mb_wait(sh, &g_mb->crec[ppar][o2][0], 4, (unsigned)(iter - 1), lane, cv, -18)) return kFlowAbort;
-                const double To = gran_f64(rl_u64(cv, 0), rl_u64(cv, 1)), Lo = gran_f64(rl_u64(cv, 2), rl_u64(cv, 3)), rTo = 1.0 / To;
-                const double sr = gran_f64(rl_u64(mbs, 4), rl_u64(mbs, 5)), slr = gran_f64(rl_u64(mbs, 6), rl_u64(mbs, 7));
+                double To, Lo, rTo;
+                if ((o2 >> 3) == (c >> 3)) {      // the other chain is this workgroup's too: LDS (as with one workgroup)
+                    const int want = (iter - 1 - sh.i0) * nc_ + o2;
+                    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                    for (unsigned spin = 0; lds_ld(&sh.done[o2]) < want; ++spin) {
+                        if ((spin & 15u) == 15u) {
+                            if (sh.c.err != 0) return kFlowAbort;
+                            if (__builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) { if (lane == 0) sh.c.err = -12; return kFlowAbort; }
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    To = sh.T4[ppar][o2]; rTo = sh.rT4[ppar][o2]; Lo = sh.L4[ppar][o2];
+                } else {
+                    unsigned long long cv;
+                    if (!mb_wait(sh, &g_mb->crec[ppar][o2][0], 4, (unsigned)(iter - 1), lane, cv, -18)) return kFlowAbort;
+                    To = gran_f64(rl_u64(cv, 0), rl_u64(cv, 1)); Lo = gran_f64(rl_u64(cv, 2), rl_u64(cv, 3)); rTo = 1.0 / To;
+                }
                 const double rT1 = c == i1 ? rT : rTo, rT2 = c == i1 ? rTo : rT, L1 = c == i1 ? L_cur : Lo, L2 = c == i1 ? Lo : L_cur;
                 const double del_s = (L2 - L1) * (rT1 - rT2);                            // :292
                 if (sr >= kEps && slr <= del_s) { T = To; rT = rTo; }                    // :131-136
@@ -1416,7 +1478,7 @@ __device__ __forceinline__ bool flow_body(FwRef f_, CsRef cs_, int target_arg, i
             if (sh.c.err == 0 && last > i0) {
                 const int par = last & 3;
                 unsigned sw[8];
-                for (int k = 0; k < 8; ++k) { const unsigned long long v = ld_agent(&g_mb->swrec[par][k]); sw[k] = (unsigned)v; if ((int)(unsigned)(v >> 32) != last) sh.c.err = -20; }
+                for (int k = 0; k < 8; ++k) { const unsigned long long v = ld_agent(&g_mb->swrec[par][k]); sw[k] = (unsigned)v; if (((unsigned)(v >> 32) & 0xffffffu) != ((unsigned)last & 0xffffffu)) sh.c.err = -20; }
                 const int E = (int)sw[0], i1 = (int)sw[1], i2 = (int)sw[2], nd = (int)sw[3];
                 if (sh.c.err == 0 && nc > 1) {
                     const double sr = __longlong_as_double((long long)(((unsigned long long)sw[4] << 32) | sw[5]));

@@ -994,8 +994,10 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
         // rounds on the same eight waves.  HTM_MB=0: one workgroup.
         {
             const char *em = getenv("HTM_MB");
-            const bool on = em && em[0] == '1';
-            if (hc->flow && on && nc > 8 && (h->nch == 1 || h->nch == 2)) {
+            const bool on = !(em && em[0] == '0');
+            // (9..16 chains: two workgroups.  More would need more of the stream window per step than the one wave of a workgroup that
+            // keeps it can load -- 128 positions, an iteration of 16 chains takes ~90)
+            if (hc->flow && on && nc > 8 && nc <= 16 && (h->nch == 1 || h->nch == 2)) {
                 const int nb = (nc + 7) / 8;
                 if (hc->blocks_fit - nb >= 1) {
                     hc->mb_blocks = nb;
