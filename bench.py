@@ -370,8 +370,18 @@ def main(argv=None):
         except Exception:
             traffic = None
         nch = 1 if S <= 64 else 2 if S <= 128 else 4 if S <= 256 else 0
+        try:
+            loops = cs.master_stats()        # which main loop the library selected for this chain set
+        except Exception:
+            loops = {}
         if lockstep:
-            kname = f"k_mcmc<{nch}, *, 2> (persistent lock-step: one iteration per hand-shake, swap records exchanged inside the kernel)"
+            lk = loops.get("lockstep_loop", 4)
+            kname = (f"k_mcmc<{nch}, *, {lk}> (persistent lock-step rank: " +
+                     ("free-running chain master, per-chain swap records and per-rank headers written into the peers' inboxes from inside the kernel, "
+                      "only the pair's two chains wait" if lk == 4 else "one iteration per hand-shake, swap records exchanged inside the kernel") + ")")
+        elif persistent and loops.get("single_rank_loop", 3) == 7:
+            kname = (f"k_mcmc<{nch}, *, 7> (free-running chain masters, one workgroup per eight chains, + resident full-evaluation workers: "
+                     "one persistent launch)")
         elif persistent and os.environ.get("HTM_FLOW", "1") != "0":
             kname = (f"k_mcmc<{nch}, *, 3> (free-running chain master + resident full-evaluation workers: propose + partial/full "
                      "log-likelihood + judge + swap, one persistent launch)")

@@ -223,7 +223,13 @@ __device__ __forceinline__ bool flow_swap_at(CsRef cs_, const StepShared &sh, co
 __device__ __forceinline__ int flow_next_base(CsRef cs, const StepShared &sh, const Ring &rg, int pos, int n, int limit)
 {
     if (pos < 0) return -1;
-    const int E = hop_ahead(rg, pos, n);
+    // (chained table entries when n > kHops: each one read must lie inside the window -- limit -- like the result)
+    int E = pos;
+    {
+        int m = n;
+        while (m > kHops) { if (E + 16 >= limit) return -1; E += rg.hop[(E & rg.mask) * kHops + kHops - 1]; m -= kHops; }
+        if (m > 0) { if (E + 16 >= limit) return -1; E += rg.hop[(E & rg.mask) * kHops + m - 1]; }
+    }
     int i1, i2, nd;
     if (E + 16 >= limit || !flow_swap_at(cs, sh, rg, E, limit, i1, i2, nd)) return -1;
     return E + nd;
@@ -1369,7 +1375,16 @@ __device__ __forceinline__ bool flow_body(FwRef f_, CsRef cs_, int target_arg, i
         }
         // where the step starts: known from the step before (FlowNext), or from the hop table now
         const bool known = nx.p >= 0 && nx.it == iter && nx.c == c && nx.epoch == W.epoch;
-        const int p = known ? nx.p : hop_ahead(rg, W.rpos, c - W.rc);
+        // (more than kHops steps from the reference position take chained table entries: every entry read must lie inside the
+        // window -- a position past it holds another iteration's numbers, and nothing downstream would notice)
+        auto hops_in_window = [&](int pos, int n) __attribute__((always_inline)) {
+            const int lim = lds_ld(&sh.fill) - 16;
+            int q = pos;
+            while (n > kHops) { if (q >= lim) return -1; q += rg.hop[(q & rg.mask) * kHops + kHops - 1]; n -= kHops; }
+            if (n > 0) { if (q >= lim) return -1; q += rg.hop[(q & rg.mask) * kHops + n - 1]; }
+            return q;
+        };
+        int p = known ? nx.p : hops_in_window(W.rpos, c - W.rc);
         if (!known) nx.p = -1;
         if (!LOCK && wave == 0 && c == 0 && lane == 0) {      // (a lock-step rank asks the others through its swap record: flow_post_record)
             // chain 0's wave decides where the launch ends: record buffers or produced stream nearly used up.  Everybody
@@ -1390,13 +1405,14 @@ __device__ __forceinline__ bool flow_body(FwRef f_, CsRef cs_, int target_arg, i
             }
         }
         // the window covers this step (chain 0's wave keeps it 3 iterations ahead); a fail-stop, never expected to wait
-        if (__builtin_expect(!known && p + 16 >= lds_ld(&sh.fill), 0)) {      // (a known start was checked against the window when it was looked up)
+        if (__builtin_expect(!known && (p < 0 || p + 16 >= lds_ld(&sh.fill)), 0)) {      // (a known start was checked against the window when it was looked up)
             if (wave == 0) { if (lane == 0) sh.c.err = -13; break; }
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
             bool dead = false;
-            while (p + 16 >= lds_ld(&sh.fill)) {
+            while (p < 0 || p + 16 >= lds_ld(&sh.fill)) {
                 if (sh.c.err != 0 || __builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) { dead = true; break; }
                 __builtin_amdgcn_s_sleep(4);
+                if (p < 0) p = hops_in_window(W.rpos, c - W.rc);
             }
             if (dead) { if (lane == 0 && sh.c.err == 0) sh.c.err = -13; break; }
         }
