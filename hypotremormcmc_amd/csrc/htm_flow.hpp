@@ -220,12 +220,16 @@ __device__ __forceinline__ bool flow_swap_at(CsRef cs_, const StepShared &sh, co
 }
 
 // base of the next iteration when n chain steps of this one remain from pos; -1 if the window does not cover it
+// (BOUNDED: chained table entries -- n > kHops -- are read only inside the window.  Two master workgroups keep a shorter lead
+// than the three iterations of one workgroup, whose look-ups have never come near the window's end.)
+template <bool BOUNDED = false>
 __device__ __forceinline__ int flow_next_base(CsRef cs, const StepShared &sh, const Ring &rg, int pos, int n, int limit)
 {
     if (pos < 0) return -1;
     // (chained table entries when n > kHops: each one read must lie inside the window -- limit -- like the result)
     int E = pos;
-    {
+    if (!BOUNDED || n <= kHops) E = hop_ahead(rg, pos, n);      // (one entry, at a position inside the window)
+    else {
         int m = n;
         while (m > kHops) { if (E + 16 >= limit) return -1; E += rg.hop[(E & rg.mask) * kHops + kHops - 1]; m -= kHops; }
         if (m > 0) { if (E + 16 >= limit) return -1; E += rg.hop[(E & rg.mask) * kHops + m - 1]; }
@@ -265,13 +269,14 @@ __device__ __forceinline__ void flow_void_books(CsRef cs, FlowShared &sh, int wa
 // step itself starts at or after the anchor.  Returns false if the epoch moved on meanwhile (the caller looks again).
 // (g != nullptr: a multi-block launch -- epoch and anchor are MbShared's; false: the anchor of epoch e is not there (yet, or
 // any more): the caller looks at the epoch again)
+template <bool MB = false>
 __device__ __forceinline__ bool flow_adopt(CsRef cs_, FlowShared &sh, const Ring &rg, FlowWave &W, int e, int it, int c, bool in_turn, bool &stands,
                                            const MbShared *g = nullptr)
 {
     CsRef cs = rebase(cs_);
     const int nc = cs.n_chains;
     unsigned long long a;
-    if (g) {
+    if constexpr (MB) {
         const unsigned long long a0 = ld_agent(&g->anch[e & 1][0]), a1 = ld_agent(&g->anch[e & 1][1]);
         if ((int)(unsigned)(a0 >> 32) != e || (int)(unsigned)(a1 >> 32) != e) return false;
         a = (a0 << 32) | (a1 & 0xffffffffull);
@@ -289,16 +294,16 @@ __device__ __forceinline__ bool flow_adopt(CsRef cs_, FlowShared &sh, const Ring
     if (!stands) {
         // the current step starts at or after the anchor: same iteration, or the anchor sits in the iteration before
         if (ia == it) { W.rc = ca; W.rpos = ap; }
-        else { W.rc = 0; W.rpos = flow_next_base(cs, sh, rg, ap, nc - ca, 1 << 30); }
-        W.rc1 = 0; W.rpos1 = flow_next_base(cs, sh, rg, W.rpos, nc - W.rc, limit);
-        W.B2 = flow_next_base(cs, sh, rg, W.rpos1, nc, limit);
+        else { W.rc = 0; W.rpos = flow_next_base<MB>(cs, sh, rg, ap, nc - ca, 1 << 30); }
+        W.rc1 = 0; W.rpos1 = flow_next_base<MB>(cs, sh, rg, W.rpos, nc - W.rc, limit);
+        W.B2 = flow_next_base<MB>(cs, sh, rg, W.rpos1, nc, limit);
     } else if (ia == it) {
         W.rc = ca; W.rpos = ap;                         // (the wave's later chains of this iteration)
-        W.rc1 = 0; W.rpos1 = flow_next_base(cs, sh, rg, ap, nc - ca, limit);
-        W.B2 = flow_next_base(cs, sh, rg, W.rpos1, nc, limit);
+        W.rc1 = 0; W.rpos1 = flow_next_base<MB>(cs, sh, rg, ap, nc - ca, limit);
+        W.B2 = flow_next_base<MB>(cs, sh, rg, W.rpos1, nc, limit);
     } else {                                            // the anchor is a step of the next iteration
         W.rc1 = ca; W.rpos1 = ap;
-        W.B2 = flow_next_base(cs, sh, rg, ap, nc - ca, limit);
+        W.B2 = flow_next_base<MB>(cs, sh, rg, ap, nc - ca, limit);
     }
     return true;
 }
@@ -652,7 +657,8 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
             if (NW >= nc_ && W.rpos1 >= 0 && W.B2 >= 0 && c >= W.rc1 && iter + 1 <= sh.c.iter_target && rg.mir_n > 0) {
                 la = 1; la_epoch = W.epoch;
                 const int n1 = c - W.rc1;
-                if (nc_ <= kHops) {
+                // (one workgroup: a wave has one chain only with <= 8 = kHops chains, the tables reach in one entry)
+                if (!MB || nc_ <= kHops) {
                     if (n1 > 0) hA = rg.hop[(W.rpos1 & M) * kHops + n1 - 1];
                     if (c > 0) hB = rg.hop[(W.B2 & M) * kHops + c - 1];
                     hE = rg.hop[(W.B2 & M) * kHops + nc_ - 1];
@@ -676,7 +682,7 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
             L_new = L_cur + wave_sum1(out[0] - out[1]);
             // look-ahead, second round trip: what the stream holds at those positions -- used after the commit
             if (la) {
-                if (la == 1) { la_p1 = W.rpos1 + uni(hA); la_p2 = W.B2 + uni(hB); la_E2 = W.B2 + uni(hE); }
+                if (!MB || la == 1) { la_p1 = W.rpos1 + uni(hA); la_p2 = W.B2 + uni(hB); la_E2 = W.B2 + uni(hE); }
                 else { la_p1 = uni(la_p1); la_p2 = uni(la_p2); la_E2 = uni(la_E2); }
                 const int lim = uni(sh.fill) - 16;
                 if (la_p1 < lim && la_p2 < lim && la_E2 + 16 < lim) {
@@ -819,7 +825,7 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
             }
             if (__builtin_expect(e != W.epoch, 0)) {
                 bool stands = false;
-                if (!flow_adopt(cs, sh, rg, W, e, iter, c, true, stands, MB ? g_mb : nullptr)) { if (MB) __builtin_amdgcn_s_sleep(1); continue; }
+                if (!flow_adopt<MB>(cs, sh, rg, W, e, iter, c, true, stands, g_mb)) { if (MB) __builtin_amdgcn_s_sleep(1); continue; }
                 flow_void_books(cs, sh, wave, NW, nc_, lane);
                 if (!stands) return kFlowRestart;
                 continue;
@@ -1080,7 +1086,7 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
             }
             // (this wave's own view: from what it has just written; a later rejection finds it at its next look)
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            while (!flow_adopt(cs, sh, rg, W, e1, iter, c, true, stands, g_mb)) {
+            while (!flow_adopt<true>(cs, sh, rg, W, e1, iter, c, true, stands, g_mb)) {
                 if (__builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) { if (lane == 0) sh.c.err = -19; return kFlowAbort; }
                 __builtin_amdgcn_s_sleep(1);
             }
@@ -1326,8 +1332,8 @@ __device__ __forceinline__ bool flow_body(FwRef f_, CsRef cs_, int target_arg, i
 
     FlowWave W;
     W.epoch = 0; W.akey = 0; W.rc = 0; W.rpos = 0;
-    W.rc1 = 0; W.rpos1 = flow_next_base(cs, sh, rg, 0, nc, sh.fill);
-    W.B2 = flow_next_base(cs, sh, rg, W.rpos1, nc, sh.fill);
+    W.rc1 = 0; W.rpos1 = flow_next_base<MB>(cs, sh, rg, 0, nc, sh.fill);
+    W.B2 = flow_next_base<MB>(cs, sh, rg, W.rpos1, nc, sh.fill);
     FlowNext nx;
     nx.p = -1; nx.it = 0; nx.c = 0; nx.epoch = 0; nx.type = 5; nx.idx = 0; nx.evt = 1; nx.dec_w = 6; nx.g = 0.0; nx.r = 0.0; nx.logr = 0.0; nx.b3 = -1;
     int iter = i0 + 1;
@@ -1360,7 +1366,7 @@ __device__ __forceinline__ bool flow_body(FwRef f_, CsRef cs_, int target_arg, i
             const int e = tp.epoch;
             if (__builtin_expect(e != W.epoch, 0)) {
                 bool stands = false;
-                if (!flow_adopt(cs, sh, rg, W, e, iter, c, false, stands, g_mb)) {
+                if (!flow_adopt<MB>(cs, sh, rg, W, e, iter, c, false, stands, g_mb)) {
                     if constexpr (MB) { mb_take(mw, mb_look(g_mb, nc, lane)); }      // (the anchor of that epoch is gone or not there yet: look again)
                     continue;
                 }
@@ -1370,8 +1376,8 @@ __device__ __forceinline__ bool flow_body(FwRef f_, CsRef cs_, int target_arg, i
         }
         if (iter > tp.last_iter || tp.err != 0) break;      // (a lock-step rank: the swap of its last iteration is applied after the loop)
         if (__builtin_expect(W.rpos1 < 0 || W.B2 < 0, 0)) {      // predictions the window did not cover when they were made
-            if (W.rpos1 < 0) { W.rpos1 = flow_next_base(cs, sh, rg, W.rpos, nc - W.rc, sh.fill); W.rc1 = 0; }
-            if (W.B2 < 0 && W.rpos1 >= 0) W.B2 = flow_next_base(cs, sh, rg, W.rpos1, nc - W.rc1, sh.fill);
+            if (W.rpos1 < 0) { W.rpos1 = flow_next_base<MB>(cs, sh, rg, W.rpos, nc - W.rc, sh.fill); W.rc1 = 0; }
+            if (W.B2 < 0 && W.rpos1 >= 0) W.B2 = flow_next_base<MB>(cs, sh, rg, W.rpos1, nc - W.rc1, sh.fill);
         }
         // where the step starts: known from the step before (FlowNext), or from the hop table now
         const bool known = nx.p >= 0 && nx.it == iter && nx.c == c && nx.epoch == W.epoch;
@@ -1384,7 +1390,9 @@ __device__ __forceinline__ bool flow_body(FwRef f_, CsRef cs_, int target_arg, i
             if (n > 0) { if (q >= lim) return -1; q += rg.hop[(q & rg.mask) * kHops + n - 1]; }
             return q;
         };
-        int p = known ? nx.p : hops_in_window(W.rpos, c - W.rc);
+        // (up to kHops steps: ONE entry, at a position that was inside the window when it became the wave's reference -- no look at
+        // the window's extent on the way to every step)
+        int p = known ? nx.p : ((!MB || c - W.rc <= kHops) ? hop_ahead(rg, W.rpos, c - W.rc) : hops_in_window(W.rpos, c - W.rc));
         if (!known) nx.p = -1;
         if (!LOCK && wave == 0 && c == 0 && lane == 0) {      // (a lock-step rank asks the others through its swap record: flow_post_record)
             // chain 0's wave decides where the launch ends: record buffers or produced stream nearly used up.  Everybody
@@ -1437,14 +1445,14 @@ __device__ __forceinline__ bool flow_body(FwRef f_, CsRef cs_, int target_arg, i
             iter += 1;
             rec_phase = rec_phase + 1 == n_int ? 0 : rec_phase + 1;
             if (W.rpos1 < 0) {    // (the window did not cover the prediction when it was made: it does now)
-                W.rpos1 = flow_next_base(cs, sh, rg, W.rpos, nc - W.rc, 1 << 30); W.rc1 = 0;
+                W.rpos1 = flow_next_base<MB>(cs, sh, rg, W.rpos, nc - W.rc, 1 << 30); W.rc1 = 0;
                 W.B2 = -1;
             }
             W.rc = W.rc1; W.rpos = W.rpos1;
-            W.rc1 = 0; W.rpos1 = W.B2 >= 0 ? W.B2 : flow_next_base(cs, sh, rg, W.rpos, nc - W.rc, sh.fill);
+            W.rc1 = 0; W.rpos1 = W.B2 >= 0 ? W.B2 : flow_next_base<MB>(cs, sh, rg, W.rpos, nc - W.rc, sh.fill);
             // (the base of the iteration after next: looked up during the step, or from the tables now)
             if (nx.p >= 0 && nx.epoch == W.epoch && nx.it == iter && nx.b3 >= 0 && W.rpos1 >= 0) W.B2 = nx.b3;
-            else W.B2 = flow_next_base(cs, sh, rg, W.rpos1, nc, sh.fill);
+            else W.B2 = flow_next_base<MB>(cs, sh, rg, W.rpos1, nc, sh.fill);
         }
     }
 #ifdef HTM_STAMPS

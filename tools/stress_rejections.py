@@ -15,7 +15,7 @@ from oracle import oracle
 n_iter = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 bad = 0
 SEED0 = int(sys.argv[4]) if len(sys.argv) > 4 else 0      # another set of data sets and random streams
-SHAPES = ((64, 64, 8), (1000, 64, 8), (200, 64, 3), (30, 20, 7), (100, 64, 16), (64, 32, 27))
+SHAPES = ((64, 64, 8), (1000, 64, 8), (200, 64, 3), (30, 20, 7), (100, 64, 16), (64, 32, 27), (64, 64, 16), (300, 128, 13))      # (9..16 chains: two master workgroups)
 if len(sys.argv) > 2:        # "a:b": a slice of the shapes
     a_, b_ = (int(x) for x in sys.argv[2].split(":"))
     SHAPES = SHAPES[a_:b_]
