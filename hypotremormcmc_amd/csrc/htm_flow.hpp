@@ -1412,6 +1412,11 @@ __device__ __forceinline__ bool flow_body(FwRef f_, CsRef cs_, int target_arg, i
             if (code && lds_ld(&sh.last_iter) > iter) { sh.stop_code = code; lds_st(&sh.last_iter, iter); }
             }
         }
+        if constexpr (MB) {
+            // (chain 0's wave, all lanes: its own view of the launch's end at once -- its next look may still return the old word)
+            if (wave == 0 && c == 0 && mw.last_iter > iter &&
+                (mw.n_lik + 5 * nc > cs.cap_lik || mw.n_smp + 5 * nc > cs.cap_smp || sh.avail < p + 3 * wd + 32)) mw.last_iter = iter;
+        }
         // the window covers this step (chain 0's wave keeps it 3 iterations ahead); a fail-stop, never expected to wait
         if (__builtin_expect(!known && (p < 0 || p + 16 >= lds_ld(&sh.fill)), 0)) {      // (a known start was checked against the window when it was looked up)
             if (wave == 0) { if (lane == 0) sh.c.err = -13; break; }
