@@ -116,7 +116,15 @@ enum { MW_EPOCH = 0, MW_LAST = 1, MW_ERR = 2, MW_STOP = 3, MW_NLIK = 4, MW_NSMP 
 struct MbWave {                   // what a chain wave of a multi-block launch saw with its latest look at MbShared
     int epoch, last_iter, err, n_lik, n_smp;
     unsigned long long pv;        // lane < n_chains: prog[lane]
+#ifdef HTM_MB_DIAG
+    unsigned hist;                // diagnostics (tools/mb_steplog.py): a nibble per event of the current step -- 0kee entered in epoch ee (k: start known from the look-ahead), 10ee adopted ee at the top, 11ee adopted ee in the turn
+#endif
 };
+#ifdef HTM_MB_DIAG
+#define MB_HIST(mw_, nib_) do { (mw_).hist = ((mw_).hist << 4) | (unsigned)(nib_); } while (0)
+#else
+#define MB_HIST(mw_, nib_) do { } while (0)
+#endif
 // one look: lane < nc: prog[lane]; lanes 59..63: words 4, 5 (records written), 0 (epoch), 1 (last iteration), 2 (failure)
 __device__ __forceinline__ unsigned long long mb_look(const MbShared *g, int nc, int lane)
 {
@@ -826,6 +834,7 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
             if (__builtin_expect(e != W.epoch, 0)) {
                 bool stands = false;
                 if (!flow_adopt<MB>(cs, sh, rg, W, e, iter, c, true, stands, g_mb)) { if (MB) __builtin_amdgcn_s_sleep(1); continue; }
+                if constexpr (MB) MB_HIST(mw, 0xC | (e & 3));
                 flow_void_books(cs, sh, wave, NW, nc_, lane);
                 if (!stands) return kFlowRestart;
                 continue;
@@ -1107,7 +1116,12 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
         if (lane == 0 && row < sh.c.slog_cap) {
             int32_t *ir = cs.slog_i + 8 * (size_t)row;
             double *dr = cs.slog_d + 4 * (size_t)row;
-            ir[0] = iter; ir[1] = c; ir[2] = type; ir[3] = idx + 1; ir[4] = ok; ir[5] = acc; ir[6] = need_full; ir[7] = 0;
+            ir[0] = iter; ir[1] = c; ir[2] = type; ir[3] = idx + 1; ir[4] = ok; ir[5] = acc; ir[6] = need_full;
+            // (several master workgroups: where the step started and the epoch it was committed in -- diagnostics, tools/mb_steplog.py)
+            ir[7] = MB ? (int)(((unsigned)p & 0xffffffu) | (((unsigned)W.epoch & 0xffu) << 24)) : 0;
+#ifdef HTM_MB_DIAG
+            if constexpr (MB) { ir[6] = need_full | (int)((mw.hist & 0xfffffu) << 4) | (int)(((unsigned)(p - W.rpos) & 0x7fu) << 24); }
+#endif
             dr[0] = x_new; dr[1] = L_new; dr[2] = L_post; dr[3] = T;
         }
     }
@@ -1340,6 +1354,9 @@ __device__ __forceinline__ bool flow_body(FwRef f_, CsRef cs_, int target_arg, i
     int c = MB ? 8 * mb_b + wave : wave;
     bool alive = MB ? (wave < 8 && c < nc) : (wave < nc && wave < NW);
     MbWave mw;
+#ifdef HTM_MB_DIAG
+    mw.hist = 0u;
+#endif
     mw.epoch = 0; mw.last_iter = sh.c.iter_target; mw.err = 0; mw.n_lik = sh.c.n_lik; mw.n_smp = sh.c.n_smp; mw.pv = 0ull;
 #ifdef HTM_STAMPS
     const unsigned long long t_loop0 = __builtin_amdgcn_s_memtime();
@@ -1371,6 +1388,7 @@ __device__ __forceinline__ bool flow_body(FwRef f_, CsRef cs_, int target_arg, i
                     continue;
                 }
                 flow_void_books(cs, sh, MB ? c : wave, MB ? 64 : NW, nc, lane);
+                if constexpr (MB) MB_HIST(mw, 0x8 | (e & 3));
                 continue;      // (the book read above is void with it: from the top)
             }
         }
@@ -1439,11 +1457,15 @@ __device__ __forceinline__ bool flow_body(FwRef f_, CsRef cs_, int target_arg, i
             else __builtin_amdgcn_s_setprio(0);
         }
         // (several master workgroups: a wave has one chain -- "wave" c of as many waves as there are chains)
+        if constexpr (MB) MB_HIST(mw, (known ? 4 : 0) | (W.epoch & 3));
         const int r = flow_step<NCH, F32, LOCK, MB>(f, cs, sh, rg, W, nx, g_mb, mw, s_gath, wmax, s_sx, s_sy, s_sz, c, p, iter, lane, MB ? c : wave,
                                               MB ? 64 : NW, launch, wave == 0, look, back, rec_phase == 1, tp);
         if (r == kFlowRestart) continue;
         if (r == kFlowAbort || r == kFlowStop) break;
         // ---- this wave's next step
+#ifdef HTM_MB_DIAG
+        mw.hist = 0u;
+#endif
         c += MB ? nc : NW;
         if (c >= nc) {
             c = MB ? 8 * mb_b + wave : wave;

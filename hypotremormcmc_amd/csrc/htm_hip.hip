@@ -922,10 +922,19 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
     // (sized by what an iteration can really draw, 6 per chain step + the swap's, not by wmax's rounding to 64: at 16 chains
     // the two-iteration window then fits a 512-position ring instead of 1024 -- half the LDS, so the mirror fits too)
     const int wdraw = 6 * nc + 16;
-    auto ring_for = [&](int look) { int r = 256; while (r < look * wdraw + 64) r *= 2; return r; };
+    // Several master workgroups (9..16 chains, k_mcmc<.., 7>): a workgroup's window is kept by the wave of its FIRST chain, and
+    // that chain can be two iterations ahead of a chain of its own workgroup that sat in a full evaluation (its turn asks the
+    // later chains for their checks of the iteration before only).  The late chain then adopts an anchor that lies up to three
+    // iterations behind the keeper's position: the ring must hold the look-ahead (3 wd + 24) AND three iterations + the spread of
+    // eight chains behind it, or the anchor's table entries have been overwritten by positions one ring further on (the
+    // mismatch of profiles/r04_z_mb_open_issue.txt: a base computed from evicted entries).  With two chains per wave -- one
+    // workgroup -- the keeper cannot get further than one iteration ahead, and up to eight chains leave the ring mostly empty.
+    const int mb_need = (3 * wdraw + 24) + (3 * wdraw + 16) + 6 * 8 + 16;
+    bool mb_want = nc > 8 && nc <= 16 && d.n_procs == 1 && (h->nch == 1 || h->nch == 2) && !(getenv("HTM_MB") && getenv("HTM_MB")[0] == '0');
+    auto ring_for = [&](int look) { int r = 256; while (r < look * wdraw + 64 || (mb_want && r < mb_need)) r *= 2; return r; };
     hc->dev.mirror_n = 0; hc->dev.mirror_steps = 0;
-    hc->ring_size = ring_for(2);
-    {
+    for (int pass = 0; pass < 2; ++pass) {
+        hc->ring_size = ring_for(2);
         // preference: long window + values + step sizes, long window + values, short window + both, short + values, nothing
         const int looks[4] = {4, 4, 2, 2}, steps[4] = {1, 0, 1, 0};
         for (int k = 0; k < 4; ++k)
@@ -933,6 +942,8 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
                 hc->ring_size = ring_for(looks[k]); hc->dev.mirror_n = (int)mir; hc->dev.mirror_steps = steps[k];
                 break;
             }
+        if (hc->dev.mirror_n > 0 || !mb_want) break;
+        mb_want = false;      // (the longer ring does not fit beside the mirror: one workgroup, the usual ring)
     }
     hc->step_smem = lds_fixed + (size_t)hc->ring_size * lds_pos + (1 + hc->dev.mirror_steps) * (size_t)hc->dev.mirror_n * sizeof(double);
     if (hc->step_smem > lds_cap) return cleanup(fail(HTM_EINVAL, "n_chains / n_sta too large for k_step's LDS budget"));
@@ -993,10 +1004,8 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
         // More than eight chains on a rank: a master workgroup for every eight (k_mcmc<.., 7>, htm_flow.hpp MbShared) instead of
         // rounds on the same eight waves.
         {
-            // (opt-in, HTM_MB=1: one run in four of ONE rejection-heavy stress configuration -- 100 x 64 x 16, depth steps of 20 -- differs
-            // from the oracle in one chain's log-likelihood from iteration 8539 on, cause not found: DESIGN.md 9)
-            const char *em = getenv("HTM_MB");
-            const bool on = em && em[0] == '1';
+            // (HTM_MB=0: one workgroup.  The ring was sized for several above: mb_want, mb_need)
+            const bool on = mb_want && hc->ring_size >= mb_need;
             // (9..16 chains: two workgroups.  More would need more of the stream window per step than the one wave of a workgroup that
             // keeps it can load -- 128 positions, an iteration of 16 chains takes ~90)
             if (hc->flow && on && nc > 8 && nc <= 16 && (h->nch == 1 || h->nch == 2)) {
