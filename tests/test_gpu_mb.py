@@ -1,5 +1,5 @@
 """GPU parity of SEVERAL MASTER WORKGROUPS in one launch (csrc/htm_flow.hpp MbShared, k_mcmc<.., 7>; 9..16 chains on a rank: two
-workgroups of eight chain waves; opt-in: HTM_MB=1): what the chains of a rank share -- checks, epoch and anchor, the swap, the
+workgroups of eight chain waves; the default there, HTM_MB=0: one workgroup): what the chains of a rank share -- checks, epoch and anchor, the swap, the
 end of the launch -- goes through memory instead of LDS, so the runs that matter are the rejection-heavy ones (every Rayleigh
 rejection, src/cls_model.f90:178-181, is an epoch change every chain of the other workgroup has to learn from memory) and the
 ones cut into many launches.  Criteria as in tests/test_gpu_chains.py: the oracle step by step, bit-equality with the single
@@ -11,9 +11,9 @@ from tests.test_gpu_chains import RTOL_TRACE, _build_world
 
 import os
 
-# The path is opt-in (HTM_MB=1) and so are its tests (HTM_TEST_MB=1): one run in four of one stress configuration
-# (tools/mb_repro.py: 100 x 64 x 16, depth steps of 20, 20 000 iterations) still differs from the oracle, DESIGN.md 9.
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("HTM_TEST_MB") != "1", reason="two master workgroups are opt-in: HTM_TEST_MB=1")]
+# (The one stress configuration that used to differ from the oracle in one run of seven -- tools/mb_repro.py: 100 x 64 x 16, depth
+# steps of 20 -- is test_the_configuration_that_used_to_differ below; what it was: DESIGN.md 3.0, profiles/r04_y_mb_steplog_*.txt.)
+pytestmark = [pytest.mark.gpu]
 
 
 def _job(E, S, nc, seed, sz, n_iter, **kw):
@@ -91,3 +91,30 @@ def test_two_master_workgroups_checkpoint_and_fp32(monkeypatch):
         _, s = _build_world(data, dict(params, forward_precision="fp32")); s[0].run(600)
         out.append((s[0].likelihood_trace(), s[0].rng_state()))
     assert all(np.array_equal(x, y) for x, y in zip(out[0][0], out[1][0])) and out[0][1] == out[1][1]
+
+
+def test_the_configuration_that_used_to_differ(monkeypatch):
+    """100 x 64 x 16, depth steps of 20 (tools/mb_repro.py): a chain late from a full evaluation adopts an anchor up to three
+    iterations behind the wave that keeps its workgroup's stream window -- the window must still hold it (csrc/htm_hip.hip:
+    mb_need).  With a 512-position ring one run in seven took ONE step of chain 2 from a wrong stream position (iterations
+    5171, 5636, 6596, 7283, 8537, ...); every step of several runs against the oracle's step log."""
+    from oracle import oracle
+
+    monkeypatch.setenv("HTM_MB", "1")
+    n_iter = 9000
+    data, params = _job(100, 64, 16, 4, 20.0, n_iter)
+    job = oracle.Job(params, data); job.enable_steplog(n_iter * 16); job.run(n_iter)
+    oi, od = job.steplog()
+    for run in range(6):
+        _, sets = _build_world(data, params)
+        cs = sets[0]
+        assert cs.master_stats()["single_rank_loop"] == 7, "two master workgroups were not selected"
+        cs.enable_steplog(n_iter * 16)
+        cs.run(n_iter)
+        gi, gd = cs.steplog()
+        assert len(gi) == len(oi)
+        assert np.array_equal(gi[:, 0], oi[:, 0]) and np.array_equal(gi[:, 1], oi[:, 2]), run
+        assert np.array_equal(gi[:, 2:7], oi[:, 3:8]), "run %d: a step differs (type / element / prior check / decision)" % run
+        np.testing.assert_allclose(gd[:, 2], od[:, 2], rtol=RTOL_TRACE)
+        assert cs.rng_state() == job.rng_state(0)
+        del cs, sets
