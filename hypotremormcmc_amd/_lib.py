@@ -42,6 +42,7 @@ SIGNATURES = {
     "htm_last_error": (C.c_char_p, []),
     "htm_abi_version": (C.c_int, []),
     "htm_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "htm_device_physical_id": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
     "htm_forward_create": (C.c_int, [C.c_int, C.c_int] + [dp] * 7 + [C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
     "htm_forward_destroy": (C.c_int, [vp]),
     "htm_forward_set_precision": (C.c_int, [vp, C.c_int]),

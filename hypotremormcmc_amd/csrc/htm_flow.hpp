@@ -1117,9 +1117,11 @@ __device__ __forceinline__ int flow_step(FwRef f_, CsRef cs_, FlowShared &sh, co
             int32_t *ir = cs.slog_i + 8 * (size_t)row;
             double *dr = cs.slog_d + 4 * (size_t)row;
             ir[0] = iter; ir[1] = c; ir[2] = type; ir[3] = idx + 1; ir[4] = ok; ir[5] = acc; ir[6] = need_full;
-            // (several master workgroups: where the step started and the epoch it was committed in -- diagnostics, tools/mb_steplog.py)
-            ir[7] = MB ? (int)(((unsigned)p & 0xffffffu) | (((unsigned)W.epoch & 0xffu) << 24)) : 0;
+            ir[7] = 0;
 #ifdef HTM_MB_DIAG
+            // (several master workgroups, diagnostic build: where the step started, the epoch it was committed in, the step's history
+            // of epoch adoptions and its distance from the wave's reference position -- tools/mb_steplog.py)
+            if constexpr (MB) { ir[7] = (int)(((unsigned)p & 0xffffffu) | (((unsigned)W.epoch & 0xffu) << 24)); }
             if constexpr (MB) { ir[6] = need_full | (int)((mw.hist & 0xfffffu) << 4) | (int)(((unsigned)(p - W.rpos) & 0x7fu) << 24); }
 #endif
             dr[0] = x_new; dr[1] = L_new; dr[2] = L_post; dr[3] = T;

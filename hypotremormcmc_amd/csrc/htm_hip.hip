@@ -396,6 +396,19 @@ int htm_device_count(int *n)
     return HTM_OK;
 }
 
+int htm_device_physical_id(int device, int *id)
+{
+    if (!id) return fail(HTM_EINVAL, "id is NULL");
+    *id = -1;
+    int dom = 0, bus = 0, dv = 0;
+    if (hipDeviceGetAttribute(&dom, hipDeviceAttributePciDomainID, device) != hipSuccess ||
+        hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, device) != hipSuccess ||
+        hipDeviceGetAttribute(&dv, hipDeviceAttributePciDeviceId, device) != hipSuccess)
+        return fail(HTM_ENODEVICE, "no PCI address for HIP device %d", device);
+    *id = ((dom & 0x7fff) << 16) | ((bus & 0xff) << 8) | (dv & 0xff);
+    return HTM_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------
 int htm_forward_create(int n_sta, int n_events, const double *sta_x, const double *sta_y, const double *sta_z,
                        const double *t_obs, const double *t_stdv, const double *a_obs, const double *a_stdv,

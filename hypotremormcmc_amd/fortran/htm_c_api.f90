@@ -15,7 +15,7 @@ module htm_c_api
   public :: htm_chains_xchg_handle, htm_chains_xchg_connect, htm_chains_xchg_probe, htm_chains_run_lockstep_direct
   public :: HTM_XCHG_HANDLE_BYTES, HTM_COMM_ID_BYTES
   public :: htm_comm_unique_id, htm_comm_create, htm_comm_destroy, htm_chains_run_lockstep_comm
-  public :: htm_device_count, htm_quantiles, htm_select_regress
+  public :: htm_device_count, htm_device_physical_id, htm_quantiles, htm_select_regress
   public :: htm_chains_checkpoint_size, htm_chains_checkpoint_save, htm_chains_checkpoint_load
 
   integer(c_size_t), parameter :: HTM_XCHG_HANDLE_BYTES = 64_c_size_t, HTM_COMM_ID_BYTES = 128_c_size_t
@@ -250,6 +250,12 @@ module htm_c_api
        integer(c_int), intent(out) :: n
        integer(c_int) :: rc
      end function htm_device_count
+     function htm_device_physical_id(device, id) bind(C, name="htm_device_physical_id") result(rc)
+       import :: c_int
+       integer(c_int), value :: device
+       integer(c_int), intent(out) :: id
+       integer(c_int) :: rc
+     end function htm_device_physical_id
 
      !> checkpoint / resume (include/htm_hip.h); blob = c_loc of a byte buffer of htm_chains_checkpoint_size bytes
      function htm_chains_checkpoint_size(handle, bytes) bind(C, name="htm_chains_checkpoint_size") result(rc)

@@ -186,15 +186,19 @@ program hypo_tremor_mcmc_hip
   ! Ranks that share a GPU (fewer GPUs than ranks on a node): every rank's persistent launch must be resident at once, so each
   ! takes its share of the CUs.  The ranks of this node tell each other which device they use.
   block
-    integer :: node_comm, n_node, k, same
+    integer :: node_comm, n_node, k, same, my_gpu
+    integer(c_int) :: pci
     integer, allocatable :: devs(:)
     call mpi_comm_split_type(MPI_COMM_WORLD, MPI_COMM_TYPE_SHARED, 0, MPI_INFO_NULL, node_comm, ierr)
     call mpi_comm_size(node_comm, n_node, ierr)
     allocate(devs(n_node))
-    call mpi_allgather(int(htm_default_device), 1, MPI_INTEGER, devs, 1, MPI_INTEGER, node_comm, ierr)
+    ! (the GPU by its PCI address, not by its ordinal: with a visible-devices mask per rank every rank's ordinal is 0)
+    my_gpu = -1 - int(htm_default_device)
+    if (htm_device_physical_id(int(max(0, htm_default_device), c_int), pci) == 0) my_gpu = int(pci)
+    call mpi_allgather(my_gpu, 1, MPI_INTEGER, devs, 1, MPI_INTEGER, node_comm, ierr)
     same = 0
     do k = 1, n_node
-       if (devs(k) == int(htm_default_device)) same = same + 1
+       if (devs(k) == my_gpu) same = same + 1
     end do
     if (same > 1) call check(htm_chains_share_gpu(chains, int(same, c_int)), "htm_chains_share_gpu")
     call mpi_comm_free(node_comm, ierr)

@@ -102,7 +102,15 @@ class TorchWorld:
             return
         import socket
 
-        mine = (socket.gethostname(), int(self.r.cs.fwd.device))
+        # (the GPU by its PCI address, not by its ordinal: with a visible-devices mask per rank every rank's ordinal is 0)
+        import ctypes
+        from . import _lib
+
+        pid = ctypes.c_int(-1)
+        dev = int(self.r.cs.fwd.device)
+        if _lib.load().htm_device_physical_id(dev, ctypes.byref(pid)) != 0:
+            pid.value = -1 - dev
+        mine = (socket.gethostname(), int(pid.value))
         where = [None] * self.world
         self.dist.all_gather_object(where, mine, group=self.group)
         k = sum(1 for w in where if tuple(w) == mine)

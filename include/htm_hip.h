@@ -46,6 +46,10 @@ typedef struct htm_chains  htm_chains;
 const char *htm_last_error(void);
 int         htm_abi_version(void);          /* bumped when this header changes incompatibly */
 int         htm_device_count(int *n);       /* number of visible HIP devices */
+/* The GPU behind a device ordinal as (PCI domain << 16 | bus << 8 | device): the same number in every process that sees this
+ * GPU, whatever ordinal HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES gave it there -- what ranks compare to find out that they
+ * share a GPU (htm_chains_share_gpu; the reference has one MPI rank per CPU core and no such notion, src/mod_mpi.f90). */
+int         htm_device_physical_id(int device, int *id);
 
 /* ------------------------------------------------------------------------------------------------
  * `type forward`                                                  reference: src/cls_forward.f90
