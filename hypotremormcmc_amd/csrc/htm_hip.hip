@@ -944,7 +944,13 @@ int htm_chains_create(htm_forward *h, const htm_chains_init *init, htm_chains **
     // workgroup -- the keeper cannot get further than one iteration ahead, and up to eight chains leave the ring mostly empty.
     const int mb_need = (3 * wdraw + 24) + (3 * wdraw + 16) + 6 * 8 + 16;
     bool mb_want = nc > 8 && nc <= 16 && d.n_procs == 1 && (h->nch == 1 || h->nch == 2) && !(getenv("HTM_MB") && getenv("HTM_MB")[0] == '0');
-    auto ring_for = [&](int look) { int r = 256; while (r < look * wdraw + 64 || (mb_want && r < mb_need)) r *= 2; return r; };
+    // The same rule for the free-running loop of ONE workgroup with a wave per chain (up to eight chains; single rank and lock-step
+    // ranks): the keeper's wave runs chain 0 only and gets as far ahead of a late chain.  (More than eight chains on one
+    // workgroup: the keeper's wave has two chains and meets every other chain's check within an iteration.)  Rings of 256
+    // positions -- 4 and 5 chains -- were too short for it by this count; HTM_RING_SLACK=0 keeps the old sizes (A/B only).
+    const bool slack = !(getenv("HTM_RING_SLACK") && getenv("HTM_RING_SLACK")[0] == '0');
+    const int fr_need = (nc <= 8 && slack) ? (3 * wdraw + 24) + (3 * wdraw + 16) : 0;
+    auto ring_for = [&](int look) { int r = 256; while (r < look * wdraw + 64 || r < fr_need || (mb_want && r < mb_need)) r *= 2; return r; };
     hc->dev.mirror_n = 0; hc->dev.mirror_steps = 0;
     for (int pass = 0; pass < 2; ++pass) {
         hc->ring_size = ring_for(2);
