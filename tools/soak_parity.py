@@ -15,7 +15,8 @@ from oracle import oracle
 n1 = int(sys.argv[1]) if len(sys.argv) > 1 else 60000
 n2 = int(sys.argv[2]) if len(sys.argv) > 2 else 200000
 bad = 0
-for (E, S, nc, n_iter, seed) in ((1000, 64, 8, n1, 7), (64, 64, 8, n2, 8), (64, 64, 5, n2, 9)):
+# (16 chains: two master workgroups; 4 and 5 chains: the rings that grew from 256 to 512 positions)
+for (E, S, nc, n_iter, seed) in ((1000, 64, 8, n1, 7), (64, 64, 8, n2, 8), (64, 64, 5, n2, 9), (1000, 64, 16, n1 // 2, 11), (64, 64, 16, n2, 12), (64, 64, 4, n2, 13)):
     data = synth.make_synthetic(E, S, seed)
     params = dict(synth.DEFAULT_PARAMS, n_procs=1, n_chains=nc, n_cool=2, n_iter=n_iter, n_burn=n_iter // 2, n_interval=50)
     t0 = time.time()
